@@ -1,0 +1,463 @@
+"""CPU oracle (numpy, float64) for the rcognita hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package ``rcognita_amd`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do,
+and there only as the checker.
+
+This is a restatement of the reference algorithm, not a copy: every function works on arrays with
+arbitrary leading batch dimensions (``[..., ds]``) instead of the reference's one-env-at-a-time
+1-D arrays.  Each function cites the reference lines it follows (paths relative to
+``/root/reference``).
+
+Parity status: the reference has no tests and no golden vectors, so this oracle is
+pinned against outputs of the reference itself, generated in the build container by
+``oracle/gen_fixtures.py`` and committed under ``tests/golden/`` (checked by
+``tests/test_oracle_golden.py``).
+
+Third-party arithmetic on the reference path that is NOT under /root/reference:
+``scipy.integrate.RK45`` (setup.py pins ``scipy >= 1.5.0``; installed 1.15.3) and
+``scipy.optimize.minimize(method='SLSQP')``.  The fixed-step RK4 and candidate-argmin used by the
+GPU path are the build's own definitions; they are restated here so
+the HIP kernels have a bit-level-comparable CPU twin, and are compared against reference RK45
+trajectories (constant action) in the golden tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# System table (rcognita/systems.py:255-428)
+# ----------------------------------------------------------------------------------------------
+SYS_3WROBOT = 0
+SYS_3WROBOT_NI = 1
+SYS_2TANK = 2
+
+SYS_NAMES = {SYS_3WROBOT: "3wrobot", SYS_3WROBOT_NI: "3wrobotNI", SYS_2TANK: "2tank"}
+SYS_DIMS = {  # sys_id -> (dim_state, dim_input, n_pars); dim_output == dim_state for all three
+    SYS_3WROBOT: (5, 2, 2),
+    SYS_3WROBOT_NI: (3, 2, 0),
+    SYS_2TANK: (2, 1, 5),
+}
+
+MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
+MODE_IDS = {"MPC": MODE_MPC, "RQL": MODE_RQL, "SQL": MODE_SQL}
+
+STAGE_QUADRATIC, STAGE_BIQUADRATIC = 0, 1
+STAGE_IDS = {"quadratic": STAGE_QUADRATIC, "biquadratic": STAGE_BIQUADRATIC}
+
+CRITIC_QUAD_LIN, CRITIC_QUADRATIC, CRITIC_QUAD_NOMIX, CRITIC_QUAD_MIX = 0, 1, 2, 3
+CRITIC_IDS = {
+    "quad-lin": CRITIC_QUAD_LIN,
+    "quadratic": CRITIC_QUADRATIC,
+    "quad-nomix": CRITIC_QUAD_NOMIX,
+    "quad-mix": CRITIC_QUAD_MIX,
+}
+
+
+def dim_critic(critic_struct: int, dim_output: int, dim_input: int) -> int:
+    """Number of critic weights (rcognita/controllers.py:1024-1039)."""
+    n = dim_output + dim_input
+    if critic_struct == CRITIC_QUAD_LIN:
+        return n * (n + 1) // 2 + n
+    if critic_struct == CRITIC_QUADRATIC:
+        return n * (n + 1) // 2
+    if critic_struct == CRITIC_QUAD_NOMIX:
+        return n
+    if critic_struct == CRITIC_QUAD_MIX:
+        return dim_output + dim_output * dim_input + dim_input
+    raise ValueError(critic_struct)
+
+
+def critic_bounds(critic_struct: int, dc: int):
+    """(Wmin, Wmax) (rcognita/controllers.py:1026-1039)."""
+    if critic_struct in (CRITIC_QUAD_LIN, CRITIC_QUAD_MIX):
+        return -1e3 * np.ones(dc), 1e3 * np.ones(dc)
+    return np.zeros(dc), 1e3 * np.ones(dc)
+
+
+@dataclass
+class OracleCfg:
+    """Everything the path needs besides per-env data.  Mirrors ``rcg_cfg`` in include/rcg.h."""
+
+    sys_id: int
+    n_actor: int = 5
+    mode: int = MODE_MPC
+    gamma: float = 1.0
+    pred_step_size: float = 0.02
+    dt_sim: float = 0.01
+    substeps_per_tick: int = 1
+    sampling_time: float = 0.01
+    pars: Sequence[float] = ()
+    ctrl_bnds: Optional[np.ndarray] = None  # [du, 2]
+    R1: Optional[np.ndarray] = None  # [n, n]
+    R2: Optional[np.ndarray] = None  # [n, n]
+    stage_obj_struct: int = STAGE_QUADRATIC
+    target: Optional[np.ndarray] = None  # None <=> reference's ``observation_target == []``
+    critic_struct: int = CRITIC_QUAD_NOMIX
+    n_critic: int = 4
+    buffer_size: int = 10
+    ref_lag: bool = False  # rollout starts from the previous sim step's state
+    accum_every_substep: bool = False  # reference quirk, Appendix A-5
+
+    def __post_init__(self):
+        ds, du, npar = SYS_DIMS[self.sys_id]
+        self.pars = np.asarray(self.pars, dtype=np.float64)
+        assert self.pars.shape[-1] == npar if npar else True
+        if self.ctrl_bnds is not None:
+            self.ctrl_bnds = np.asarray(self.ctrl_bnds, dtype=np.float64).reshape(du, 2)
+        n = ds + du
+        if self.R1 is None:
+            self.R1 = np.eye(n)
+        self.R1 = np.asarray(self.R1, dtype=np.float64).reshape(n, n)
+        if self.R2 is not None:
+            self.R2 = np.asarray(self.R2, dtype=np.float64).reshape(n, n)
+        if self.target is not None:
+            self.target = np.asarray(self.target, dtype=np.float64).reshape(ds)
+        # Ncritic = min(Ncritic, buffer_size - 1)  (rcognita/controllers.py:1015)
+        self.n_critic = int(min(self.n_critic, self.buffer_size - 1))
+
+    @property
+    def ds(self):
+        return SYS_DIMS[self.sys_id][0]
+
+    @property
+    def du(self):
+        return SYS_DIMS[self.sys_id][1]
+
+    @property
+    def dc(self):
+        return dim_critic(self.critic_struct, self.ds, self.du)
+
+
+# ----------------------------------------------------------------------------------------------
+# Environment: right-hand sides
+# ----------------------------------------------------------------------------------------------
+def state_dyn(sys_id: int, state, action, pars):
+    """``Sys*._state_dyn`` without disturbance.
+
+    3wrobot   rcognita/systems.py:308-323   pars = (m, I)
+    3wrobotNI rcognita/systems.py:370-382   no pars
+    2tank     rcognita/systems.py:412-419   pars = (tau1, tau2, K1, K2, K3)
+
+    ``state [..., ds]``, ``action [..., du]``, ``pars [..., np]`` (broadcastable) -> ``[..., ds]``.
+    The action is used as given: no clipping here (the rollout in ``_actor_cost`` calls this
+    directly, rcognita/controllers.py:1294).
+    """
+    state = np.asarray(state, dtype=np.float64)
+    action = np.asarray(action, dtype=np.float64)
+    pars = np.asarray(pars, dtype=np.float64)
+    shape = np.broadcast_shapes(state.shape[:-1], action.shape[:-1], pars.shape[:-1])
+    d = np.zeros(shape + (state.shape[-1],))
+    if sys_id == SYS_3WROBOT:
+        m, inertia = pars[..., 0], pars[..., 1]
+        d[..., 0] = state[..., 3] * np.cos(state[..., 2])
+        d[..., 1] = state[..., 3] * np.sin(state[..., 2])
+        d[..., 2] = state[..., 4]
+        d[..., 3] = 1 / m * action[..., 0]
+        d[..., 4] = 1 / inertia * action[..., 1]
+    elif sys_id == SYS_3WROBOT_NI:
+        d[..., 0] = action[..., 0] * np.cos(state[..., 2])
+        d[..., 1] = action[..., 0] * np.sin(state[..., 2])
+        d[..., 2] = action[..., 1]
+    elif sys_id == SYS_2TANK:
+        tau1, tau2, K1, K2, K3 = (pars[..., i] for i in range(5))
+        d[..., 0] = 1 / tau1 * (-state[..., 0] + K1 * action[..., 0])
+        d[..., 1] = 1 / tau2 * (-state[..., 1] + K2 * state[..., 0] + K3 * state[..., 1] ** 2)
+    else:
+        raise ValueError(sys_id)
+    return d
+
+
+def clip_action(action, ctrl_bnds):
+    """Box clip applied by ``closed_loop_rhs`` (rcognita/systems.py:241-243).
+
+    The reference clips iff ``ctrl_bnds.any()``; an all-zero bounds array means "unconstrained".
+    Returned as a value (the reference mutates the stored array in place, SURVEY §8b Ownership).
+    """
+    action = np.asarray(action, dtype=np.float64)
+    if ctrl_bnds is None or not np.any(ctrl_bnds):
+        return action
+    return np.clip(action, ctrl_bnds[:, 0], ctrl_bnds[:, 1])
+
+
+def closed_loop_rhs(sys_id: int, state, action, pars, ctrl_bnds):
+    """``System.closed_loop_rhs`` for ``is_disturb = is_dyn_ctrl = 0`` (rcognita/systems.py:213-253).
+
+    Returns ``(rhs, clipped_action)``.
+    """
+    a = clip_action(action, ctrl_bnds)
+    return state_dyn(sys_id, state, a, pars), a
+
+
+def rk4_step(sys_id: int, state, action, pars, ctrl_bnds, h: float):
+    """One classical RK4 step of the closed loop under a zero-order-held action.
+
+    Build-defined replacement of scipy RK45 inside ``Simulator.sim_step``
+    (rcognita/simulator.py:156-168).  The clip is evaluated in every stage,
+    as the reference's RHS does; with a held action it is the same value each time.
+    """
+    k1, _ = closed_loop_rhs(sys_id, state, action, pars, ctrl_bnds)
+    k2, _ = closed_loop_rhs(sys_id, state + (0.5 * h) * k1, action, pars, ctrl_bnds)
+    k3, _ = closed_loop_rhs(sys_id, state + (0.5 * h) * k2, action, pars, ctrl_bnds)
+    k4, _ = closed_loop_rhs(sys_id, state + h * k3, action, pars, ctrl_bnds)
+    return state + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+
+
+# ----------------------------------------------------------------------------------------------
+# Controller: stage objective, critic, actor cost
+# ----------------------------------------------------------------------------------------------
+def _chi(obs, act, target):
+    obs = np.asarray(obs, dtype=np.float64)
+    act = np.asarray(act, dtype=np.float64)
+    shape = np.broadcast_shapes(obs.shape[:-1], act.shape[:-1])
+    obs = np.broadcast_to(obs, shape + obs.shape[-1:])
+    act = np.broadcast_to(act, shape + act.shape[-1:])
+    if target is None:
+        return np.concatenate([obs, act], axis=-1)
+    return np.concatenate([obs - target, act], axis=-1)
+
+
+def stage_obj(obs, act, cfg: OracleCfg):
+    """``CtrlOptPred.stage_obj`` (rcognita/controllers.py:1063-1084)."""
+    chi = _chi(obs, act, cfg.target)
+    quad = np.einsum("...i,ij,...j->...", chi, cfg.R1, chi)
+    if cfg.stage_obj_struct == STAGE_QUADRATIC:
+        return quad
+    chi2 = chi**2
+    return np.einsum("...i,ij,...j->...", chi2, cfg.R2, chi2) + quad
+
+
+def critic_features(obs, act, cfg: OracleCfg):
+    """Regressor of ``CtrlOptPred._critic`` (rcognita/controllers.py:1200-1212).
+
+    ``uptria2vec`` is the row-major upper triangle incl. diagonal (rcognita/utilities.py:81-96).
+    ``quad-mix`` uses the raw observation; the target is ignored there (controllers.py:1212).
+    """
+    chi = _chi(obs, act, cfg.target)
+    n = chi.shape[-1]
+    cs = cfg.critic_struct
+    if cs in (CRITIC_QUAD_LIN, CRITIC_QUADRATIC):
+        iu, ju = np.triu_indices(n)
+        quad = chi[..., iu] * chi[..., ju]
+        if cs == CRITIC_QUADRATIC:
+            return quad
+        return np.concatenate([quad, chi], axis=-1)
+    if cs == CRITIC_QUAD_NOMIX:
+        return chi * chi
+    if cs == CRITIC_QUAD_MIX:
+        obs = np.asarray(obs, dtype=np.float64)
+        act = np.asarray(act, dtype=np.float64)
+        shape = np.broadcast_shapes(obs.shape[:-1], act.shape[:-1])
+        obs = np.broadcast_to(obs, shape + obs.shape[-1:])
+        act = np.broadcast_to(act, shape + act.shape[-1:])
+        kron = (obs[..., :, None] * act[..., None, :]).reshape(shape + (-1,))
+        return np.concatenate([obs**2, kron, act**2], axis=-1)
+    raise ValueError(cs)
+
+
+def critic(obs, act, w, cfg: OracleCfg):
+    """``CtrlOptPred._critic`` = ``w @ regressor`` (rcognita/controllers.py:1192-1214)."""
+    return np.sum(np.asarray(w, dtype=np.float64) * critic_features(obs, act, cfg), axis=-1)
+
+
+def actor_cost(action_sqn, obs, state_sys, cfg: OracleCfg, pars=None, w_critic=None):
+    """``CtrlOptPred._actor_cost`` for ``is_est_model = 0`` (rcognita/controllers.py:1273-1328).
+
+    ``action_sqn [..., N*du]`` or ``[..., N, du]``; ``obs [..., dy]``; ``state_sys [..., ds]``.
+    Explicit-Euler rollout with ``pred_step_size`` from ``state_sys`` using the unclipped
+    ``_state_dyn`` (controllers.py:1290-1296), ``observation_sqn[0] = obs``; then
+    MPC  sum_{k<N} gamma^k rho(y_k,u_k)                       (controllers.py:1304-1306)
+    RQL  sum_{k<N-1} gamma^k rho + Q_w(y_{N-1}, u_{N-1})        (controllers.py:1307-1310)
+    SQL  sum_{k<N} Q_w(y_k,u_k), undiscounted                   (controllers.py:1311-1326)
+    """
+    N, du, ds = cfg.n_actor, cfg.du, cfg.ds
+    pars = cfg.pars if pars is None else pars
+    u = np.asarray(action_sqn, dtype=np.float64)
+    if not (u.ndim >= 2 and u.shape[-2:] == (N, du)):
+        # flat, step-major [N*du] as the reference passes it (controllers.py:1284)
+        u = u.reshape(u.shape[:-1] + (N, du))
+    obs = np.asarray(obs, dtype=np.float64)
+    state = np.asarray(state_sys, dtype=np.float64)
+    y = obs  # y_0
+    J = 0.0
+    g = 1.0
+    for k in range(N):
+        if k > 0:
+            state = state + cfg.pred_step_size * state_dyn(cfg.sys_id, state, u[..., k - 1, :], pars)
+            y = state  # sys_out is the identity for all three systems (systems.py:347-351,396-399,426-428)
+        if cfg.mode == MODE_MPC:
+            J = J + g * stage_obj(y, u[..., k, :], cfg)
+        elif cfg.mode == MODE_RQL:
+            if k < N - 1:
+                J = J + g * stage_obj(y, u[..., k, :], cfg)
+            else:
+                J = J + critic(y, u[..., k, :], w_critic, cfg)
+        elif cfg.mode == MODE_SQL:
+            J = J + critic(y, u[..., k, :], w_critic, cfg)
+        else:
+            raise ValueError(cfg.mode)
+        g = g * cfg.gamma
+    return J
+
+
+def critic_cost(w, w_prev, obs_buf, act_buf, cfg: OracleCfg):
+    """``CtrlOptPred._critic_cost`` (rcognita/controllers.py:1216-1245).
+
+    ``obs_buf [..., buffer_size, dy]``, ``act_buf [..., buffer_size, du]`` with the newest row
+    LAST (``push_vec``, rcognita/utilities.py:78-79).  The reference indexes rows
+    ``0 .. Ncritic-1`` - the OLDEST rows (controllers.py:1231-1234).
+    """
+    Jc = 0.0
+    for k in range(cfg.n_critic - 1, 0, -1):
+        y_prev, y_next = obs_buf[..., k - 1, :], obs_buf[..., k, :]
+        u_prev, u_next = act_buf[..., k - 1, :], act_buf[..., k, :]
+        c_prev = critic(y_prev, u_prev, w, cfg)
+        c_next = critic(y_next, u_next, w_prev, cfg)
+        e = c_prev - cfg.gamma * c_next - stage_obj(y_prev, u_prev, cfg)
+        Jc = Jc + 0.5 * e**2
+    return Jc
+
+
+def push_vec(buf, vec):
+    """FIFO push: drop row 0, append at the bottom (rcognita/utilities.py:78-79). Batched."""
+    return np.concatenate([buf[..., 1:, :], np.asarray(vec)[..., None, :]], axis=-2)
+
+
+def critic_td_system(w_prev, obs_buf, act_buf, cfg: OracleCfg):
+    """The TD stack of ``_critic_cost`` written as ``Jc(w) = 1/2 |A w - b|^2``.
+
+    Row r (r = 0 .. Ncritic-2) is the reference's term k = r + 1:
+    ``A[r] = phi(y_{k-1}, u_{k-1})``, ``b[r] = gamma * w_prev . phi(y_k, u_k) + rho(y_{k-1}, u_{k-1})``.
+    """
+    rows = []
+    rhs = []
+    for k in range(1, cfg.n_critic):
+        rows.append(critic_features(obs_buf[..., k - 1, :], act_buf[..., k - 1, :], cfg))
+        rhs.append(
+            cfg.gamma * critic(obs_buf[..., k, :], act_buf[..., k, :], w_prev, cfg)
+            + stage_obj(obs_buf[..., k - 1, :], act_buf[..., k - 1, :], cfg)
+        )
+    return np.stack(rows, axis=-2), np.stack(rhs, axis=-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# Build-defined pieces with a CPU twin: candidate argmin, control tick
+# ----------------------------------------------------------------------------------------------
+def argmin_first(J):
+    """Deterministic argmin over the last axis: lower J wins, ties go to the
+    lower candidate index, NaN counts as +inf.  Returns ``(best_J, best_idx int32)``."""
+    Jc = np.where(np.isnan(J), np.inf, J)
+    idx = np.argmin(Jc, axis=-1).astype(np.int32)
+    return np.take_along_axis(Jc, idx[..., None].astype(np.int64), axis=-1)[..., 0], idx
+
+
+def grid_candidates(cfg: OracleCfg, K: int, action_prev=None):
+    """Build-defined generated candidate set: constant-over-horizon sequences.
+
+    du = 2: ``g x g`` level grid with ``g = isqrt(K)``, candidate ``k -> (i, j) = (k // g, k % g)``;
+    du = 1: ``K`` levels.  Level ``i`` of an input is ``lo + i * (hi - lo) / (g - 1)``.
+    Returns ``[K, N, du]``.
+    """
+    du, N = cfg.du, cfg.n_actor
+    lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
+    if du == 1:
+        g = K
+        lev = lo[0] + np.arange(g) * ((hi[0] - lo[0]) / max(g - 1, 1))
+        first = lev[:, None]
+    else:
+        g = int(np.floor(np.sqrt(K) + 1e-9))
+        assert g * g == K, "du=2 grid needs a square K"
+        i, j = np.divmod(np.arange(K), g)
+        first = np.stack(
+            [lo[0] + i * ((hi[0] - lo[0]) / max(g - 1, 1)), lo[1] + j * ((hi[1] - lo[1]) / max(g - 1, 1))],
+            axis=-1,
+        )
+    return np.broadcast_to(first[:, None, :], (K, N, du)).copy()
+
+
+@dataclass
+class EnvBatch:
+    """Per-env data of a batch of closed loops (host twin of the device handle's SoA tensors)."""
+
+    state: np.ndarray  # [B, ds]
+    action: np.ndarray  # [B, du]   action currently applied (ZOH)
+    accum: np.ndarray  # [B]
+    step_idx: np.ndarray  # [B] int32  control ticks done in the current episode
+    episode_idx: np.ndarray  # [B] int32
+    pars: np.ndarray  # [B, np] or [np]
+    state_prev: Optional[np.ndarray] = None  # state before the last substep (ref_lag)
+    best_J: Optional[np.ndarray] = None
+    best_idx: Optional[np.ndarray] = None
+    w_critic: Optional[np.ndarray] = None  # [B, dc]
+    w_prev: Optional[np.ndarray] = None
+    obs_buf: Optional[np.ndarray] = None  # [B, buffer_size, dy]
+    act_buf: Optional[np.ndarray] = None  # [B, buffer_size, du]
+
+
+def new_batch(cfg: OracleCfg, state0, action0=None, pars=None) -> EnvBatch:
+    state0 = np.array(state0, dtype=np.float64).reshape(-1, cfg.ds)
+    B = state0.shape[0]
+    if action0 is None:
+        # action_curr = action_min / 10 when action_init == [] (rcognita/controllers.py:973-975)
+        action0 = np.broadcast_to(cfg.ctrl_bnds[:, 0] / 10.0, (B, cfg.du))
+    dc = cfg.dc
+    return EnvBatch(
+        state=state0,
+        action=np.array(np.broadcast_to(action0, (B, cfg.du)), dtype=np.float64),
+        accum=np.zeros(B),
+        step_idx=np.zeros(B, dtype=np.int32),
+        episode_idx=np.zeros(B, dtype=np.int32),
+        pars=np.asarray(cfg.pars if pars is None else pars, dtype=np.float64),
+        state_prev=state0.copy(),
+        w_critic=np.ones((B, dc)),
+        w_prev=np.ones((B, dc)),
+        obs_buf=np.zeros((B, cfg.buffer_size, cfg.ds)),
+        act_buf=np.zeros((B, cfg.buffer_size, cfg.du)),
+    )
+
+
+def sim_substeps(cfg: OracleCfg, env: EnvBatch, n_substeps: int):
+    """``n_substeps`` RK4 steps of size ``dt_sim`` under the held action (row 10)."""
+    for _ in range(n_substeps):
+        env.state_prev = env.state
+        env.state = rk4_step(cfg.sys_id, env.state, env.action, env.pars, cfg.ctrl_bnds, cfg.dt_sim)
+        if cfg.accum_every_substep:
+            env.accum = env.accum + stage_obj(env.state, env.action, cfg) * cfg.sampling_time
+
+
+def control_tick(cfg: OracleCfg, env: EnvBatch, cand):
+    """One env.control-step (unit U2 of SURVEY §8d) for every env of the batch.
+
+    Order follows the reference loop (presets/main_3wrobot.py:419-429):
+      1. sim_step        : ``substeps_per_tick`` RK4 substeps with the held, clipped action
+      2. compute_action  : evaluate ``_actor_cost`` for the K candidates ``cand [B, K, N, du]`` (or
+                           ``[K, N, du]`` shared) from the new observation, take the argmin, the new
+                           action is the first ``du`` entries of the winner (controllers.py:1427)
+      3. receive_action  : the action is held until the next tick
+      4. upd_accum_obj   : ``accum += rho(obs, action) * sampling_time`` (controllers.py:1086-1093)
+      5. ``step_idx += 1`` (int32)
+    """
+    sim_substeps(cfg, env, cfg.substeps_per_tick)
+    obs = env.state
+    state_sys = env.state_prev if cfg.ref_lag else env.state
+    cand = np.asarray(cand, dtype=np.float64)
+    if cand.ndim == 3:
+        cand = np.broadcast_to(cand[None], (obs.shape[0],) + cand.shape)
+    J = actor_cost(
+        cand,
+        obs[:, None, :],
+        state_sys[:, None, :],
+        cfg,
+        pars=env.pars[:, None, :] if env.pars.ndim == 2 else env.pars,
+        w_critic=None if env.w_critic is None else env.w_critic[:, None, :],
+    )
+    best_J, best_idx = argmin_first(J)
+    env.best_J, env.best_idx = best_J, best_idx
+    env.action = np.take_along_axis(cand[:, :, 0, :], best_idx[:, None, None].astype(np.int64), axis=1)[:, 0, :]
+    if not cfg.accum_every_substep:
+        env.accum = env.accum + stage_obj(obs, env.action, cfg) * cfg.sampling_time
+    env.step_idx = env.step_idx + np.int32(1)
+    return J
