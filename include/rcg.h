@@ -1,0 +1,232 @@
+/* rcg.h - C ABI of the MI355X-native rcognita hot path (librcg.so).
+ *
+ * The reference (AIDynamicAction/rcognita, pure Python) has no FFI: its "plugin API" for this path
+ * is the duck-typed class surface System / Simulator / CtrlOptPred.  This header is the boundary a
+ * binding for that surface calls into; every entry point names the reference method(s) it
+ * replaces (paths relative to the reference checkout).  The Python mirror of the class surface that
+ * binds these symbols with ctypes lives in rcognita_amd/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every function returns RCG_OK (0) or a negative rcg_status; rcg_last_error() gives the text.
+ *   - Batched data is struct-of-arrays, env index innermost: a tensor written "[d][B]" stores
+ *     component c of env b at element c*B + b.  Element type is the handle's dtype (f32 or f64).
+ *   - Candidate action sequences are "[B][K][N][du]" (env-major, then candidate, then the
+ *     reference's own flat step-major action_sqn layout, rcognita/controllers.py:1284).
+ *   - "dev" pointers are HIP device pointers (e.g. torch.Tensor.data_ptr()); arguments documented
+ *     with a `where` flag accept host or device memory.
+ *   - One handle <-> one device <-> one HIP stream; calls on one handle are not re-entrant.
+ *     All launches are asynchronous on the handle's stream unless the call returns host data.
+ */
+#ifndef RCG_H
+#define RCG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCG_VERSION 100 /* 0.1.0 */
+
+/* ---- limits ------------------------------------------------------------------------------- */
+#define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
+#define RCG_MAX_DU 2    /* largest dim_input                                    */
+#define RCG_MAX_CHI 7   /* RCG_MAX_DS + RCG_MAX_DU                               */
+#define RCG_MAX_PARS 5  /* largest parameter vector (Sys2Tank)                  */
+#define RCG_MAX_DC 35   /* quad-lin critic on chi of length 7                   */
+#define RCG_MAX_ROW 64  /* N*du floats per candidate row staged in LDS          */
+
+/* ---- enums --------------------------------------------------------------------------------- */
+typedef enum rcg_status {
+  RCG_OK = 0,
+  RCG_ERR_BAD_ARG = -1,
+  RCG_ERR_HIP = -2,       /* a HIP runtime call failed; text in rcg_last_error           */
+  RCG_ERR_NO_DEVICE = -3, /* no gfx950 device visible: the library has no CPU fallback   */
+  RCG_ERR_UNSUPPORTED = -4,
+  RCG_ERR_NONFINITE = -5  /* returned by rcg_episode_stats when any env is flagged       */
+} rcg_status;
+
+/* rcognita/systems.py:255 (Sys3WRobot), :353 (Sys3WRobotNI), :401 (Sys2Tank) */
+typedef enum rcg_system { RCG_SYS_3WROBOT = 0, RCG_SYS_3WROBOT_NI = 1, RCG_SYS_2TANK = 2 } rcg_system;
+/* CtrlOptPred modes, rcognita/controllers.py:1304-1326 */
+typedef enum rcg_mode { RCG_MODE_MPC = 0, RCG_MODE_RQL = 1, RCG_MODE_SQL = 2 } rcg_mode;
+/* stage_obj_struct, rcognita/controllers.py:1076-1082 */
+typedef enum rcg_stage { RCG_STAGE_QUADRATIC = 0, RCG_STAGE_BIQUADRATIC = 1 } rcg_stage;
+/* critic_struct, rcognita/controllers.py:1024-1039, 1204-1212 */
+typedef enum rcg_critic_struct {
+  RCG_CRITIC_QUAD_LIN = 0,
+  RCG_CRITIC_QUADRATIC = 1,
+  RCG_CRITIC_QUAD_NOMIX = 2,
+  RCG_CRITIC_QUAD_MIX = 3
+} rcg_critic_struct;
+typedef enum rcg_dtype { RCG_F32 = 0, RCG_F64 = 1 } rcg_dtype;
+typedef enum rcg_where { RCG_HOST = 0, RCG_DEVICE = 1 } rcg_where;
+
+/* rcg_cfg.flags */
+#define RCG_FLAG_HAS_TARGET 0x1          /* observation_target != [] (controllers.py:1069)              */
+#define RCG_FLAG_PER_ENV_PARS 0x2        /* pars is a [np][B] device tensor (RCG_FIELD_PARS), not cfg.pars */
+#define RCG_FLAG_REF_LAG 0x4             /* rollout starts from the state before the last substep
+                                            (reference loop order, presets/main_3wrobot.py:425-428)    */
+#define RCG_FLAG_ACCUM_EVERY_SUBSTEP 0x8 /* upd_accum_obj every sim step (controllers.py:1093 quirk)    */
+#define RCG_FLAG_NO_CLIP 0x10            /* ctrl_bnds all zero <=> unconstrained (systems.py:241)       */
+
+/* per-env tensors owned by the handle (rcg_set_field / rcg_get_field) */
+typedef enum rcg_field {
+  RCG_FIELD_STATE = 0,       /* [ds][B]  real    System._state / Simulator.state_full            */
+  RCG_FIELD_ACTION = 1,      /* [du][B]  real    System.action == CtrlOptPred.action_curr (ZOH)   */
+  RCG_FIELD_ACCUM = 2,       /* [B]      real    CtrlOptPred.accum_obj_val                        */
+  RCG_FIELD_STEP_IDX = 3,    /* [B]      int32   control ticks done in the current episode        */
+  RCG_FIELD_EPISODE_IDX = 4, /* [B]      int32                                                    */
+  RCG_FIELD_STATUS = 5,      /* [B]      uint32  bit0: non-finite state seen, env frozen          */
+  RCG_FIELD_PARS = 6,        /* [np][B]  real    only with RCG_FLAG_PER_ENV_PARS                  */
+  RCG_FIELD_STATE_INIT = 7,  /* [ds][B]  real    Simulator.state_full_init                        */
+  RCG_FIELD_STATE_PREV = 8,  /* [ds][B]  real    state before the last RK4 substep                */
+  RCG_FIELD_BEST_J = 9,      /* [B]      real    J of the last argmin                             */
+  RCG_FIELD_BEST_IDX = 10,   /* [B]      int32   winning candidate index of the last argmin       */
+  RCG_FIELD_W_CRITIC = 11,   /* [dc][B]  real    CtrlOptPred.w_critic                             */
+  RCG_FIELD_W_PREV = 12,     /* [dc][B]  real    CtrlOptPred.w_critic_prev                        */
+  RCG_FIELD_OBS_BUF = 13,    /* [buffer_size][dy][B] real, newest row last (utilities.py:78)      */
+  RCG_FIELD_ACT_BUF = 14,    /* [buffer_size][du][B] real                                         */
+  RCG_FIELD_RETURNS = 15,    /* [B]      real    accum_obj of the last finished episode           */
+  RCG_FIELD_COUNT_ = 16
+} rcg_field;
+
+/* Plain-old-data configuration.  All reals are double here and are converted to the handle's
+ * dtype once, at rcg_create.  Matrices are row-major n x n with n = ds + du. */
+typedef struct rcg_cfg {
+  int32_t struct_size;      /* = sizeof(rcg_cfg); checked by rcg_create                          */
+  int32_t sys_id;           /* rcg_system                                                         */
+  int32_t batch;            /* B >= 1                                                             */
+  int32_t dtype;            /* rcg_dtype                                                          */
+  int32_t device;           /* HIP device ordinal                                                 */
+  int32_t n_actor;          /* Nactor (controllers.py:965), 1 <= N, N*du <= RCG_MAX_ROW           */
+  int32_t mode;             /* rcg_mode                                                           */
+  int32_t stage_obj_struct; /* rcg_stage                                                          */
+  int32_t critic_struct;    /* rcg_critic_struct                                                  */
+  int32_t n_critic;         /* Ncritic; clipped to buffer_size-1 as controllers.py:1015          */
+  int32_t buffer_size;      /* controllers.py:980-981                                             */
+  int32_t substeps_per_tick; /* RK4 substeps of dt_sim per controller sampling period            */
+  int32_t flags;            /* RCG_FLAG_*                                                         */
+  int32_t reserved_;
+  double dt_sim;            /* RK4 step                                                           */
+  double sampling_time;     /* controller sampling time (controllers.py:962)                      */
+  double pred_step_size;    /* Euler step of the rollout (controllers.py:966)                     */
+  double gamma;             /* discount (controllers.py:1012)                                     */
+  double pars[8];           /* system parameters: 3wrobot (m, I); 2tank (tau1,tau2,K1,K2,K3)      */
+  double ctrl_bnds[4];      /* [du][2] = (lo, hi) per input (systems.py:241-243)                  */
+  double R1[49];            /* stage_obj_pars[0], leading dimension n                             */
+  double R2[49];            /* stage_obj_pars[1] (biquadratic only)                               */
+  double target[8];         /* observation_target (used iff RCG_FLAG_HAS_TARGET)                  */
+  double action_init[4];    /* action applied before the first tick (controllers.py:973-978)      */
+  double w_init[40];        /* w_critic_init (controllers.py:1041-1042: ones)                     */
+  double w_min[40];         /* Wmin / Wmax (controllers.py:1026-1039)                             */
+  double w_max[40];
+} rcg_cfg;
+
+/* Per-shard summary of episode returns: what ranks exchange. */
+typedef struct rcg_summary {
+  double count;    /* envs in the shard                              */
+  double sum;      /* sum of returns                                 */
+  double sumsq;    /* sum of squared returns                         */
+  double min;
+  double max;
+  double n_failed; /* envs whose status bit0 is set                  */
+} rcg_summary;
+
+typedef struct rcg_handle rcg_handle;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int rcg_version(void);
+/* Text of the last error on this handle; h == NULL: last error of a failed rcg_create in this
+ * thread.  Never NULL. */
+const char* rcg_last_error(const rcg_handle* h);
+/* Number of visible HIP devices (0 if none / no driver).  Does not create a context. */
+int rcg_device_count(void);
+
+/* ---- life cycle: System.__init__ (systems.py:69-145), Simulator.__init__ (simulator.py:71-154),
+ *      CtrlOptPred.__init__ (controllers.py:811-1044) ------------------------------------------ */
+int rcg_create(const rcg_cfg* cfg, rcg_handle** out);
+int rcg_destroy(rcg_handle* h);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
+int rcg_set_stream(rcg_handle* h, void* hip_stream);
+int rcg_synchronize(rcg_handle* h);
+
+/* Device-memory helpers so that a host language without a GPU array library can drive the ABI. */
+int rcg_dev_alloc(rcg_handle* h, uint64_t bytes, void** dev_out);
+int rcg_dev_free(rcg_handle* h, void* dev);
+int rcg_memcpy_h2d(rcg_handle* h, void* dev_dst, const void* host_src, uint64_t bytes);
+int rcg_memcpy_d2h(rcg_handle* h, void* host_dst, const void* dev_src, uint64_t bytes);
+
+/* ---- per-env tensors ----------------------------------------------------------------------- */
+/* Copy a whole field in or out (layout and element type: rcg_field).  Synchronous for RCG_HOST. */
+int rcg_set_field(rcg_handle* h, int field, const void* src, int where);
+int rcg_get_field(rcg_handle* h, int field, void* dst, int where);
+/* Size in bytes of a field for this handle (0 if the field is not allocated). */
+int64_t rcg_field_bytes(const rcg_handle* h, int field);
+/* Raw device pointer of a field (zero-copy access; valid until rcg_destroy). */
+int rcg_field_ptr(rcg_handle* h, int field, void** dev_out);
+
+/* ---- stateless operators (unit parity; all pointers are device pointers) ------------------- */
+/* Sys*._state_dyn (systems.py:308-323, 370-382, 412-419) when clip == 0;
+ * System.closed_loop_rhs (systems.py:213-253) when clip != 0: the action is clipped to ctrl_bnds
+ * first and the clipped value is written to clipped_action (may be NULL).
+ * state [ds][n], action [du][n] -> dstate [ds][n].  Uses cfg.pars (or, with
+ * RCG_FLAG_PER_ENV_PARS and n == B, the per-env parameters). */
+int rcg_rhs(rcg_handle* h, const void* state, const void* action, void* dstate, void* clipped_action,
+            int32_t n, int32_t clip);
+/* CtrlOptPred.stage_obj (controllers.py:1063-1084): obs [dy][n], act [du][n] -> out [n]. */
+int rcg_stage_obj(rcg_handle* h, const void* obs, const void* act, void* out, int32_t n);
+/* CtrlOptPred._critic (controllers.py:1192-1214): w [dc][n] -> out [n]. */
+int rcg_critic(rcg_handle* h, const void* obs, const void* act, const void* w, void* out, int32_t n);
+/* CtrlOptPred._actor_cost (controllers.py:1273-1328) for K candidate sequences per env.
+ * cand [B][K][N][du]; obs [dy][B] and state_sys [ds][B] (NULL: the handle's STATE for both);
+ * w [dc][B] (NULL: the handle's W_CRITIC; ignored in MPC mode) -> J [B][K]. */
+int rcg_actor_cost(rcg_handle* h, const void* cand, int32_t K, const void* obs, const void* state_sys,
+                   const void* w, void* J);
+/* CtrlOptPred._critic_cost (controllers.py:1216-1245) on the handle's buffers and W_PREV.
+ * w [dc][B] (NULL: the handle's W_CRITIC) -> Jc [B]. */
+int rcg_critic_cost(rcg_handle* h, const void* w, void* Jc);
+
+/* ---- stateful steps ------------------------------------------------------------------------ */
+/* Simulator.sim_step (simulator.py:156-168) x n_substeps: fixed-step RK4 of closed_loop_rhs with
+ * the held ACTION, clipped (systems.py:241-243).  Updates STATE, STATE_PREV, STATUS. */
+int rcg_sim_step(rcg_handle* h, int32_t n_substeps);
+/* Replacement of CtrlOptPred._actor_optimizer (controllers.py:1330-1427): evaluate _actor_cost for
+ * K candidates per env and take the argmin (lower J wins, ties -> lower index, NaN = +inf).
+ * cand [B][K][N][du], or NULL for the generated level grid (K levels for du = 1, g*g for du = 2).
+ * obs / state_sys as rcg_actor_cost.  Outputs (each may be NULL): action [du][B] = first du
+ * entries of the winner (controllers.py:1427), best_J [B], best_idx [B] int32.  Does not modify
+ * the handle's ACTION. */
+int rcg_actor_argmin(rcg_handle* h, const void* cand, int32_t K, const void* obs, const void* state_sys,
+                     void* action, void* best_J, int32_t* best_idx);
+/* One env.control-step for every env (the loop body of presets/main_3wrobot.py:419-429):
+ * sim_step x substeps_per_tick -> [RQL/SQL: buffer push + critic fit] -> actor argmin over K
+ * candidates -> ACTION := winner's first action -> ACCUM += stage_obj(obs, action)*sampling_time ->
+ * STEP_IDX += 1.  cand as rcg_actor_argmin. */
+int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
+/* RQL/SQL bookkeeping of CtrlOptPred.compute_action (controllers.py:1458-1477): push (ACTION, obs)
+ * into the buffers and, if do_fit != 0, refit W_CRITIC by bounded least squares on the TD stack of
+ * _critic_cost (replacement of _critic_optimizer, controllers.py:1248-1271); W_PREV := W_CRITIC. */
+int rcg_critic_update(rcg_handle* h, int32_t do_fit);
+/* Episode boundary (Simulator.reset, simulator.py:197-204; CtrlOptPred.reset, controllers.py:1046):
+ * RETURNS := ACCUM; ACCUM := 0; STATE := STATE_INIT; ACTION := action_init; STEP_IDX := 0;
+ * EPISODE_IDX += 1.  Critic weights and buffers are retained, as in the reference. */
+int rcg_episode_reset(rcg_handle* h);
+/* Summary of `RETURNS` (from_accum == 0) or of the running ACCUM (from_accum != 0) over this
+ * handle's envs; returns_out (host, [B] real, may be NULL) receives the per-env values. */
+int rcg_episode_stats(rcg_handle* h, int32_t from_accum, void* returns_out, rcg_summary* out);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+typedef enum rcg_kernel { RCG_KERNEL_ACTOR = 0, RCG_KERNEL_SIM = 1, RCG_KERNEL_CRITIC = 2, RCG_KERNEL_COUNT_ = 3 } rcg_kernel;
+/* enable != 0: bracket every launch of the kernels above with HIP events recorded on the handle's
+ * own stream and reset the totals; enable == 0: stop recording. */
+int rcg_profile(rcg_handle* h, int32_t enable);
+/* Synchronise, then return the summed device time (ms) and number of launches of one kernel since
+ * the last rcg_profile(h, 1). */
+int rcg_profile_read(rcg_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCG_H */

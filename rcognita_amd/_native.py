@@ -1,0 +1,136 @@
+"""ctypes binding of librcg.so (C ABI: include/rcg.h).
+
+The library is built in-tree (``make lib`` or ``__graft_entry__.build()``) at
+``rcognita_amd/lib/librcg.so``.  There is no fallback of any kind: if the shared object is missing,
+or no HIP device is visible when a handle is created, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librcg.so")
+
+# ---- enums (include/rcg.h) -------------------------------------------------------------------
+RCG_VERSION = 100
+OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
+SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
+MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
+STAGE_QUADRATIC, STAGE_BIQUADRATIC = 0, 1
+CRITIC_QUAD_LIN, CRITIC_QUADRATIC, CRITIC_QUAD_NOMIX, CRITIC_QUAD_MIX = 0, 1, 2, 3
+F32, F64 = 0, 1
+HOST, DEVICE = 0, 1
+FLAG_HAS_TARGET, FLAG_PER_ENV_PARS, FLAG_REF_LAG, FLAG_ACCUM_EVERY_SUBSTEP, FLAG_NO_CLIP = 1, 2, 4, 8, 16
+
+(FIELD_STATE, FIELD_ACTION, FIELD_ACCUM, FIELD_STEP_IDX, FIELD_EPISODE_IDX, FIELD_STATUS, FIELD_PARS,
+ FIELD_STATE_INIT, FIELD_STATE_PREV, FIELD_BEST_J, FIELD_BEST_IDX, FIELD_W_CRITIC, FIELD_W_PREV, FIELD_OBS_BUF,
+ FIELD_ACT_BUF, FIELD_RETURNS) = range(16)
+
+MODE_IDS = {"MPC": MODE_MPC, "RQL": MODE_RQL, "SQL": MODE_SQL}
+STAGE_IDS = {"quadratic": STAGE_QUADRATIC, "biquadratic": STAGE_BIQUADRATIC}
+CRITIC_IDS = {"quad-lin": CRITIC_QUAD_LIN, "quadratic": CRITIC_QUADRATIC, "quad-nomix": CRITIC_QUAD_NOMIX,
+              "quad-mix": CRITIC_QUAD_MIX}
+SYS_IDS = {"3wrobot": SYS_3WROBOT, "3wrobotNI": SYS_3WROBOT_NI, "2tank": SYS_2TANK}
+SYS_DIMS = {SYS_3WROBOT: (5, 2, 2), SYS_3WROBOT_NI: (3, 2, 0), SYS_2TANK: (2, 1, 5)}  # ds, du, n_pars
+
+# every symbol include/rcg.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "rcg_version", "rcg_last_error", "rcg_device_count", "rcg_create", "rcg_destroy", "rcg_set_stream",
+    "rcg_synchronize", "rcg_dev_alloc", "rcg_dev_free", "rcg_memcpy_h2d", "rcg_memcpy_d2h", "rcg_set_field",
+    "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
+    "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
+    "rcg_critic_update", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
+]
+KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
+
+
+class RcgCfg(C.Structure):
+    """``rcg_cfg`` of include/rcg.h (field order and types must match exactly)."""
+
+    _fields_ = [
+        ("struct_size", C.c_int32), ("sys_id", C.c_int32), ("batch", C.c_int32), ("dtype", C.c_int32),
+        ("device", C.c_int32), ("n_actor", C.c_int32), ("mode", C.c_int32), ("stage_obj_struct", C.c_int32),
+        ("critic_struct", C.c_int32), ("n_critic", C.c_int32), ("buffer_size", C.c_int32),
+        ("substeps_per_tick", C.c_int32), ("flags", C.c_int32), ("reserved_", C.c_int32),
+        ("dt_sim", C.c_double), ("sampling_time", C.c_double), ("pred_step_size", C.c_double), ("gamma", C.c_double),
+        ("pars", C.c_double * 8), ("ctrl_bnds", C.c_double * 4), ("R1", C.c_double * 49), ("R2", C.c_double * 49),
+        ("target", C.c_double * 8), ("action_init", C.c_double * 4), ("w_init", C.c_double * 40),
+        ("w_min", C.c_double * 40), ("w_max", C.c_double * 40),
+    ]
+
+
+class RcgSummary(C.Structure):
+    _fields_ = [("count", C.c_double), ("sum", C.c_double), ("sumsq", C.c_double), ("min", C.c_double),
+                ("max", C.c_double), ("n_failed", C.c_double)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librcg error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load librcg.so once.  Raises if it has not been built - there is no Python fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first (`make lib` at the repo root, or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`).  rcognita_amd has no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    sig = {
+        "rcg_version": (C.c_int, []),
+        "rcg_last_error": (C.c_char_p, [vp]),
+        "rcg_device_count": (C.c_int, []),
+        "rcg_create": (C.c_int, [C.POINTER(RcgCfg), C.POINTER(vp)]),
+        "rcg_destroy": (C.c_int, [vp]),
+        "rcg_set_stream": (C.c_int, [vp, vp]),
+        "rcg_synchronize": (C.c_int, [vp]),
+        "rcg_dev_alloc": (C.c_int, [vp, u64, C.POINTER(vp)]),
+        "rcg_dev_free": (C.c_int, [vp, vp]),
+        "rcg_memcpy_h2d": (C.c_int, [vp, vp, vp, u64]),
+        "rcg_memcpy_d2h": (C.c_int, [vp, vp, vp, u64]),
+        "rcg_set_field": (C.c_int, [vp, C.c_int, vp, C.c_int]),
+        "rcg_get_field": (C.c_int, [vp, C.c_int, vp, C.c_int]),
+        "rcg_field_bytes": (i64, [vp, C.c_int]),
+        "rcg_field_ptr": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+        "rcg_rhs": (C.c_int, [vp, vp, vp, vp, vp, i32, i32]),
+        "rcg_stage_obj": (C.c_int, [vp, vp, vp, vp, i32]),
+        "rcg_critic": (C.c_int, [vp, vp, vp, vp, vp, i32]),
+        "rcg_actor_cost": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
+        "rcg_critic_cost": (C.c_int, [vp, vp, vp]),
+        "rcg_sim_step": (C.c_int, [vp, i32]),
+        "rcg_actor_argmin": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp]),
+        "rcg_control_tick": (C.c_int, [vp, vp, i32]),
+        "rcg_critic_update": (C.c_int, [vp, i32]),
+        "rcg_episode_reset": (C.c_int, [vp]),
+        "rcg_episode_stats": (C.c_int, [vp, i32, vp, C.POINTER(RcgSummary)]),
+        "rcg_profile": (C.c_int, [vp, i32]),
+        "rcg_profile_read": (C.c_int, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the .so does not export what rcg.h declares
+        fn.restype = res
+        fn.argtypes = args
+    if L.rcg_version() != RCG_VERSION:
+        raise ImportError(f"librcg.so version {L.rcg_version()} != binding version {RCG_VERSION}; rebuild")
+    _lib = L
+    return L
+
+
+def last_error(handle=None) -> str:
+    return lib().rcg_last_error(handle).decode("utf-8", "replace")
+
+
+def check(rc, handle=None, allow=()):
+    if rc != OK and rc not in allow:
+        raise NativeError(rc, last_error(handle))
+    return rc

@@ -1,0 +1,618 @@
+// rcg_kernels.hpp - HIP kernels of the rcognita hot path for gfx950 (CDNA4, wave64).
+//
+// Data layout in HBM: struct-of-arrays with the env index innermost ("[d][B]": component c of env
+// b at c*B + b), so that with lane == env every load/store of a wave is one contiguous 256 B (f32)
+// segment.  Candidate action sequences are [B][K][N][du]: one candidate is one contiguous row of
+// R = N*du reals, the rows of one env are contiguous, the envs follow each other.
+//
+// Kernels
+//   k_actor   _actor_cost for K candidates per env + wave argmin (+ tick epilogue).  A wave owns a
+//             contiguous tile of <= 64 candidate rows (one env, or 64/Kp envs when K < 64); the
+//             tile is pulled from HBM with coalesced 16 B/lane loads, parked in LDS, and each lane
+//             then walks ITS row step by step while unrolling the Euler rollout in registers.
+//             The running cost is a register; the argmin over candidates is a wave butterfly.
+//   k_sim     closed_loop_rhs + fixed-step RK4, lane == env.
+//   k_rhs / k_stage_obj / k_critic / k_critic_cost   the reference's operators, lane == point,
+//             for unit parity.
+//   k_critic_push, k_episode_reset, k_stats          bookkeeping.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rcg.h"
+#include "rcg_systems.hpp"
+
+namespace rcg {
+
+enum : int { STAGE_FULL = 1, STAGE_BIQUAD = 2 };
+
+// Wave-uniform parameters, passed by value in the kernarg segment (=> scalar loads / SGPRs).
+// Kept small on purpose: the two full n x n stage-cost matrices live in a device buffer (`Rfull`)
+// that only the non-diagonal path reads; with them inline the struct overflowed the SGPR file and
+// every kernel spilled scalars into VGPRs.
+template <typename real>
+struct KParams {
+  real pars[RCG_MAX_PARS];
+  real lo[RCG_MAX_DU], hi[RCG_MAX_DU];
+  const real* __restrict__ Rfull;           // [2][49]: R1 then R2, row-major, leading dimension n
+  real R1d[RCG_MAX_CHI], R2d[RCG_MAX_CHI];  // diagonals (used when !(stage_kind & STAGE_FULL))
+  real target[RCG_MAX_DS];
+  real gamma, h_pred, dt_sim, sampling_time;
+  int B, n_actor, mode, critic_struct, dc, n_critic, buffer_size;
+  int stage_kind, has_target, clip, per_env_pars, ref_lag, accum_every_substep;
+};
+
+// ---------------------------------------------------------------------------------------------
+// chi = [obs - target, act]   (controllers.py:1069-1072, 1200-1203)
+template <int DS, int DU, bool TGT, typename real>
+__device__ __forceinline__ void make_chi(const KParams<real>& P, const real* y, const real* u, real* chi) {
+#pragma unroll
+  for (int i = 0; i < DS; ++i) chi[i] = TGT ? y[i] - P.target[i] : y[i];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) chi[DS + c] = u[c];
+}
+
+// stage_obj on a ready chi: diagonal R1 only (the presets' case, main_3wrobot.py:177)
+template <int NCHI, typename real>
+__device__ __forceinline__ real stage_diag(const KParams<real>& P, const real* chi) {
+  real q = 0;
+#pragma unroll
+  for (int i = 0; i < NCHI; ++i) q = fma_r(P.R1d[i] * chi[i], chi[i], q);
+  return q;
+}
+
+// stage_obj, every structure (controllers.py:1076-1082):
+//   quadratic   chi @ R1 @ chi            biquadratic   chi**2 @ R2 @ chi**2 + chi @ R1 @ chi
+template <int NCHI, typename real>
+__device__ __forceinline__ real stage_any(const KParams<real>& P, const real* chi) {
+  real q;
+  if (!(P.stage_kind & STAGE_FULL)) {
+    q = stage_diag<NCHI, real>(P, chi);
+    if (P.stage_kind & STAGE_BIQUAD) {
+      real q4 = 0;
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) {
+        const real c2 = chi[i] * chi[i];
+        q4 = fma_r(P.R2d[i] * c2, c2, q4);
+      }
+      q = q4 + q;
+    }
+  } else {
+    q = 0;
+#pragma unroll
+    for (int j = 0; j < NCHI; ++j) {  // (chi @ R1)[j] * chi[j]
+      real v = 0;
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) v = fma_r(chi[i], P.Rfull[i * NCHI + j], v);
+      q = fma_r(v, chi[j], q);
+    }
+    if (P.stage_kind & STAGE_BIQUAD) {
+      real c2[NCHI];
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) c2[i] = chi[i] * chi[i];
+      real q4 = 0;
+#pragma unroll
+      for (int j = 0; j < NCHI; ++j) {
+        real v = 0;
+#pragma unroll
+        for (int i = 0; i < NCHI; ++i) v = fma_r(c2[i], P.Rfull[49 + i * NCHI + j], v);
+        q4 = fma_r(v, c2[j], q4);
+      }
+      q = q4 + q;
+    }
+  }
+  return q;
+}
+
+// _critic = w @ regressor (controllers.py:1192-1214).  `w(i)` returns weight i of this lane's env.
+// chi already holds [obs - target, act]; quad-mix uses the RAW observation y (controllers.py:1212).
+template <int DS, int DU, typename real, typename WGet>
+__device__ __forceinline__ real critic_value(const KParams<real>& P, const real* chi, const real* y,
+                                             const real* u, WGet w) {
+  constexpr int NCHI = DS + DU;
+  real acc = 0;
+  const int cs = P.critic_struct;
+  if (cs == RCG_CRITIC_QUAD_LIN || cs == RCG_CRITIC_QUADRATIC) {
+    int idx = 0;  // uptria2vec: row-major upper triangle incl. diagonal (utilities.py:81-96)
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i)
+#pragma unroll
+      for (int j = i; j < NCHI; ++j) acc = fma_r(w(idx++), chi[i] * chi[j], acc);
+    if (cs == RCG_CRITIC_QUAD_LIN) {
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) acc = fma_r(w(idx++), chi[i], acc);
+    }
+  } else if (cs == RCG_CRITIC_QUAD_NOMIX) {
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) acc = fma_r(w(i), chi[i] * chi[i], acc);
+  } else {  // quad-mix: [obs**2, kron(obs, act), act**2]
+#pragma unroll
+    for (int i = 0; i < DS; ++i) acc = fma_r(w(i), y[i] * y[i], acc);
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int c = 0; c < DU; ++c) acc = fma_r(w(DS + i * DU + c), y[i] * u[c], acc);
+#pragma unroll
+    for (int c = 0; c < DU; ++c) acc = fma_r(w(DS + DS * DU + c), u[c] * u[c], acc);
+  }
+  return acc;
+}
+
+template <typename Sys, typename real>
+__device__ __forceinline__ typename Sys::template Pre<real> load_pre(const KParams<real>& P,
+                                                                     const real* pars_env, long b) {
+  real pv[Sys::NP > 0 ? Sys::NP : 1];
+#pragma unroll
+  for (int i = 0; i < Sys::NP; ++i) pv[i] = pars_env ? pars_env[(long)i * P.B + b] : P.pars[i];
+  return Sys::template prepare<real>(pv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_actor
+// ---------------------------------------------------------------------------------------------
+template <typename real>
+struct ActorArgs {
+  const real* cand;       // [B][K][N][du], or nullptr: generated level grid
+  const real* obs;        // [dy][B]
+  const real* state_sys;  // [ds][B]
+  const real* pars_env;   // [np][B] or nullptr
+  const real* w;          // [dc][B] (RQL/SQL)
+  real* J;                // [B][K] or nullptr
+  real* action_out;       // [du][B] or nullptr
+  real* best_J;           // [B] or nullptr
+  int32_t* best_idx;      // [B] or nullptr
+  real* accum;            // tick epilogue: accum += rho(obs, action) * sampling_time; or nullptr
+  int32_t* step_idx;      // tick epilogue: += 1; or nullptr
+  int K;                  // candidates per env
+  int Kp;                 // K rounded up to a power of two (K < 64), else 64
+  int G;                  // envs per wave: 64 / Kp (K < 64), else 1
+  int n_tiles;            // ceil(K / 64) (K >= 64), else 1
+  int grid_g;             // generated grid: levels per input
+  int vec_ok;             // rows are 16-B granular: stage with dwordx4
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));  // one 16-B global_load_dwordx4 / ds_write_b128
+
+// Pull `n` reals (a whole tile of candidate rows, contiguous in HBM) into this wave's LDS region.
+// Control flow is wave-uniform (scalar compares): full 1-KiB rows of 64 lanes x 16 B, up to 8 of them
+// (8 KiB per wave) in flight before the first LDS write, then one partial row.
+template <typename real>
+__device__ __forceinline__ void stage_tile(const real* __restrict__ g, real* __restrict__ l, int n,
+                                           int lane, int vec_ok) {
+  if (vec_ok) {
+    const int nv = (int)(((long)n * (long)sizeof(real)) >> 4);
+    const v4f* __restrict__ gv = reinterpret_cast<const v4f*>(g);
+    v4f* __restrict__ lv = reinterpret_cast<v4f*>(l);
+    const int nfull = nv >> 6;
+    for (int base = 0; base < nfull; base += 8) {
+      const int cnt = nfull - base;  // wave-uniform
+      v4f r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < cnt) r[j] = __builtin_nontemporal_load(&gv[(base + j) * 64 + lane]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < cnt) lv[(base + j) * 64 + lane] = r[j];
+    }
+    const int i = nfull * 64 + lane;
+    if (i < nv) lv[i] = __builtin_nontemporal_load(&gv[i]);
+  } else {
+    for (int i = lane; i < n; i += 64) l[i] = g[i];
+  }
+}
+
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM>
+__global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave_in_wg = threadIdx.x >> 6;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+  const long B = P.B;
+  const int K = A.K, N = P.n_actor, R = N * DU;
+  if (wave * A.G >= B) return;  // wave-uniform; no workgroup barrier is used below
+
+  real* const lds = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * 64 * R;
+
+  const bool big = K >= 64;
+  const int seg = big ? 64 : A.Kp;          // lanes that share one env
+  const int e = big ? 0 : lane / seg;       // env slot inside the wave
+  const int kl = big ? lane : lane - e * seg;
+  const long b_raw = wave * A.G + e;
+  const bool env_ok = b_raw < B;
+  const long b = env_ok ? b_raw : B - 1;
+
+  // per-env inputs (broadcast loads: the lanes of one segment read the same address)
+  real y0[DS], xs[DS];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    y0[c] = A.obs[(long)c * B + b];
+    xs[c] = A.state_sys[(long)c * B + b];
+  }
+  const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
+  const real h = P.h_pred;
+  auto wget = [&](int i) -> real { return A.w[(long)i * B + b]; };
+
+  real bestJ = inf_r<real>();
+  int bestI = 0x7fffffff;
+  real bestU[DU];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) bestU[c] = 0;
+
+  const int envs_here = big ? 1 : (int)((B - wave * A.G) < A.G ? (B - wave * A.G) : A.G);
+
+  for (int t = 0; t < A.n_tiles; ++t) {
+    const int k = big ? t * 64 + kl : kl;
+    const bool valid = env_ok && k < K;
+    int r = 0;  // my row inside the tile
+    real ugen[DU];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) ugen[c] = 0;
+    if (STREAM) {
+      const long row0 = big ? b * K + (long)t * 64 : wave * A.G * (long)K;
+      const int nrows = big ? (K - t * 64 < 64 ? K - t * 64 : 64) : envs_here * K;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous tile's LDS reads are done
+      stage_tile<real>(A.cand + row0 * R, lds, nrows * R, lane, A.vec_ok);
+      // LDS ops of one wave are executed in order; wait for our own writes, no workgroup barrier
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      r = valid ? (big ? kl : e * K + kl) : 0;
+    } else {
+      // generated candidates: constant-over-horizon level grid (du = 2: k -> (k / g, k % g))
+      const int g = A.grid_g;
+      const real den = (real)(g > 1 ? g - 1 : 1);
+      if (DU == 1) {
+        ugen[0] = P.lo[0] + (real)k * ((P.hi[0] - P.lo[0]) / den);
+      } else {
+        const int gi = k / g, gj = k - gi * g;
+        ugen[0] = P.lo[0] + (real)gi * ((P.hi[0] - P.lo[0]) / den);
+        ugen[DU - 1] = P.lo[DU - 1] + (real)gj * ((P.hi[DU - 1] - P.lo[DU - 1]) / den);
+      }
+    }
+    const real* const urow = lds + (size_t)r * R;
+
+    // ---- _actor_cost: explicit-Euler rollout + running cost (controllers.py:1284-1326) --------
+    real x[DS], y[DS];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+      x[c] = xs[c];
+      y[c] = y0[c];
+    }
+    real J = 0, gk = 1;
+    real u[DU], up[DU], u0[DU];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) up[c] = 0;
+    for (int kk = 0; kk < N; ++kk) {
+#pragma unroll
+      for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];
+      if (kk == 0) {
+#pragma unroll
+        for (int c = 0; c < DU; ++c) u0[c] = u[c];
+      } else {
+        real d[DS];
+        Sys::template rhs<real>(pre, x, up, d);  // unclipped, as sys_rhs([], state, u[k-1])
+#pragma unroll
+        for (int c = 0; c < DS; ++c) {
+          x[c] = fma_r(h, d[c], x[c]);
+          y[c] = x[c];  // sys_out is the identity
+        }
+      }
+      real chi[NCHI];
+      make_chi<DS, DU, TGT, real>(P, y, u, chi);
+      if (!GENERIC) {  // MPC, quadratic, diagonal R1
+        J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
+      } else if (P.mode == RCG_MODE_MPC) {
+        J = fma_r(gk, stage_any<NCHI, real>(P, chi), J);
+      } else if (P.mode == RCG_MODE_RQL) {
+        if (kk < N - 1)
+          J = fma_r(gk, stage_any<NCHI, real>(P, chi), J);
+        else
+          J += critic_value<DS, DU, real>(P, chi, y, u, wget);
+      } else {  // SQL
+        J += critic_value<DS, DU, real>(P, chi, y, u, wget);
+      }
+      gk *= P.gamma;
+#pragma unroll
+      for (int c = 0; c < DU; ++c) up[c] = u[c];
+    }
+
+    if (A.J && valid) A.J[b * K + k] = J;
+    const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
+    if (valid && (Jc < bestJ || bestI == 0x7fffffff)) {
+      bestJ = Jc;
+      bestI = k;
+#pragma unroll
+      for (int c = 0; c < DU; ++c) bestU[c] = u0[c];
+    }
+  }
+
+  // ---- argmin over the segment: lower J wins, ties -> lower candidate index -------------------
+  for (int m = 1; m < seg; m <<= 1) {
+    const real oJ = __shfl_xor(bestJ, m, 64);
+    const int oI = __shfl_xor(bestI, m, 64);
+    real oU[DU];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) oU[c] = __shfl_xor(bestU[c], m, 64);
+    const bool take = (oJ < bestJ) || (oJ == bestJ && oI < bestI);
+    if (take) {
+      bestJ = oJ;
+      bestI = oI;
+#pragma unroll
+      for (int c = 0; c < DU; ++c) bestU[c] = oU[c];
+    }
+  }
+
+  if (kl == 0 && env_ok) {
+#pragma unroll
+    for (int c = 0; c < DU; ++c)
+      if (A.action_out) A.action_out[(long)c * B + b] = bestU[c];
+    if (A.best_J) A.best_J[b] = bestJ;
+    if (A.best_idx) A.best_idx[b] = bestI;
+    if (A.accum) {  // upd_accum_obj (controllers.py:1086-1093)
+      real chi[NCHI];
+      make_chi<DS, DU, TGT, real>(P, y0, bestU, chi);
+      A.accum[b] += stage_any<NCHI, real>(P, chi) * P.sampling_time;
+    }
+    if (A.step_idx) A.step_idx[b] += 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sim: closed_loop_rhs (systems.py:213-253) under classical RK4, lane == env
+// ---------------------------------------------------------------------------------------------
+template <typename real>
+struct SimArgs {
+  real* state;           // [ds][B] in/out
+  real* state_prev;      // [ds][B] out: state before the last substep
+  const real* action;    // [du][B]
+  const real* pars_env;  // [np][B] or nullptr
+  real* accum;           // [B] (only touched with accum_every_substep)
+  uint32_t* status;      // [B]
+  int n_sub;
+};
+
+template <typename Sys, typename real, bool TGT>
+__global__ __launch_bounds__(256) void k_sim(const SimArgs<real> A, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long B = P.B;
+  if (b >= B) return;
+  const uint32_t st = A.status[b];
+  if (st & 1u) return;  // frozen env
+
+  real x[DS], xp[DS], u[DU];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) xp[c] = x[c] = A.state[(long)c * B + b];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) {
+    const real a = A.action[(long)c * B + b];
+    u[c] = P.clip ? clamp_r<real>(a, P.lo[c], P.hi[c]) : a;  // systems.py:241-243
+  }
+  const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
+  const real h = P.dt_sim, hh = (real)0.5 * P.dt_sim, h6 = P.dt_sim / (real)6;
+  real acc = 0;
+
+  for (int s = 0; s < A.n_sub; ++s) {
+    real k1[DS], k2[DS], k3[DS], k4[DS], t[DS];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) xp[c] = x[c];
+    Sys::template rhs<real>(pre, x, u, k1);
+#pragma unroll
+    for (int c = 0; c < DS; ++c) t[c] = fma_r(hh, k1[c], x[c]);
+    Sys::template rhs<real>(pre, t, u, k2);
+#pragma unroll
+    for (int c = 0; c < DS; ++c) t[c] = fma_r(hh, k2[c], x[c]);
+    Sys::template rhs<real>(pre, t, u, k3);
+#pragma unroll
+    for (int c = 0; c < DS; ++c) t[c] = fma_r(h, k3[c], x[c]);
+    Sys::template rhs<real>(pre, t, u, k4);
+#pragma unroll
+    for (int c = 0; c < DS; ++c)
+      x[c] = fma_r(h6, ((k1[c] + (real)2 * k2[c]) + (real)2 * k3[c]) + k4[c], x[c]);
+    if (P.accum_every_substep) {
+      real chi[NCHI];
+      make_chi<DS, DU, TGT, real>(P, x, u, chi);
+      acc = fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, acc);
+    }
+  }
+
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < DS; ++c) ok = ok && finite_r<real>(x[c]);
+  if (!ok) {  // freeze the env at its last finite state and flag it (error convention)
+    A.status[b] = st | 1u;
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    A.state[(long)c * B + b] = x[c];
+    A.state_prev[(long)c * B + b] = xp[c];
+  }
+  if (P.accum_every_substep) A.accum[b] += acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit operators, lane == point
+// ---------------------------------------------------------------------------------------------
+template <typename Sys, typename real>
+__global__ void k_rhs(const real* state, const real* action, real* dstate, real* clipped, const real* pars_env,
+                      long n, int clip, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  real x[DS], u[DU], d[DS];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) x[c] = state[(long)c * n + i];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) {
+    const real a = action[(long)c * n + i];
+    u[c] = (clip && P.clip) ? clamp_r<real>(a, P.lo[c], P.hi[c]) : a;
+    if (clipped) clipped[(long)c * n + i] = u[c];
+  }
+  const auto pre = load_pre<Sys, real>(P, pars_env, i);
+  Sys::template rhs<real>(pre, x, u, d);
+#pragma unroll
+  for (int c = 0; c < DS; ++c) dstate[(long)c * n + i] = d[c];
+}
+
+template <typename Sys, typename real>
+__global__ void k_stage_obj(const real* obs, const real* act, real* out, long n, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  real y[DS], u[DU], chi[NCHI];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) y[c] = obs[(long)c * n + i];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) u[c] = act[(long)c * n + i];
+  if (P.has_target)
+    make_chi<DS, DU, true, real>(P, y, u, chi);
+  else
+    make_chi<DS, DU, false, real>(P, y, u, chi);
+  out[i] = stage_any<NCHI, real>(P, chi);
+}
+
+template <typename Sys, typename real>
+__global__ void k_critic(const real* obs, const real* act, const real* w, real* out, long n, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  real y[DS], u[DU], chi[NCHI];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) y[c] = obs[(long)c * n + i];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) u[c] = act[(long)c * n + i];
+  if (P.has_target)
+    make_chi<DS, DU, true, real>(P, y, u, chi);
+  else
+    make_chi<DS, DU, false, real>(P, y, u, chi);
+  out[i] = critic_value<DS, DU, real>(P, chi, y, u, [&](int k) -> real { return w[(long)k * n + i]; });
+}
+
+// _critic_cost (controllers.py:1216-1245) on the OLDEST Ncritic buffer rows, lane == env
+template <typename Sys, typename real>
+__global__ void k_critic_cost(const real* w, const real* w_prev, const real* obs_buf, const real* act_buf, real* Jc,
+                              const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long B = P.B;
+  if (b >= B) return;
+  real acc = 0;
+  for (int k = P.n_critic - 1; k >= 1; --k) {
+    real yp[DS], yn[DS], up[DU], un[DU], chip[NCHI], chin[NCHI];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+      yp[c] = obs_buf[((long)(k - 1) * DS + c) * B + b];
+      yn[c] = obs_buf[((long)k * DS + c) * B + b];
+    }
+#pragma unroll
+    for (int c = 0; c < DU; ++c) {
+      up[c] = act_buf[((long)(k - 1) * DU + c) * B + b];
+      un[c] = act_buf[((long)k * DU + c) * B + b];
+    }
+    if (P.has_target) {
+      make_chi<DS, DU, true, real>(P, yp, up, chip);
+      make_chi<DS, DU, true, real>(P, yn, un, chin);
+    } else {
+      make_chi<DS, DU, false, real>(P, yp, up, chip);
+      make_chi<DS, DU, false, real>(P, yn, un, chin);
+    }
+    const real cp = critic_value<DS, DU, real>(P, chip, yp, up, [&](int i) -> real { return w[(long)i * B + b]; });
+    const real cn =
+        critic_value<DS, DU, real>(P, chin, yn, un, [&](int i) -> real { return w_prev[(long)i * B + b]; });
+    const real e = cp - P.gamma * cn - stage_any<NCHI, real>(P, chip);
+    acc += (real)0.5 * e * e;
+  }
+  Jc[b] = acc;
+}
+
+// push_vec (utilities.py:78-79) on both buffers: drop row 0, append (obs, action) at the bottom
+template <typename Sys, typename real>
+__global__ void k_critic_push(real* obs_buf, real* act_buf, const real* obs, const real* action, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU;
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long B = P.B;
+  if (b >= B) return;
+  const int bs = P.buffer_size;
+  for (int r = 0; r < bs - 1; ++r) {
+#pragma unroll
+    for (int c = 0; c < DS; ++c) obs_buf[((long)r * DS + c) * B + b] = obs_buf[((long)(r + 1) * DS + c) * B + b];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) act_buf[((long)r * DU + c) * B + b] = act_buf[((long)(r + 1) * DU + c) * B + b];
+  }
+#pragma unroll
+  for (int c = 0; c < DS; ++c) obs_buf[((long)(bs - 1) * DS + c) * B + b] = obs[(long)c * B + b];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) act_buf[((long)(bs - 1) * DU + c) * B + b] = action[(long)c * B + b];
+}
+
+template <typename real>
+__global__ void k_episode_reset(real* state, real* state_prev, const real* state_init, real* action, real* accum,
+                                real* returns, int32_t* step_idx, int32_t* episode_idx, uint32_t* status, int ds,
+                                int du, real a0, real a1, long B) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  returns[b] = accum[b];
+  accum[b] = 0;
+  for (int c = 0; c < ds; ++c) {
+    const real v = state_init[(long)c * B + b];
+    state[(long)c * B + b] = v;
+    state_prev[(long)c * B + b] = v;
+  }
+  action[b] = a0;
+  if (du > 1) action[B + b] = a1;
+  step_idx[b] = 0;
+  episode_idx[b] += 1;
+  status[b] = 0;
+}
+
+// One workgroup of 1024 lanes strides over the shard: deterministic (count, sum, sumsq, min, max, n_failed).
+template <typename real>
+__global__ __launch_bounds__(1024) void k_stats(const real* v, const uint32_t* status, long B, double* out) {
+  __shared__ double s_sum[16], s_sq[16], s_min[16], s_max[16], s_fail[16];
+  double sum = 0, sq = 0, mn = __builtin_huge_val(), mx = -__builtin_huge_val(), nf = 0;
+  for (long i = threadIdx.x; i < B; i += blockDim.x) {
+    const double x = (double)v[i];
+    sum += x;
+    sq += x * x;
+    mn = x < mn ? x : mn;
+    mx = x > mx ? x : mx;
+    nf += (status[i] & 1u) ? 1.0 : 0.0;
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    sum += __shfl_xor(sum, m, 64);
+    sq += __shfl_xor(sq, m, 64);
+    nf += __shfl_xor(nf, m, 64);
+    const double omn = __shfl_xor(mn, m, 64), omx = __shfl_xor(mx, m, 64);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_sum[wv] = sum;
+    s_sq[wv] = sq;
+    s_min[wv] = mn;
+    s_max[wv] = mx;
+    s_fail[wv] = nf;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    double a = 0, q = 0, lo = __builtin_huge_val(), hi = -__builtin_huge_val(), f = 0;
+    for (int i = 0; i < nw; ++i) {
+      a += s_sum[i];
+      q += s_sq[i];
+      lo = s_min[i] < lo ? s_min[i] : lo;
+      hi = s_max[i] > hi ? s_max[i] : hi;
+      f += s_fail[i];
+    }
+    out[0] = (double)B;
+    out[1] = a;
+    out[2] = q;
+    out[3] = lo;
+    out[4] = hi;
+    out[5] = f;
+  }
+}
+
+}  // namespace rcg

@@ -1,0 +1,66 @@
+// rcg_math.hpp - device math for the rcognita hot path on gfx950.
+//
+// The robot heading alpha is unbounded (it reached -72 rad in a 2 s constant-torque run,
+// SURVEY.md hard part 3), so the f32 path cannot use the bare v_sin_f32/v_cos_f32 fast forms.
+// sincos_r<float> does an FMA-based three-constant Cody-Waite reduction by pi/2 followed by the
+// classic degree-7/8 minimax polynomials on [-pi/4, pi/4]: ~25 VALU ops for both values; max abs
+// error 8.7e-8 for |x| <= 1e5 (checked against float64 libm with an exact-FMA float32 emulation).  sincos_r<double> defers to the device libm (parity/debug build of the path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rcg {
+
+template <typename real>
+__device__ __forceinline__ void sincos_r(real x, real* s, real* c);
+
+template <>
+__device__ __forceinline__ void sincos_r<float>(float x, float* s, float* c) {
+  // k = nearest integer to x * 2/pi
+  const float kf = __builtin_rintf(x * 0.63661977236758134308f);
+  // pi/2 = C1 + C2 + C3 with C1 = fl(pi/2), C2 = fl(pi/2 - C1), C3 = fl(pi/2 - C1 - C2)
+  float r = __builtin_fmaf(kf, -1.57079637050628662109375f, x);
+  r = __builtin_fmaf(kf, 4.37113882867379288655e-8f, r);   // -C2
+  r = __builtin_fmaf(kf, 1.71512451000588187280e-15f, r);  // -C3
+  const float r2 = r * r;
+  // sin(r) = r + r^3 * (S1 + r^2 (S2 + r^2 S3)),  cos(r) = 1 - r^2/2 + r^4 (C0 + r^2 (C1 + r^2 C2))
+  float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, r2, -1.6666654611e-1f);
+  const float sr = __builtin_fmaf(ps * r2, r, r);
+  float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, r2, 4.166664568298827e-2f);
+  const float cr = __builtin_fmaf(pc * r2, r2, __builtin_fmaf(r2, -0.5f, 1.0f));
+  const int k = (int)kf;
+  // quadrant: k&1 swaps, sign of sin flips for k&2, sign of cos flips for (k+1)&2
+  const float ss = (k & 1) ? cr : sr;
+  const float cc = (k & 1) ? sr : cr;
+  *s = (k & 2) ? -ss : ss;
+  *c = ((k + 1) & 2) ? -cc : cc;
+}
+
+template <>
+__device__ __forceinline__ void sincos_r<double>(double x, double* s, double* c) {
+  ::sincos(x, s, c);
+}
+
+// typed fused multiply-add (NB: __builtin_fma is the double form; on float operands it would
+// silently promote the whole expression to f64)
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename real>
+__device__ __forceinline__ real clamp_r(real v, real lo, real hi) {
+  // np.clip semantics (systems.py:243): min(max(v, lo), hi); NaN propagates
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+template <typename real>
+__device__ __forceinline__ bool finite_r(real v) {
+  return __builtin_isfinite(v);
+}
+
+template <typename real>
+__device__ __forceinline__ real inf_r() {
+  return (real)__builtin_huge_val();
+}
+
+}  // namespace rcg

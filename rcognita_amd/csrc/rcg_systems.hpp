@@ -1,0 +1,72 @@
+// rcg_systems.hpp - the three built-in environments as compile-time policies.
+//
+// Each policy gives the dimensions and the open-loop right-hand side `Sys*._state_dyn` of the
+// reference (disturbance-free branch; is_disturb = 0 in every preset).
+// `Pre` holds per-env values derived once from the parameter vector (e.g. 1/m), so the rollout's
+// inner loop does no divisions.
+#pragma once
+#include "rcg_math.hpp"
+
+namespace rcg {
+
+// rcognita/systems.py:308-323  state = (x, y, alpha, v, omega), action = (F, M), pars = (m, I)
+struct Sys3WRobot {
+  static constexpr int DS = 5, DU = 2, NP = 2;
+  template <typename real>
+  struct Pre {
+    real inv_m, inv_I;
+  };
+  template <typename real>
+  __device__ __forceinline__ static Pre<real> prepare(const real* p) {
+    return {(real)1 / p[0], (real)1 / p[1]};
+  }
+  template <typename real>
+  __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
+    real s, c;
+    sincos_r<real>(x[2], &s, &c);
+    d[0] = x[3] * c;
+    d[1] = x[3] * s;
+    d[2] = x[4];
+    d[3] = q.inv_m * u[0];  // 1/m * action[0]
+    d[4] = q.inv_I * u[1];  // 1/I * action[1]
+  }
+};
+
+// rcognita/systems.py:370-382  state = (x, y, alpha), action = (v, omega), no pars
+struct Sys3WRobotNI {
+  static constexpr int DS = 3, DU = 2, NP = 0;
+  template <typename real>
+  struct Pre {};
+  template <typename real>
+  __device__ __forceinline__ static Pre<real> prepare(const real*) {
+    return {};
+  }
+  template <typename real>
+  __device__ __forceinline__ static void rhs(const Pre<real>&, const real* x, const real* u, real* d) {
+    real s, c;
+    sincos_r<real>(x[2], &s, &c);
+    d[0] = u[0] * c;
+    d[1] = u[0] * s;
+    d[2] = u[1];
+  }
+};
+
+// rcognita/systems.py:412-419  state = (h1, h2), action = (u), pars = (tau1, tau2, K1, K2, K3)
+struct Sys2Tank {
+  static constexpr int DS = 2, DU = 1, NP = 5;
+  template <typename real>
+  struct Pre {
+    real inv_tau1, inv_tau2, K1, K2, K3;
+  };
+  template <typename real>
+  __device__ __forceinline__ static Pre<real> prepare(const real* p) {
+    return {(real)1 / p[0], (real)1 / p[1], p[2], p[3], p[4]};
+  }
+  template <typename real>
+  __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
+    d[0] = q.inv_tau1 * (-x[0] + q.K1 * u[0]);
+    d[1] = q.inv_tau2 * (-x[1] + q.K2 * x[0] + q.K3 * (x[1] * x[1]));
+  }
+};
+
+}  // namespace rcg

@@ -1,0 +1,394 @@
+"""Engine: one librcg handle = a batch of B closed loops (System + Simulator + CtrlOptPred state)
+resident in HBM on one MI355X.
+
+Host-side arrays use the reference's natural shapes with a leading batch axis (``state [B, ds]``,
+``action_sqn [B, K, N, du]``); the device layout is struct-of-arrays with the env index innermost
+(include/rcg.h).  Inputs may be numpy arrays (uploaded), :class:`DeviceArray` or torch CUDA tensors
+(zero-copy, must already be in the device layout and dtype).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class EngineConfig:
+    """Python mirror of ``rcg_cfg``.  Names follow the reference's constructor arguments
+    (rcognita/systems.py:69-79, rcognita/controllers.py:811-837)."""
+
+    sys_id: int
+    batch: int = 1
+    dtype: str = "f32"  # "f32" | "f64"
+    device: int = 0
+    Nactor: int = 5
+    mode: str = "MPC"
+    stage_obj_struct: str = "quadratic"
+    critic_struct: str = "quad-nomix"
+    Ncritic: int = 4
+    buffer_size: int = 0  # 0: no critic buffers (MPC)
+    substeps_per_tick: int = 1
+    dt_sim: float = 0.01
+    sampling_time: float = 0.01
+    pred_step_size: float = 0.02
+    gamma: float = 1.0
+    pars: Sequence[float] = ()
+    ctrl_bnds: Optional[np.ndarray] = None  # [du, 2]
+    R1: Optional[np.ndarray] = None  # [n, n] or diagonal [n]
+    R2: Optional[np.ndarray] = None
+    observation_target: Optional[Sequence[float]] = None  # None <=> the reference's []
+    action_init: Optional[Sequence[float]] = None  # None <=> action_min / 10 (controllers.py:973-975)
+    per_env_pars: bool = False
+    ref_lag: bool = False
+    accum_every_substep: bool = False
+
+    def to_native(self) -> N.RcgCfg:
+        ds, du, npar = N.SYS_DIMS[self.sys_id]
+        n = ds + du
+        c = N.RcgCfg()
+        c.struct_size = C.sizeof(N.RcgCfg)
+        c.sys_id, c.batch, c.device = int(self.sys_id), int(self.batch), int(self.device)
+        c.dtype = {"f32": N.F32, "f64": N.F64}[self.dtype]
+        c.n_actor = int(self.Nactor)
+        c.mode = N.MODE_IDS[self.mode]
+        c.stage_obj_struct = N.STAGE_IDS[self.stage_obj_struct]
+        c.critic_struct = N.CRITIC_IDS[self.critic_struct]
+        c.n_critic, c.buffer_size = int(self.Ncritic), int(self.buffer_size)
+        c.substeps_per_tick = int(self.substeps_per_tick)
+        c.dt_sim, c.sampling_time = float(self.dt_sim), float(self.sampling_time)
+        c.pred_step_size, c.gamma = float(self.pred_step_size), float(self.gamma)
+        flags = 0
+        pars = np.asarray(self.pars, dtype=np.float64).reshape(-1)
+        if len(pars) < npar:
+            raise ValueError(f"system needs {npar} parameters, got {len(pars)}")
+        for i in range(npar):
+            c.pars[i] = pars[i]
+        bnds = np.zeros((du, 2)) if self.ctrl_bnds is None else np.asarray(self.ctrl_bnds, dtype=np.float64).reshape(du, 2)
+        for i in range(du):
+            c.ctrl_bnds[2 * i], c.ctrl_bnds[2 * i + 1] = bnds[i, 0], bnds[i, 1]
+        for name, M in (("R1", self.R1), ("R2", self.R2)):
+            if M is None:
+                M = np.eye(n) if name == "R1" else np.zeros((n, n))
+            M = np.asarray(M, dtype=np.float64)
+            if M.ndim == 1:
+                M = np.diag(M)
+            if M.shape != (n, n):
+                raise ValueError(f"{name} must be [{n},{n}] (or its diagonal), got {M.shape}")
+            arr = getattr(c, name)
+            for i in range(n):
+                for j in range(n):
+                    arr[i * n + j] = M[i, j]
+        if self.observation_target is not None and len(self.observation_target) > 0:
+            t = np.asarray(self.observation_target, dtype=np.float64).reshape(ds)
+            for i in range(ds):
+                c.target[i] = t[i]
+            flags |= N.FLAG_HAS_TARGET
+        a0 = bnds[:, 0] / 10.0 if self.action_init is None or len(self.action_init) == 0 else np.asarray(
+            self.action_init, dtype=np.float64).reshape(du)
+        for i in range(du):
+            c.action_init[i] = a0[i]
+        dc = dim_critic(self.critic_struct, ds, du)
+        lo, hi = critic_bounds(self.critic_struct)
+        for i in range(dc):
+            c.w_init[i], c.w_min[i], c.w_max[i] = 1.0, lo, hi  # controllers.py:1026-1042
+        if self.per_env_pars:
+            flags |= N.FLAG_PER_ENV_PARS
+        if self.ref_lag:
+            flags |= N.FLAG_REF_LAG
+        if self.accum_every_substep:
+            flags |= N.FLAG_ACCUM_EVERY_SUBSTEP
+        c.flags = flags
+        return c
+
+
+def dim_critic(critic_struct: str, dy: int, du: int) -> int:
+    """rcognita/controllers.py:1024-1039."""
+    n = dy + du
+    return {"quad-lin": n * (n + 1) // 2 + n, "quadratic": n * (n + 1) // 2, "quad-nomix": n,
+            "quad-mix": dy + dy * du + du}[critic_struct]
+
+
+def critic_bounds(critic_struct: str):
+    """(Wmin, Wmax) scalars, rcognita/controllers.py:1026-1039."""
+    return (-1e3, 1e3) if critic_struct in ("quad-lin", "quad-mix") else (0.0, 1e3)
+
+
+class DeviceArray:
+    """A raw HBM allocation made through the C ABI (no torch needed)."""
+
+    def __init__(self, engine: "Engine", shape, dtype):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        N.check(N.lib().rcg_dev_alloc(engine._h, max(self.nbytes, 16), C.byref(p)), engine._h)
+        self.ptr = p.value
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, (a.shape, self.shape)
+        if self.nbytes:
+            N.check(N.lib().rcg_memcpy_h2d(self.engine._h, self.ptr, a.ctypes.data, self.nbytes), self.engine._h)
+        return self
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            N.check(N.lib().rcg_memcpy_d2h(self.engine._h, out.ctypes.data, self.ptr, self.nbytes), self.engine._h)
+        return out
+
+    def free(self):
+        if self.ptr and self.engine._h:
+            N.lib().rcg_dev_free(self.engine._h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class Engine:
+    """Owner of one ``rcg_handle``."""
+
+    def __init__(self, cfg: EngineConfig):
+        self.cfg = cfg
+        self._h = None
+        L = N.lib()
+        self.ds, self.du, self.npar = N.SYS_DIMS[cfg.sys_id]
+        self.dy = self.ds
+        self.B = int(cfg.batch)
+        self.N = int(cfg.Nactor)
+        self.real = np.float32 if cfg.dtype == "f32" else np.float64
+        self.dc = dim_critic(cfg.critic_struct, self.dy, self.du)
+        self.buffer_size = int(cfg.buffer_size)
+        native = cfg.to_native()
+        h = C.c_void_p()
+        rc = L.rcg_create(C.byref(native), C.byref(h))
+        if rc != N.OK:
+            raise N.NativeError(rc, N.last_error(None))
+        self._h = h
+
+    # ------------------------------------------------------------------ life cycle
+    def close(self):
+        if self._h:
+            N.lib().rcg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        N.check(N.lib().rcg_set_stream(self._h, C.c_void_p(stream_ptr or 0)), self._h)
+
+    def synchronize(self):
+        N.check(N.lib().rcg_synchronize(self._h), self._h)
+
+    # ------------------------------------------------------------------ device memory
+    def empty(self, shape, dtype=None) -> DeviceArray:
+        return DeviceArray(self, shape, self.real if dtype is None else dtype)
+
+    def to_device(self, arr, dtype=None) -> DeviceArray:
+        a = np.ascontiguousarray(arr, dtype=self.real if dtype is None else dtype)
+        return DeviceArray(self, a.shape, a.dtype).upload(a)
+
+    def _in(self, x, keep, soa_from=None):
+        """Device pointer of an input.  numpy -> (optionally AoS->SoA transposed) upload."""
+        if x is None:
+            return None
+        if isinstance(x, DeviceArray):
+            return C.c_void_p(x.ptr)
+        if _is_torch(x):
+            if not x.is_cuda or not x.is_contiguous():
+                raise ValueError("torch inputs must be contiguous CUDA tensors in the device layout")
+            return C.c_void_p(x.data_ptr())
+        a = np.asarray(x, dtype=self.real)
+        if soa_from is not None:
+            a = soa_from(a)
+        d = self.to_device(a)
+        keep.append(d)
+        return C.c_void_p(d.ptr)
+
+    # ------------------------------------------------------------------ per-env tensors
+    _FIELD_DIMS = {
+        N.FIELD_STATE: "ds", N.FIELD_ACTION: "du", N.FIELD_ACCUM: None, N.FIELD_STEP_IDX: None,
+        N.FIELD_EPISODE_IDX: None, N.FIELD_STATUS: None, N.FIELD_PARS: "npar", N.FIELD_STATE_INIT: "ds",
+        N.FIELD_STATE_PREV: "ds", N.FIELD_BEST_J: None, N.FIELD_BEST_IDX: None, N.FIELD_W_CRITIC: "dc",
+        N.FIELD_W_PREV: "dc", N.FIELD_RETURNS: None,
+    }
+    _FIELD_INT = {N.FIELD_STEP_IDX: np.int32, N.FIELD_EPISODE_IDX: np.int32, N.FIELD_BEST_IDX: np.int32,
+                  N.FIELD_STATUS: np.uint32}
+
+    def _field_meta(self, f):
+        """(device shape, dtype, host->device transform, device->host transform)."""
+        dt = self._FIELD_INT.get(f, self.real)
+        B = self.B
+        if f in (N.FIELD_OBS_BUF, N.FIELD_ACT_BUF):
+            d = self.dy if f == N.FIELD_OBS_BUF else self.du
+            return (self.buffer_size, d, B), dt, (lambda a: a.reshape(B, self.buffer_size, d).transpose(1, 2, 0)), (
+                lambda a: a.transpose(2, 0, 1))
+        dim = self._FIELD_DIMS[f]
+        if dim is None:
+            return (B,), dt, (lambda a: a.reshape(B)), (lambda a: a)
+        d = getattr(self, dim)
+        return (d, B), dt, (lambda a: np.broadcast_to(a, (B, d)).T), (lambda a: a.T)
+
+    def set_field(self, f, value):
+        """Host array in the reference's shape (``[B, d]``, ``[B]``, ``[B, buffer_size, d]``)."""
+        shape, dt, h2d, _ = self._field_meta(f)
+        if isinstance(value, DeviceArray) or _is_torch(value):
+            ptr = value.ptr if isinstance(value, DeviceArray) else value.data_ptr()
+            N.check(N.lib().rcg_set_field(self._h, f, C.c_void_p(ptr), N.DEVICE), self._h)
+            return
+        a = np.ascontiguousarray(h2d(np.asarray(value, dtype=dt)), dtype=dt)
+        assert a.shape == shape, (a.shape, shape)
+        N.check(N.lib().rcg_set_field(self._h, f, a.ctypes.data, N.HOST), self._h)
+
+    def get_field(self, f) -> np.ndarray:
+        shape, dt, _, d2h = self._field_meta(f)
+        out = np.empty(shape, dtype=dt)
+        N.check(N.lib().rcg_get_field(self._h, f, out.ctypes.data, N.HOST), self._h)
+        return np.ascontiguousarray(d2h(out))
+
+    def field_ptr(self, f) -> int:
+        p = C.c_void_p()
+        N.check(N.lib().rcg_field_ptr(self._h, f, C.byref(p)), self._h)
+        return p.value
+
+    def set_state(self, state, also_init=True):
+        self.set_field(N.FIELD_STATE, state)
+        if also_init:
+            self.set_field(N.FIELD_STATE_INIT, state)
+
+    def get_state(self):
+        return self.get_field(N.FIELD_STATE)
+
+    # ------------------------------------------------------------------ stateless operators
+    def rhs(self, state, action, clip=False):
+        """``_state_dyn`` (clip=False) / ``closed_loop_rhs`` (clip=True) on ``n`` points.
+        Returns ``(dstate [n, ds], clipped_action [n, du])``."""
+        state = np.asarray(state, dtype=self.real).reshape(-1, self.ds)
+        action = np.asarray(action, dtype=self.real).reshape(-1, self.du)
+        n = state.shape[0]
+        keep = []
+        ps = self._in(state, keep, lambda a: a.T)
+        pa = self._in(action, keep, lambda a: a.T)
+        d, ca = self.empty((self.ds, n)), self.empty((self.du, n))
+        N.check(N.lib().rcg_rhs(self._h, ps, pa, C.c_void_p(d.ptr), C.c_void_p(ca.ptr), n, 1 if clip else 0), self._h)
+        return d.to_host().T.copy(), ca.to_host().T.copy()
+
+    def stage_obj(self, obs, act):
+        obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)
+        act = np.asarray(act, dtype=self.real).reshape(-1, self.du)
+        n = obs.shape[0]
+        keep = []
+        out = self.empty((n,))
+        N.check(N.lib().rcg_stage_obj(self._h, self._in(obs, keep, lambda a: a.T), self._in(act, keep, lambda a: a.T),
+                                      C.c_void_p(out.ptr), n), self._h)
+        return out.to_host()
+
+    def critic(self, obs, act, w):
+        obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)
+        act = np.asarray(act, dtype=self.real).reshape(-1, self.du)
+        w = np.asarray(w, dtype=self.real).reshape(-1, self.dc)
+        n = obs.shape[0]
+        keep = []
+        out = self.empty((n,))
+        N.check(N.lib().rcg_critic(self._h, self._in(obs, keep, lambda a: a.T), self._in(act, keep, lambda a: a.T),
+                                   self._in(w, keep, lambda a: a.T), C.c_void_p(out.ptr), n), self._h)
+        return out.to_host()
+
+    def _cand(self, cand, keep):
+        """Candidates ``[B, K, N, du]`` (numpy / device).  Returns (pointer, K)."""
+        if cand is None:
+            return None, None
+        if isinstance(cand, DeviceArray) or _is_torch(cand):
+            shape = tuple(cand.shape)
+            K = shape[1] if len(shape) >= 2 else None
+            return self._in(cand, keep), K
+        a = np.asarray(cand, dtype=self.real)
+        if a.ndim == 3:  # [K, N, du] shared by all envs
+            a = np.broadcast_to(a[None], (self.B,) + a.shape)
+        a = a.reshape(self.B, -1, self.N, self.du)
+        return self._in(a, keep), a.shape[1]
+
+    def actor_cost(self, cand, obs=None, state_sys=None, w=None):
+        """``_actor_cost`` of every candidate: ``cand [B, K, N, du]`` -> ``J [B, K]``."""
+        keep = []
+        pc, K = self._cand(cand, keep)
+        J = self.empty((self.B, K))
+        N.check(N.lib().rcg_actor_cost(self._h, pc, K, self._in(obs, keep, lambda a: a.reshape(self.B, self.dy).T),
+                                       self._in(state_sys, keep, lambda a: a.reshape(self.B, self.ds).T),
+                                       self._in(w, keep, lambda a: a.reshape(self.B, self.dc).T), C.c_void_p(J.ptr)),
+                self._h)
+        return J.to_host()
+
+    def critic_cost(self, w=None):
+        keep = []
+        Jc = self.empty((self.B,))
+        N.check(N.lib().rcg_critic_cost(self._h, self._in(w, keep, lambda a: a.reshape(self.B, self.dc).T),
+                                        C.c_void_p(Jc.ptr)), self._h)
+        return Jc.to_host()
+
+    # ------------------------------------------------------------------ stateful steps
+    def sim_step(self, n_substeps=1):
+        N.check(N.lib().rcg_sim_step(self._h, int(n_substeps)), self._h)
+
+    def actor_argmin(self, cand=None, K=None, obs=None, state_sys=None):
+        """Returns ``(action [B, du], best_J [B], best_idx [B] int32)``."""
+        keep = []
+        pc, Kc = self._cand(cand, keep)
+        K = Kc if K is None else int(K)
+        act, bj, bi = self.empty((self.du, self.B)), self.empty((self.B,)), self.empty((self.B,), np.int32)
+        N.check(N.lib().rcg_actor_argmin(self._h, pc, K, self._in(obs, keep, lambda a: a.reshape(self.B, self.dy).T),
+                                         self._in(state_sys, keep, lambda a: a.reshape(self.B, self.ds).T),
+                                         C.c_void_p(act.ptr), C.c_void_p(bj.ptr), C.c_void_p(bi.ptr)), self._h)
+        return act.to_host().T.copy(), bj.to_host(), bi.to_host()
+
+    def control_tick(self, cand=None, K=None):
+        """One env.control-step for all envs.  ``cand`` on device for the timed path."""
+        keep = []
+        pc, Kc = self._cand(cand, keep)
+        K = Kc if K is None else int(K)
+        N.check(N.lib().rcg_control_tick(self._h, pc, K), self._h)
+        if keep:  # temporaries were uploaded for this call: finish before they are freed
+            self.synchronize()
+
+    def critic_update(self, do_fit=True):
+        N.check(N.lib().rcg_critic_update(self._h, 1 if do_fit else 0), self._h)
+
+    def episode_reset(self):
+        N.check(N.lib().rcg_episode_reset(self._h), self._h)
+
+    def episode_stats(self, from_accum=False, want_returns=False):
+        """Returns ``(summary dict, returns [B] or None)``; ``n_failed > 0`` does not raise here."""
+        s = N.RcgSummary()
+        out = np.empty((self.B,), dtype=self.real) if want_returns else None
+        N.check(N.lib().rcg_episode_stats(self._h, 1 if from_accum else 0, out.ctypes.data if want_returns else None,
+                                          C.byref(s)), self._h, allow=(N.ERR_NONFINITE,))
+        return {k: getattr(s, k) for k in ("count", "sum", "sumsq", "min", "max", "n_failed")}, out
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, enable=True):
+        """Bracket the kernels with HIP events on the engine's own stream (rcg_profile)."""
+        N.check(N.lib().rcg_profile(self._h, 1 if enable else 0), self._h)
+
+    def profile_read(self, kernel=N.KERNEL_ACTOR):
+        """(total device ms, launches) of one kernel since ``profile(True)``."""
+        ms, n = C.c_double(), C.c_int64()
+        N.check(N.lib().rcg_profile_read(self._h, int(kernel), C.byref(ms), C.byref(n)), self._h)
+        return ms.value, n.value

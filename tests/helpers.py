@@ -37,3 +37,57 @@ def rel_err_norm(a, b, floor=1.0):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
+# ---- HIP engine builders (import of rcognita_amd is deferred so CPU-only collection works) ----
+def engine_cfg(name, batch, dtype="f64", **kw):
+    """EngineConfig that matches ``oracle_cfg(name, **same kw)``."""
+    from rcognita_amd import EngineConfig
+    from rcognita_amd import _native as N
+
+    p = PRESETS[name]
+    inv_mode = {v: k for k, v in O.MODE_IDS.items()}
+    inv_stage = {v: k for k, v in O.STAGE_IDS.items()}
+    inv_critic = {v: k for k, v in O.CRITIC_IDS.items()}
+    base = dict(
+        sys_id=N.SYS_IDS[name], batch=batch, dtype=dtype, pars=p["pars"], ctrl_bnds=np.array(p["bnds"], dtype=float),
+        R1=np.diag(np.array(p["R1"], dtype=float)), observation_target=p["target"], dt_sim=p["dt"],
+        sampling_time=p["dt"], pred_step_size=p["dt"] * p["mult"],
+    )
+    ren = dict(n_actor="Nactor", n_critic="Ncritic", target="observation_target")
+    for k, v in kw.items():
+        k2 = ren.get(k, k)
+        if k == "mode":
+            v = inv_mode[v]
+        elif k == "stage_obj_struct":
+            v = inv_stage[v]
+        elif k == "critic_struct":
+            v = inv_critic[v]
+        base[k2] = v
+    return EngineConfig(**base)
+
+
+def both(name, batch, dtype="f64", **kw):
+    """(Engine, OracleCfg) built from the same keyword set (oracle naming)."""
+    from rcognita_amd import Engine
+
+    okw = {k: v for k, v in kw.items() if k not in ("per_env_pars",)}
+    return Engine(engine_cfg(name, batch, dtype, **kw)), oracle_cfg(name, **okw)
+
+
+def rand_states(rng, name, n):
+    if name == "3wrobot":
+        return np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-8, 8, n),
+                         rng.uniform(-3, 3, n), rng.uniform(-3, 3, n)], axis=-1)
+    if name == "3wrobotNI":
+        return np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-8, 8, n)], axis=-1)
+    return np.stack([rng.uniform(0, 2, n), rng.uniform(-2, 2, n)], axis=-1)
+
+
+def rand_actions(rng, name, shape, overshoot=1.0):
+    b = np.array(PRESETS[name]["bnds"], dtype=float)
+    mid, half = b.mean(axis=1), 0.5 * (b[:, 1] - b[:, 0])
+    return mid + overshoot * half * rng.uniform(-1, 1, tuple(shape) + (b.shape[0],))
+
+
+TOL = {"f64": 1e-11, "f32": 1e-5}  # f32: the north star's stated tolerance (BASELINE.json)

@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/rcg.h declares, the ctypes struct matches the C struct, and the product path fails loudly
+(no CPU fallback) when there is no GPU.  No compute is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT
+
+
+def test_header_symbols_all_exported():
+    from rcognita_amd import _native as N
+
+    hdr = open(os.path.join(ROOT, "include", "rcg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rcg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    L = N.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.rcg_version() == N.RCG_VERSION
+
+
+def test_cfg_struct_layout_matches_c(tmp_path):
+    """sizeof/offsetof of rcg_cfg as gcc sees it == the ctypes mirror."""
+    from rcognita_amd import _native as N
+
+    src = tmp_path / "layout.c"
+    fields = [f[0] for f in N.RcgCfg._fields_]
+    body = "".join(f'printf("{f} %zu\\n", offsetof(rcg_cfg, {f}));' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rcg.h"\nint main(){printf("size %zu\\n", sizeof(rcg_cfg));'
+                   + body + 'printf("summary %zu\\n", sizeof(rcg_summary));return 0;}')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    assert int(out["size"]) == ctypes.sizeof(N.RcgCfg)
+    assert int(out["summary"]) == ctypes.sizeof(N.RcgSummary)
+    for f in fields:
+        assert int(out[f]) == getattr(N.RcgCfg, f).offset, f
+
+
+def test_create_argument_validation_and_no_cpu_fallback():
+    from rcognita_amd import Engine, EngineConfig
+    from rcognita_amd import _native as N
+
+    L = N.lib()
+    h = ctypes.c_void_p()
+    bad = N.RcgCfg()
+    bad.struct_size = 12
+    assert L.rcg_create(ctypes.byref(bad), ctypes.byref(h)) == N.ERR_BAD_ARG
+    assert b"struct_size" in L.rcg_last_error(None)
+    assert L.rcg_create(None, ctypes.byref(h)) == N.ERR_BAD_ARG
+    if L.rcg_device_count() == 0:
+        with pytest.raises(N.NativeError) as ei:
+            Engine(EngineConfig(sys_id=N.SYS_3WROBOT, batch=4, pars=[10, 1], ctrl_bnds=[[-300, 300], [-100, 100]]))
+        assert ei.value.code == N.ERR_NO_DEVICE
+        assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure; nothing under rcognita_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "rcognita_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, fn)
+                assert "rcg_oracle" not in txt and "liboracle" not in txt, os.path.join(dp, fn)

@@ -1,0 +1,426 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's golden
+vectors.  Needs an MI355X: every test is marked ``gpu``.
+
+Tolerances: f64 build 1e-11 relative (same arithmetic, different libm / FMA contraction);
+f32 build 1e-5 relative - the tolerance BASELINE.json's north_star states - measured as
+|hip - ref| / max(|ref|, 1).  Integer outputs (best_idx, step_idx, episode_idx) are bit-exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import rcg_oracle as O
+from tests.conftest import load_golden
+from tests.helpers import (PRESETS, SYSTEMS, TOL, both, rand_actions, rand_states, rel_err_norm)
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ["f64", "f32"]
+
+
+def _close(a, b, dtype, floor=1.0, scale=1.0, msg=""):
+    e = rel_err_norm(a, b, floor)
+    assert e <= TOL[dtype] * scale, f"{msg} rel err {e:.3e} > {TOL[dtype] * scale:.1e} ({dtype})"
+
+
+# ------------------------------------------------------------------------------------------------
+# reference golden vectors through the HIP path
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_known_answers(dtype):
+    _, k = load_golden("KAT")
+    x = np.array([[5, 5, -3 * np.pi / 4, 0.3, -0.2]])
+    u = np.array([[50.0, -20.0]])
+    eng, cfg = both("3wrobot", 1, dtype, n_actor=5, gamma=0.9, pred_step_size=0.02)
+    d, _ = eng.rhs(x, u, clip=False)
+    _close(d[0], k["kat1"], dtype, msg="KAT1")
+    d, a = eng.rhs(x, np.array([[400.0, -150.0]]), clip=True)
+    _close(d[0], k["kat2_rhs"], dtype, msg="KAT2")
+    np.testing.assert_array_equal(a[0], [300, -100])
+    _close(eng.stage_obj(x, u), 280.55165247561274, dtype, msg="KAT3")
+    aseq = np.array([[50, -20], [40, -10], [30, 0], [20, 10], [10, 20]], dtype=float)
+    w = 0.5 * np.arange(1, 8)
+    for mode in ("MPC", "RQL", "SQL"):
+        e2, _ = both("3wrobot", 1, dtype, n_actor=5, gamma=0.9, pred_step_size=0.02, mode=O.MODE_IDS[mode],
+                     critic_struct=O.CRITIC_QUAD_NOMIX, buffer_size=4)
+        J = e2.actor_cost(aseq[None, None], obs=x + 0.01, state_sys=x, w=w[None])
+        _close(J[0, 0], float(k[f"kat4_{mode}"]), dtype, msg=f"KAT4 {mode}")
+    for cs in ("quad-lin", "quadratic", "quad-nomix", "quad-mix"):
+        e3, c3 = both("3wrobot", 1, dtype, critic_struct=O.CRITIC_IDS[cs])
+        _close(e3.critic(x, u, np.linspace(0.1, 1, c3.dc)[None]), float(k[f"kat5_{cs}"]), dtype, msg=f"KAT5 {cs}")
+    e4, _ = both("2tank", 1, dtype, n_actor=4, pred_step_size=0.2)
+    d, _ = e4.rhs(np.array([[2.0, -2.0]]), np.array([[0.7]]))
+    _close(d[0], k["kat8"], dtype, floor=0.05, msg="KAT8")
+    _close(e4.stage_obj([[2.0, -2.0]], [[0.7]]), 85.49, dtype, msg="KAT9")
+    J = e4.actor_cost(np.array([0.7, 0.1, 0.9, 0.4]).reshape(1, 1, 4, 1), obs=[[2.0, -2.0]], state_sys=[[2.0, -2.0]])
+    _close(J[0, 0], float(k["kat10"]), dtype, msg="KAT10")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_F1_rhs_golden(name, dtype):
+    _, z = load_golden(f"F1_rhs_{name}")
+    eng, _ = both(name, 1, dtype)
+    d, _ = eng.rhs(z["state"], z["action"], clip=False)
+    _close(d, z["state_dyn"], dtype, msg="state_dyn")
+    d, a = eng.rhs(z["state"], z["action"], clip=True)
+    _close(d, z["closed_loop_rhs"], dtype, msg="closed_loop_rhs")
+    _close(a, z["clipped_action"], dtype, msg="clip")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_F2_stage_obj_golden(name, dtype):
+    _, z = load_golden(f"F2_stage_{name}")
+    cases = {
+        "quad_diag": dict(R1=z["R1_diag"], target=None),
+        "quad_full": dict(R1=z["R1_full"], target=None),
+        "quad_nonsym": dict(R1=z["R1_nonsym"], target=None),
+        "quad_diag_tgt": dict(R1=z["R1_diag"], target=z["target"]),
+        "biquad_full_tgt": dict(R1=z["R1_full"], R2=z["R2_full"], target=z["target"],
+                                stage_obj_struct=O.STAGE_BIQUADRATIC),
+        "biquad_diag": dict(R1=z["R1_diag"], R2=np.diag(np.diag(z["R2_full"])), target=None,
+                            stage_obj_struct=O.STAGE_BIQUADRATIC),
+    }
+    for tag, kw in cases.items():
+        eng, _ = both(name, 1, dtype, **kw)
+        # non-symmetric / full matrices mix signs: compare against the magnitude of the terms
+        floor = float(np.max(np.abs(z[tag]))) if "full" in tag or "nonsym" in tag else 1.0
+        _close(eng.stage_obj(z["obs"], z["act"]), z[tag], dtype, floor=floor, msg=tag)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_F3_critic_golden(name, dtype):
+    _, z = load_golden(f"F3_critic_{name}")
+    for cs, cid in O.CRITIC_IDS.items():
+        for ttag, tgt in (("", None), ("_tgt", z["target"])):
+            eng, _ = both(name, 1, dtype, critic_struct=cid, target=tgt)
+            ref = z[f"Q_{cs}{ttag}"]
+            _close(eng.critic(z["obs"], z["act"], z[f"w_{cs}{ttag}"]), ref, dtype, floor=float(np.max(np.abs(ref))),
+                   msg=cs + ttag)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_F4_actor_cost_golden(name, dtype):
+    """Every (N, mode, critic_struct) case of the reference's _actor_cost, state_sys != obs."""
+    meta, z = load_golden(f"F4_actor_cost_{name}")
+    for c in meta["cases"]:
+        tag = c["tag"]
+        n = z[f"{tag}__J"].shape[0]
+        eng, _ = both(name, n, dtype, n_actor=c["N"], mode=O.MODE_IDS[c["mode"]], gamma=c["gamma"],
+                      critic_struct=O.CRITIC_IDS[c["critic_struct"]], pred_step_size=c["pred_step_size"],
+                      buffer_size=4)
+        J = eng.actor_cost(z[f"{tag}__action_sqn"][:, None], obs=z[f"{tag}__obs"], state_sys=z[f"{tag}__state_sys"],
+                           w=z[f"{tag}__w"])
+        _close(J[:, 0], z[f"{tag}__J"], dtype, msg=tag)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_F5_critic_cost_golden(name, dtype):
+    meta, z = load_golden(f"F5_critic_cost_{name}")
+    from rcognita_amd import _native as N
+
+    for c in meta["cases"]:
+        tag = c["tag"]
+        n = z[f"{tag}__Jc"].shape[0]
+        eng, cfg = both(name, n, dtype, mode=O.MODE_RQL, gamma=c["gamma"],
+                        critic_struct=O.CRITIC_IDS[c["critic_struct"]], n_critic=c["Ncritic"],
+                        buffer_size=c["buffer_size"])
+        eng.set_field(N.FIELD_OBS_BUF, z[f"{tag}__obs_buf"])
+        eng.set_field(N.FIELD_ACT_BUF, z[f"{tag}__act_buf"])
+        eng.set_field(N.FIELD_W_PREV, z[f"{tag}__w_prev"])
+        np.testing.assert_allclose(eng.get_field(N.FIELD_OBS_BUF), z[f"{tag}__obs_buf"].astype(eng.real))
+        Jc = eng.critic_cost(z[f"{tag}__w"])
+        # 1/2 e^2 with e a difference of large terms: f32 tolerance applies to e, i.e. ~2x on Jc
+        _close(Jc, z[f"{tag}__Jc"], dtype, floor=float(np.max(np.abs(z[f"{tag}__Jc"]))), scale=4.0, msg=tag)
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_F6_hip_rk4_vs_reference_rk45(name):
+    """HIP fixed-step RK4 (f64) vs the reference's scipy-RK45 loop under a constant action: <= 1e-5."""
+    from rcognita_amd import _native as N
+
+    meta, z = load_golden(f"F6_rk45_const_{name}")
+    t, y = z["t"], z["y"]
+    h = meta["dt"] / 2.0
+    # sample the reference trajectory at its regular dt/2 strides (after the start-up transient)
+    eng, cfg = both(name, 1, "f64", dt_sim=h)
+    eng.set_state(y[0][None])
+    eng.set_field(N.FIELD_ACTION, np.array(meta["action"])[None])
+    # the reference grid is irregular at the start (first_step = 1e-6); integrate the oracle on the
+    # exact grid (test_oracle_golden) and here compare HIP vs oracle on a regular grid + final value
+    x_or = y[0].copy()
+    nsteps = int(round(t[-1] / h))
+    for _ in range(nsteps):
+        x_or = O.rk4_step(cfg.sys_id, x_or, np.array(meta["action"]), cfg.pars, cfg.ctrl_bnds, h)
+    eng.sim_step(nsteps)
+    x_hip = eng.get_state()[0]
+    assert rel_err_norm(x_hip, x_or) < 1e-10
+    # and against the reference's own end point, advanced by the (tiny) remaining time difference
+    rem = t[-1] - nsteps * h
+    x_end = O.rk4_step(cfg.sys_id, x_hip, np.array(meta["action"]), cfg.pars, cfg.ctrl_bnds, rem)
+    assert rel_err_norm(x_end, y[-1]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP vs oracle on seeded random inputs: tile shapes, ragged sizes, ties, NaN
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,N", [("3wrobot", 10), ("3wrobot", 7), ("3wrobotNI", 15), ("2tank", 20), ("2tank", 5)])
+@pytest.mark.parametrize("K", [1, 3, 16, 33, 64, 100, 256])
+def test_actor_cost_and_argmin_vs_oracle(name, N, K, dtype):
+    """Streamed candidates: J vs oracle; argmin bit-exact vs numpy on the SAME J; winner's first action."""
+    rng = np.random.default_rng(1000 + 7 * K + N)
+    B = 37 if K < 64 else 5  # not a multiple of the envs-per-wave group: exercises ragged tails
+    eng, cfg = both(name, B, dtype, n_actor=N, gamma=0.97)
+    x = rand_states(rng, name, B)
+    cand = rand_actions(rng, name, (B, K, N), overshoot=1.2)
+    eng.set_state(x)
+    J = eng.actor_cost(cand)
+    J_or = O.actor_cost(cand, x[:, None, :], x[:, None, :], cfg)
+    _close(J, J_or, dtype, msg="J")
+    act, bj, bi = eng.actor_argmin(cand)
+    # the argmin must be exactly numpy's first-occurrence argmin of the J the device itself computed
+    np.testing.assert_array_equal(bi, np.argmin(J, axis=1).astype(np.int32))
+    np.testing.assert_array_equal(bj, J[np.arange(B), bi])
+    np.testing.assert_array_equal(act, cand[np.arange(B), bi, 0, :].astype(eng.real))
+    if dtype == "f64":
+        _, bi_or = O.argmin_first(J_or)
+        np.testing.assert_array_equal(bi, bi_or)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_argmin_ties_and_nan(dtype):
+    """Lower index wins ties; NaN costs count as +inf; an all-NaN env returns index 0."""
+    name, N, K, B = "3wrobot", 5, 130, 4
+    rng = np.random.default_rng(5)
+    eng, cfg = both(name, B, dtype, n_actor=N)
+    x = rand_states(rng, name, B)
+    cand = rand_actions(rng, name, (B, K, N))
+    cand[0, 77] = cand[0, 3]  # exact duplicates -> equal J -> index 3 must win if it is the minimum
+    cand[0, 3] = 0.0
+    cand[0, 77] = 0.0
+    cand[0, 100] = 0.0
+    cand[1, 5, 2, 0] = np.nan  # NaN candidate is never selected
+    cand[2] = np.nan  # every candidate NaN
+    eng.set_state(x)
+    J = eng.actor_cost(cand)
+    act, bj, bi = eng.actor_argmin(cand)
+    Jc = np.where(np.isnan(J), np.inf, J)
+    np.testing.assert_array_equal(bi, np.argmin(Jc, axis=1).astype(np.int32))
+    assert np.isnan(J[1, 5]) and bi[1] != 5
+    assert bi[2] == 0 and np.isinf(bj[2])
+    assert J[0, 3] == J[0, 77] == J[0, 100]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
+@pytest.mark.parametrize("K", [1, 9, 64, 256])
+def test_generated_grid_vs_oracle(name, K, dtype):
+    """cand == NULL: the generated level grid equals oracle.grid_candidates evaluated by the oracle."""
+    if PRESETS[name]["sys_id"] != O.SYS_2TANK and int(np.sqrt(K)) ** 2 != K:
+        pytest.skip("du = 2 needs a square K")
+    rng = np.random.default_rng(77 + K)
+    B, N = 11, 6
+    eng, cfg = both(name, B, dtype, n_actor=N)
+    x = rand_states(rng, name, B)
+    eng.set_state(x)
+    act, bj, bi = eng.actor_argmin(None, K=K)
+    grid = O.grid_candidates(cfg, K)
+    J_or = O.actor_cost(grid[None], x[:, None, :], x[:, None, :], cfg)
+    bj_or, bi_or = O.argmin_first(J_or)
+    _close(bj, bj_or, dtype, msg="best_J")
+    if dtype == "f64":
+        np.testing.assert_array_equal(bi, bi_or)
+        np.testing.assert_allclose(act, grid[bi_or, 0, :], rtol=1e-13)
+    else:  # f32 may pick another candidate only if the oracle sees it as a near-tie
+        sel = J_or[np.arange(B), bi]
+        assert np.all(sel <= bj_or + 1e-5 * np.maximum(np.abs(bj_or), 1.0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_sim_step_vs_oracle(name, dtype):
+    rng = np.random.default_rng(3)
+    from rcognita_amd import _native as N
+
+    B = 300
+    eng, cfg = both(name, B, dtype)
+    x = rand_states(rng, name, B)
+    u = rand_actions(rng, name, (B,), overshoot=1.5)  # part of them gets clipped
+    eng.set_state(x)
+    eng.set_field(N.FIELD_ACTION, u)
+    eng.sim_step(3)
+    xo, prev = x, x
+    for _ in range(3):
+        prev = xo
+        xo = O.rk4_step(cfg.sys_id, xo, u, cfg.pars, cfg.ctrl_bnds, cfg.dt_sim)
+    _close(eng.get_state(), xo, dtype, msg="state")
+    _close(eng.get_field(N.FIELD_STATE_PREV), prev, dtype, msg="state_prev")
+    assert not eng.get_field(N.FIELD_STATUS).any()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,K,streamed", [("3wrobot", 64, True), ("3wrobot", 16, False), ("3wrobotNI", 100, True),
+                                             ("2tank", 32, False), ("2tank", 5, True)])
+@pytest.mark.parametrize("ref_lag", [False, True])
+def test_control_tick_closed_loop_vs_oracle(name, K, streamed, ref_lag, dtype):
+    """T ticks of the fused loop body against the oracle's control_tick: states, actions, accum,
+    integer counters.  f64: exact argmin agreement expected; f32: short horizon, tolerance 1e-5 on
+    values while the argmin agrees (a flipped near-tie legitimately forks the trajectory)."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(11 + K)
+    B, Nh, S = 13, 6, 2
+    T = 12 if dtype == "f64" else 4
+    eng, cfg = both(name, B, dtype, n_actor=Nh, substeps_per_tick=S, ref_lag=ref_lag, gamma=0.99)
+    x0 = rand_states(rng, name, B)
+    eng.set_state(x0)
+    env = O.new_batch(cfg, x0)
+    cand = rand_actions(rng, name, (B, K, Nh)) if streamed else O.grid_candidates(cfg, K)
+    dcand = eng.to_device(cand) if streamed else None
+    checked = 0
+    for t in range(T):
+        eng.control_tick(dcand if streamed else None, K=K)
+        O.control_tick(cfg, env, cand)
+        bi = eng.get_field(N.FIELD_BEST_IDX)
+        if dtype == "f32" and not np.array_equal(bi, env.best_idx):
+            break  # near-tie flipped in f32: values no longer comparable tick-by-tick
+        np.testing.assert_array_equal(bi, env.best_idx)
+        _close(eng.get_state(), env.state, dtype, scale=10, msg=f"state t={t}")
+        _close(eng.get_field(N.FIELD_ACTION), env.action, dtype, msg=f"action t={t}")
+        _close(eng.get_field(N.FIELD_ACCUM), env.accum, dtype, scale=10, floor=float(np.max(np.abs(env.accum))),
+               msg=f"accum t={t}")
+        np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), env.step_idx)  # int32, bit-exact
+        checked += 1
+    assert checked >= (T if dtype == "f64" else 1)
+
+
+def test_accum_every_substep_flag():
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(2)
+    B, K, Nh, S = 9, 16, 4, 3
+    eng, cfg = both("2tank", B, "f64", n_actor=Nh, substeps_per_tick=S, accum_every_substep=True)
+    x0 = rand_states(rng, "2tank", B)
+    eng.set_state(x0)
+    env = O.new_batch(cfg, x0)
+    for _ in range(5):
+        eng.control_tick(None, K=K)
+        O.control_tick(cfg, env, O.grid_candidates(cfg, K))
+    np.testing.assert_allclose(eng.get_field(N.FIELD_ACCUM), env.accum, rtol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_per_env_parameters(dtype):
+    """Heterogeneous (m, I) per env: coalesced [np][B] parameter loads."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(8)
+    B, K, Nh = 70, 64, 5
+    eng, cfg = both("3wrobot", B, dtype, n_actor=Nh, per_env_pars=True)
+    pars = np.stack([rng.uniform(5, 20, B), rng.uniform(0.5, 2, B)], axis=-1)
+    eng.set_field(N.FIELD_PARS, pars)
+    x0 = rand_states(rng, "3wrobot", B)
+    eng.set_state(x0)
+    env = O.new_batch(cfg, x0, pars=pars)
+    cand = rand_actions(rng, "3wrobot", (B, K, Nh))
+    J = eng.actor_cost(cand)
+    J_or = O.actor_cost(cand, x0[:, None], x0[:, None], cfg, pars=pars[:, None, :])
+    _close(J, J_or, dtype, msg="J per-env pars")
+    eng.control_tick(cand)
+    O.control_tick(cfg, env, cand)
+    _close(eng.get_state(), env.state, dtype, msg="state per-env pars")
+
+
+def test_nonfinite_state_freezes_env_and_is_reported():
+    from rcognita_amd import _native as N
+
+    B = 6
+    eng, cfg = both("2tank", B, "f32", dt_sim=50.0)  # huge step: K3*h2^2 blows up within a few steps
+    x0 = np.tile(np.array([[1.0, 1.0]]), (B, 1))
+    x0[2] = [1.0, 1e30]
+    eng.set_state(x0)
+    eng.set_field(N.FIELD_ACTION, np.full((B, 1), 0.5))
+    for _ in range(3):
+        eng.sim_step(1)
+    st = eng.get_field(N.FIELD_STATUS)
+    assert st[2] & 1
+    assert np.all(np.isfinite(eng.get_state()))
+    summ, _ = eng.episode_stats(from_accum=True)
+    assert summ["n_failed"] >= 1 and summ["count"] == B
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_episode_reset_and_stats(dtype):
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(4)
+    B, K = 1000, 16
+    eng, cfg = both("3wrobotNI", B, dtype, n_actor=3)
+    x0 = rand_states(rng, "3wrobotNI", B)
+    eng.set_state(x0)
+    for _ in range(3):
+        eng.control_tick(None, K=K)
+    acc = eng.get_field(N.FIELD_ACCUM).astype(np.float64)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, 3, np.int32))
+    eng.episode_reset()
+    summ, ret = eng.episode_stats(want_returns=True)
+    np.testing.assert_array_equal(ret.astype(np.float64), acc)
+    assert summ["count"] == B and summ["n_failed"] == 0
+    np.testing.assert_allclose(summ["sum"], acc.sum(), rtol=1e-12)
+    np.testing.assert_allclose(summ["sumsq"], (acc * acc).sum(), rtol=1e-12)
+    assert summ["min"] == acc.min() and summ["max"] == acc.max()
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.zeros(B, np.int32))
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_EPISODE_IDX), np.ones(B, np.int32))
+    np.testing.assert_array_equal(eng.get_state(), x0.astype(eng.real))
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_ACCUM), np.zeros(B, eng.real))
+    a0 = np.array(PRESETS["3wrobotNI"]["bnds"], dtype=float)[:, 0] / 10
+    np.testing.assert_allclose(eng.get_field(N.FIELD_ACTION), np.broadcast_to(a0, (B, 2)))
+
+
+# ------------------------------------------------------------------------------------------------
+# full BASELINE size: size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_full_size_C2_properties():
+    """BASELINE configs[1]: Sys3WRobot, B = 65536, Nactor = 10, K = 256 streamed candidates.
+    Properties: (a) best_J == min_k J and best_idx == first argmin of the device's own J for every env;
+    (b) permuting an env's candidates permutes its J and moves the argmin accordingly; (c) an env's
+    result does not depend on its position in the batch (env e evaluated alone == in the batch);
+    (d) a sample of envs agrees with the oracle to 1e-5."""
+    from rcognita_amd import _native as N
+
+    B, K, Nh = 65536, 256, 10
+    rng = np.random.default_rng(1234)
+    eng, cfg = both("3wrobot", B, "f32", n_actor=Nh)
+    x = np.stack([rng.uniform(-10, 10, B), rng.uniform(-10, 10, B), rng.uniform(-np.pi, np.pi, B),
+                  rng.uniform(-1, 1, B), rng.uniform(-1, 1, B)], axis=-1)
+    eng.set_state(x)
+    lo, hi = cfg.ctrl_bnds[:, 0].astype(np.float32), cfg.ctrl_bnds[:, 1].astype(np.float32)
+    cand = (lo + (hi - lo) * rng.random((B, K, Nh, 2), dtype=np.float32)).astype(np.float32)
+    dcand = eng.to_device(cand)
+    J = eng.actor_cost(dcand)
+    act, bj, bi = eng.actor_argmin(dcand)
+    np.testing.assert_array_equal(bi, np.argmin(J, axis=1).astype(np.int32))  # (a)
+    np.testing.assert_array_equal(bj, J.min(axis=1))
+    np.testing.assert_array_equal(act, cand[np.arange(B), bi, 0, :])
+    # (d) oracle sample
+    sel = rng.choice(B, 64, replace=False)
+    J_or = O.actor_cost(cand[sel].astype(np.float64), x[sel, None, :], x[sel, None, :], cfg)
+    assert rel_err_norm(J[sel], J_or) < 1e-5
+    # (b) permutation of candidates
+    perm = rng.permutation(K)
+    cand_p = np.ascontiguousarray(cand[:, perm])
+    dcand_p = eng.to_device(cand_p)
+    Jp = eng.actor_cost(dcand_p)
+    np.testing.assert_array_equal(Jp, J[:, perm])
+    # (c) position independence: first 8 envs alone in a small batch
+    e2, _ = both("3wrobot", 8, "f32", n_actor=Nh)
+    e2.set_state(x[:8])
+    np.testing.assert_array_equal(e2.actor_cost(cand[:8]), J[:8])
+    # one full tick: counters exact, state finite
+    eng.control_tick(dcand)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.ones(B, np.int32))
+    assert np.all(np.isfinite(eng.get_state()))
