@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/prof_*) into the small files kept under profiles/.
+
+    python tools/prof_summary.py --round r01 --kt gpurun_out/prof_kt --fetch gpurun_out/prof_fetch \
+        --write gpurun_out/prof_write --key k_actor_streamed_B65536_K256_N10_f32
+
+Writes profiles/<round>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, kernel names shortened),
+profiles/<round>_pmc.json (per-kernel FETCH_SIZE / WRITE_SIZE per launch, separate --pmc passes) and
+updates profiles/pmc_traffic.json, which bench.py reads for `roofline.traffic`.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
+FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read (128-B requests tallied
+at 64 B), so reads = FETCH_SIZE * 1024 * 2; WRITE_SIZE is exact for streaming stores.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)  # drop the argument list
+    name = name.replace("void ", "")
+    if len(name) > 110:
+        name = name[:107] + "..."
+    return name
+
+
+def one(pattern):
+    g = glob.glob(pattern, recursive=True)
+    return g[0] if g else None
+
+
+def counters(d, counter):
+    f = one(os.path.join(d, "**", "*_counter_collection.csv"))
+    out = {}
+    if not f:
+        return out
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        e = out.setdefault(k, {"n": 0, "sum": 0.0, "dur_ns": 0, "vgpr": r.get("VGPR_Count"), "sgpr": r.get("SGPR_Count"),
+                               "grid": r.get("Grid_Size"), "wg": r.get("Workgroup_Size")})
+        e["n"] += 1
+        e["sum"] += float(r["Counter_Value"])
+        e["dur_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", required=True)
+    ap.add_argument("--kt")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--key", help="bench.py workload key for pmc_traffic.json (k_actor entry)")
+    ap.add_argument("--kernel", default="rcg::k_actor")
+    ap.add_argument("--tag", default="")
+    a = ap.parse_args()
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    tag = f"_{a.tag}" if a.tag else ""
+
+    if a.kt:
+        f = one(os.path.join(a.kt, "**", "*_kernel_stats.csv"))
+        rows = list(csv.DictReader(open(f)))
+        dst = os.path.join(ROOT, "profiles", f"{a.round}{tag}_kernel_stats.csv")
+        with open(dst, "w", newline="") as fo:
+            w = csv.writer(fo)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+        print("wrote", dst)
+
+    pmc = {}
+    if a.fetch:
+        for k, e in counters(a.fetch, "FETCH_SIZE").items():
+            pmc.setdefault(k, {})
+            pmc[k].update(launches_fetch_pass=e["n"], FETCH_SIZE_KiB_per_launch=e["sum"] / e["n"],
+                          read_bytes_per_launch=e["sum"] / e["n"] * 1024 * 2,
+                          avg_ns_fetch_pass=e["dur_ns"] / e["n"], vgpr=e["vgpr"], sgpr=e["sgpr"], grid=e["grid"], wg=e["wg"])
+    if a.write:
+        for k, e in counters(a.write, "WRITE_SIZE").items():
+            pmc.setdefault(k, {})
+            pmc[k].update(launches_write_pass=e["n"], WRITE_SIZE_KiB_per_launch=e["sum"] / e["n"],
+                          write_bytes_per_launch=e["sum"] / e["n"] * 1024, avg_ns_write_pass=e["dur_ns"] / e["n"])
+    if pmc:
+        for k, e in pmc.items():
+            e["hbm_bytes_per_launch"] = e.get("read_bytes_per_launch", 0.0) + e.get("write_bytes_per_launch", 0.0)
+        pmc = {k: v for k, v in pmc.items() if k.startswith("rcg::")}
+        dst = os.path.join(ROOT, "profiles", f"{a.round}{tag}_pmc.json")
+        json.dump({"corrections": "bytes = KiB*1024; reads doubled (gfx950 FETCH_SIZE counts 128-B requests at 64 B)",
+                   "kernels": pmc}, open(dst, "w"), indent=1, sort_keys=True)
+        print("wrote", dst)
+        if a.key:
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            t = json.load(open(tf)) if os.path.exists(tf) else {}
+            hit = [v for k, v in pmc.items() if k.startswith(a.kernel)]
+            if hit:
+                t[a.key] = {"hbm_bytes_per_launch": hit[0]["hbm_bytes_per_launch"], "round": a.round,
+                            "read_bytes": hit[0].get("read_bytes_per_launch"), "write_bytes": hit[0].get("write_bytes_per_launch")}
+                json.dump(t, open(tf, "w"), indent=1, sort_keys=True)
+                print("updated", tf, a.key, t[a.key])
+
+
+if __name__ == "__main__":
+    main()
