@@ -108,7 +108,8 @@ typedef struct rcg_cfg {
   int32_t buffer_size;      /* controllers.py:980-981                                             */
   int32_t substeps_per_tick; /* RK4 substeps of dt_sim per controller sampling period            */
   int32_t flags;            /* RCG_FLAG_*                                                         */
-  int32_t reserved_;
+  int32_t critic_every_ticks; /* refit the critic every this many control ticks (critic_period /
+                                 sampling_time, controllers.py:1466); 0 or 1: every tick          */
   double dt_sim;            /* RK4 step                                                           */
   double sampling_time;     /* controller sampling time (controllers.py:962)                      */
   double pred_step_size;    /* Euler step of the rollout (controllers.py:966)                     */

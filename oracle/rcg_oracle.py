@@ -101,6 +101,7 @@ class OracleCfg:
     buffer_size: int = 10
     ref_lag: bool = False  # rollout starts from the previous sim step's state
     accum_every_substep: bool = False  # reference quirk, Appendix A-5
+    critic_every_ticks: int = 1  # critic_period / sampling_time (controllers.py:1466)
 
     def __post_init__(self):
         ds, du, npar = SYS_DIMS[self.sys_id]
@@ -395,6 +396,7 @@ class EnvBatch:
     w_prev: Optional[np.ndarray] = None
     obs_buf: Optional[np.ndarray] = None  # [B, buffer_size, dy]
     act_buf: Optional[np.ndarray] = None  # [B, buffer_size, du]
+    tick_count: int = 0  # control ticks issued (drives the critic period)
 
 
 def new_batch(cfg: OracleCfg, state0, action0=None, pars=None) -> EnvBatch:
@@ -441,6 +443,11 @@ def control_tick(cfg: OracleCfg, env: EnvBatch, cand):
       5. ``step_idx += 1`` (int32)
     """
     sim_substeps(cfg, env, cfg.substeps_per_tick)
+    if cfg.mode != MODE_MPC:
+        # buffer push + critic refit every `critic_every_ticks` ticks (controllers.py:1458-1477)
+        every = max(int(cfg.critic_every_ticks), 1)
+        critic_update(cfg, env, do_fit=(env.tick_count % every) == 0)
+    env.tick_count += 1
     obs = env.state
     state_sys = env.state_prev if cfg.ref_lag else env.state
     cand = np.asarray(cand, dtype=np.float64)
@@ -461,3 +468,131 @@ def control_tick(cfg: OracleCfg, env: EnvBatch, cand):
         env.accum = env.accum + stage_obj(obs, env.action, cfg) * cfg.sampling_time
     env.step_idx = env.step_idx + np.int32(1)
     return J
+
+
+# ----------------------------------------------------------------------------------------------
+# Build-defined critic fit (replacement of CtrlOptPred._critic_optimizer, controllers.py:1248-1271)
+# ----------------------------------------------------------------------------------------------
+FIT_MU_REL = 1e-8   # Tikhonov weight relative to trace(A A^T)/m
+FIT_ITERS = 40      # semismooth-Newton iterations (fixed cap: deterministic work per env)
+FIT_LS = 20         # Armijo halvings per iteration
+FIT_GTOL = 1e-12
+
+
+def _chol_solve(H, rhs):
+    """Solve the SPD system ``H x = rhs`` by an unpivoted Cholesky factorisation, written out in the
+    same operation order as the HIP kernel (rcg_critic_fit.hpp) so both take the same Newton steps."""
+    m = H.shape[0]
+    L = np.array(H, dtype=np.float64)
+    for j in range(m):
+        dj = L[j, j]
+        for k in range(j):
+            dj -= L[j, k] * L[j, k]
+        dj = np.sqrt(dj)
+        L[j, j] = dj
+        for i in range(j + 1, m):
+            s = L[i, j]
+            for k in range(j):
+                s -= L[i, k] * L[j, k]
+            L[i, j] = s / dj
+    x = np.zeros(m)
+    for i in range(m):
+        s = rhs[i]
+        for k in range(i):
+            s -= L[i, k] * x[k]
+        x[i] = s / L[i, i]
+    for i in range(m - 1, -1, -1):
+        s = x[i]
+        for k in range(i + 1, m):
+            s -= L[k, i] * x[k]
+        x[i] = s / L[i, i]
+    return x
+
+
+def critic_fit_single(A, b, w0, lo, hi):
+    """Bounded least squares of the TD stack for ONE env.
+
+    The reference minimises ``Jc(w) = 1/2 |A w - b|^2`` over the box ``[Wmin, Wmax]`` with SLSQP started
+    at ``w_critic_init`` (= ones, never updated: controllers.py:1041-1042, 1264, 1474).  SLSQP's iterates
+    are path dependent (and on the 3wrobot features it returns its start point unchanged, see
+    tests/golden/F8_slsqp_critic_3wrobot.npz), so the build defines the fit as the unique minimiser of
+
+        1/2 |A w - b|^2 + mu/2 |w - w_init|^2   s.t.  lo <= w <= hi,   mu = FIT_MU_REL * trace(A A^T) / m
+
+    (for mu -> 0 and inactive bounds: the least-squares solution closest to w_init, which is also where
+    a quasi-Newton method started at w_init with an identity Hessian converges).  It is computed in the
+    m-dimensional dual: ``w(y) = clip(w_init - A^T y / mu, lo, hi)``, maximise the concave, piecewise
+    quadratic dual by a semismooth Newton method with Armijo backtracking on the dual objective.
+    Safeguard: the feasible iterate with the smallest ``Jc`` (w_init included) is returned, so the fit
+    never increases ``Jc`` over the start point.  The HIP kernel k_critic_fit mirrors this line by line,
+    in float64 whatever the handle's dtype.
+    """
+    A = np.asarray(A, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    w0 = np.asarray(w0, dtype=np.float64)
+    m = A.shape[0]
+    tr = 0.0
+    for r in range(m):
+        tr += float(A[r] @ A[r])
+    mu = FIT_MU_REL * (tr / m) + 1e-300
+    inv_mu = 1.0 / mu
+
+    def w_of(y):
+        z = w0 - (A.T @ y) * inv_mu
+        return np.minimum(np.maximum(z, lo), hi), (z > lo) & (z < hi)
+
+    def negdual(y):
+        w, _ = w_of(y)
+        c = A.T @ y
+        return 0.5 * float(y @ y) + float(b @ y) - float(np.sum(0.5 * mu * (w - w0) ** 2 + c * w))
+
+    def primal(w):
+        r = A @ w - b
+        return 0.5 * float(r @ r)
+
+    y = np.zeros(m)
+    f = negdual(y)
+    best_w, best_P = w0.copy(), primal(w0)
+    bnorm = float(np.sqrt(b @ b))
+    for _ in range(FIT_ITERS):
+        w, free = w_of(y)
+        P = primal(w)
+        if P < best_P:
+            best_P, best_w = P, w.copy()
+        g = -(A @ w - b - y)
+        if float(np.sqrt(g @ g)) <= FIT_GTOL * (bnorm + 1.0):
+            break
+        Af = A[:, free]
+        H = (Af @ Af.T) * inv_mu + np.eye(m)
+        d = _chol_solve(H, -g)
+        slope = float(g @ d)
+        t = 1.0
+        fn = f
+        for _ in range(FIT_LS):
+            fn = negdual(y + t * d)
+            if fn <= f + 1e-4 * t * slope:
+                break
+            t *= 0.5
+        y = y + t * d
+        f = fn
+    return best_w
+
+
+def critic_fit(cfg: OracleCfg, w_prev, obs_buf, act_buf, w_init=None):
+    """Batched wrapper: ``w_prev [B, dc]``, buffers ``[B, buffer_size, d]`` -> fitted ``w [B, dc]``."""
+    A, b = critic_td_system(w_prev, obs_buf, act_buf, cfg)
+    B = A.shape[0]
+    lo, hi = critic_bounds(cfg.critic_struct, cfg.dc)
+    w0 = np.ones(cfg.dc) if w_init is None else np.asarray(w_init, dtype=np.float64)
+    return np.stack([critic_fit_single(A[i], b[i], w0, lo, hi) for i in range(B)])
+
+
+def critic_update(cfg: OracleCfg, env: EnvBatch, do_fit=True):
+    """RQL/SQL bookkeeping of compute_action (controllers.py:1458-1477): push (action_curr, obs), refit."""
+    env.act_buf = push_vec(env.act_buf, env.action)
+    env.obs_buf = push_vec(env.obs_buf, env.state)
+    if do_fit:
+        env.w_critic = critic_fit(cfg, env.w_prev, env.obs_buf, env.act_buf)
+        env.w_prev = env.w_critic
+    else:
+        env.w_critic = env.w_prev

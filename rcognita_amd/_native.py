@@ -52,7 +52,7 @@ class RcgCfg(C.Structure):
         ("struct_size", C.c_int32), ("sys_id", C.c_int32), ("batch", C.c_int32), ("dtype", C.c_int32),
         ("device", C.c_int32), ("n_actor", C.c_int32), ("mode", C.c_int32), ("stage_obj_struct", C.c_int32),
         ("critic_struct", C.c_int32), ("n_critic", C.c_int32), ("buffer_size", C.c_int32),
-        ("substeps_per_tick", C.c_int32), ("flags", C.c_int32), ("reserved_", C.c_int32),
+        ("substeps_per_tick", C.c_int32), ("flags", C.c_int32), ("critic_every_ticks", C.c_int32),
         ("dt_sim", C.c_double), ("sampling_time", C.c_double), ("pred_step_size", C.c_double), ("gamma", C.c_double),
         ("pars", C.c_double * 8), ("ctrl_bnds", C.c_double * 4), ("R1", C.c_double * 49), ("R2", C.c_double * 49),
         ("target", C.c_double * 8), ("action_init", C.c_double * 4), ("w_init", C.c_double * 40),

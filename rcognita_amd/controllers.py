@@ -1,0 +1,286 @@
+"""Predictive optimal controller with the reference's interface (rcognita/controllers.py:679-1493),
+backed by librcg.
+
+``CtrlOptPred`` keeps the reference's constructor signature, attributes and method names
+(``compute_action, receive_sys_state, stage_obj, upd_accum_obj, reset, _actor_cost, _critic,
+_critic_cost, _actor_optimizer, _critic_optimizer``) and adds a leading batch axis everywhere:
+``observation [dy]`` or ``[B, dy]``.  All arithmetic of those methods runs in the HIP kernels; there is
+no NumPy/SciPy path in this module.
+
+What differs from the reference, by construction (SURVEY.md hard part 1):
+
+* ``_actor_optimizer``: the reference calls SciPy SLSQP (finite-difference gradients, one env).  Here
+  the actor is a candidate search evaluated on the GPU: ``K`` action sequences per env go through
+  ``_actor_cost`` in one launch and the argmin wins (ties -> lower index).  Candidates are either given
+  explicitly (``candidates=``), or produced by the built-in sampler below: the reference's start
+  sequence, the previous optimum shifted by one step, a level grid of constant sequences, then
+  ``rounds - 1`` refinement rounds of shrinking perturbations around the incumbent.
+* ``_critic_optimizer``: bounded least squares on the TD stack solved natively (rcg_critic_update),
+  see rcognita_amd/csrc/rcg_critic_fit.hpp.
+* the sampling clock uses a tolerance instead of a bare float comparison, so that on the fixed-step
+  simulation grid ``t = t0 + k*dt`` every sampling period triggers exactly one control tick.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native as N
+from .engine import Engine, EngineConfig
+from .systems import System
+
+
+def ctrl_selector(t, observation, action_manual, ctrl_nominal, ctrl_benchmarking, mode):
+    """Main interface for various controllers (rcognita/controllers.py:40-63)."""
+    if mode == "manual":
+        action = action_manual
+    elif mode == "nominal":
+        action = ctrl_nominal.compute_action(t, observation)
+    else:  # Controller for benchmarking
+        action = ctrl_benchmarking.compute_action(t, observation)
+    return action
+
+
+class CtrlOptPred:
+    def __init__(self, dim_input, dim_output, mode="MPC", ctrl_bnds=[], action_init=[], t0=0, sampling_time=0.1,
+                 Nactor=1, pred_step_size=0.1, sys_rhs=[], sys_out=[], state_sys=[], prob_noise_pow=1,
+                 is_est_model=0, model_est_stage=1, model_est_period=0.1, buffer_size=20, model_order=3,
+                 model_est_checks=0, gamma=1, Ncritic=4, critic_period=0.1, critic_struct="quad-nomix",
+                 stage_obj_struct="quadratic", stage_obj_pars=[], observation_target=[],
+                 # ---- build-specific, keyword-only in spirit ----
+                 candidates=None, n_candidates=256, rounds=6, seed=0, dtype="f32", device=0):
+        if is_est_model:
+            raise NotImplementedError("is_est_model=1 needs the absent `sippy` package and is out of scope "
+                                      "(SURVEY.md 2, component 3)")
+        if mode not in ("MPC", "RQL", "SQL"):
+            raise ValueError(f"unknown mode {mode!r}")
+        sys_obj = getattr(sys_rhs, "__self__", None)
+        if not isinstance(sys_obj, System):
+            raise TypeError(
+                "sys_rhs must be the bound `_state_dyn` of a rcognita_amd System: arbitrary Python models cannot "
+                "run on the native path and there is no CPU fallback")
+        self.sys = sys_obj
+        self.dim_input, self.dim_output = dim_input, dim_output
+        self.mode = mode
+        self.ctrl_clock = t0
+        self.sampling_time = sampling_time
+        self.Nactor = Nactor
+        self.pred_step_size = pred_step_size
+        ctrl_bnds = np.asarray(ctrl_bnds, dtype=float)
+        self.action_min = np.array(ctrl_bnds[:, 0])
+        self.action_max = np.array(ctrl_bnds[:, 1])
+        self.action_sqn_min = np.tile(self.action_min, Nactor)  # rep_mat(., 1, Nactor), controllers.py:970
+        self.action_sqn_max = np.tile(self.action_max, Nactor)
+        if len(action_init) == 0:  # controllers.py:973-978
+            self.action_curr = self.action_min / 10
+        else:
+            self.action_curr = np.asarray(action_init, dtype=float)
+        self.action_sqn_init = np.tile(self.action_curr, Nactor)
+        self.sys_rhs, self.sys_out = sys_rhs, sys_out
+
+        state_sys = np.asarray(state_sys, dtype=float)
+        self._batched = state_sys.ndim == 2
+        self.B = state_sys.shape[0] if self._batched else 1
+        self.state_sys = state_sys
+        self.action_curr = np.broadcast_to(self.action_curr, (self.B, dim_input)).copy() if self._batched else self.action_curr
+        self.action_buffer = np.zeros([buffer_size, dim_input])
+        self.observation_buffer = np.zeros([buffer_size, dim_output])
+
+        self.is_est_model = 0
+        self.prob_noise_pow = prob_noise_pow
+        self.buffer_size = buffer_size
+        self.critic_clock = t0
+        self.gamma = gamma
+        self.Ncritic = int(np.min([Ncritic, buffer_size - 1]))  # controllers.py:1015
+        self.critic_period = critic_period
+        self.critic_struct = critic_struct
+        self.stage_obj_struct = stage_obj_struct
+        self.stage_obj_pars = stage_obj_pars
+        self.observation_target = observation_target
+        self.accum_obj_val = np.zeros(self.B) if self._batched else 0
+
+        spec = sys_obj.native_spec()
+        R1 = np.asarray(stage_obj_pars[0], dtype=float)
+        R2 = np.asarray(stage_obj_pars[1], dtype=float) if len(stage_obj_pars) > 1 else None
+        tgt = None if len(observation_target) == 0 else np.asarray(observation_target, dtype=float)
+        self._eng = Engine(EngineConfig(
+            sys_id=spec["sys_id"], batch=self.B, dtype=dtype, device=device, Nactor=Nactor, mode=mode,
+            stage_obj_struct=stage_obj_struct, critic_struct=critic_struct, Ncritic=Ncritic, buffer_size=buffer_size,
+            dt_sim=sampling_time, sampling_time=sampling_time, pred_step_size=pred_step_size, gamma=gamma,
+            pars=spec["pars"], ctrl_bnds=ctrl_bnds, R1=R1, R2=R2, observation_target=tgt,
+            action_init=None if len(action_init) == 0 else action_init))
+        self.dim_critic = self._eng.dc
+        lo, hi = (-1e3, 1e3) if critic_struct in ("quad-lin", "quad-mix") else (0.0, 1e3)
+        self.Wmin, self.Wmax = lo * np.ones(self.dim_critic), hi * np.ones(self.dim_critic)
+        self.w_critic_prev = np.ones(self.dim_critic)
+        self.w_critic_init = self.w_critic_prev
+        self.w_critic = np.ones(self.dim_critic)
+
+        # actor search settings
+        self.candidates = None if candidates is None else np.asarray(candidates, dtype=float)
+        self.n_candidates, self.rounds = int(n_candidates), int(rounds)
+        self._rng = np.random.default_rng(seed)
+        self._prev_opt = None  # previous optimal sequence [B, N, du] (warm start)
+        self.last_J = None
+        self.last_idx = None
+
+    # ------------------------------------------------------------------ helpers
+    def _b(self, a, d):
+        """host array ``[d]`` or ``[B, d]`` -> ``[B, d]``"""
+        return np.broadcast_to(np.asarray(a, dtype=float).reshape(-1, d), (self.B, d))
+
+    def _unb(self, a):
+        return a if self._batched else a[0]
+
+    # ------------------------------------------------------------------ reference interface
+    def reset(self, t0):
+        """rcognita/controllers.py:1046-1054: only the clock and the current action are reset."""
+        self.ctrl_clock = t0
+        self.action_curr = self._unb(np.broadcast_to(self.action_min / 10, (self.B, self.dim_input)).copy())
+
+    def receive_sys_state(self, state):
+        """rcognita/controllers.py:1056-1061."""
+        self.state_sys = state
+
+    def stage_obj(self, observation, action):
+        """rcognita/controllers.py:1063-1084 (rcg_stage_obj)."""
+        out = self._eng.stage_obj(self._b(observation, self.dim_output), self._b(action, self.dim_input)).astype(float)
+        return out if self._batched else float(out[0])
+
+    def upd_accum_obj(self, observation, action):
+        """rcognita/controllers.py:1086-1093."""
+        self.accum_obj_val = self.accum_obj_val + self.stage_obj(observation, action) * self.sampling_time
+
+    def _critic(self, observation, action, w_critic):
+        """rcognita/controllers.py:1192-1214 (rcg_critic)."""
+        out = self._eng.critic(self._b(observation, self.dim_output), self._b(action, self.dim_input),
+                               self._b(w_critic, self.dim_critic)).astype(float)
+        return out if self._batched else float(out[0])
+
+    def _sync_critic_state(self):
+        ob = np.broadcast_to(self.observation_buffer, (self.B,) + self.observation_buffer.shape[-2:])
+        ab = np.broadcast_to(self.action_buffer, (self.B,) + self.action_buffer.shape[-2:])
+        self._eng.set_field(N.FIELD_OBS_BUF, ob)
+        self._eng.set_field(N.FIELD_ACT_BUF, ab)
+        self._eng.set_field(N.FIELD_W_PREV, self._b(self.w_critic_prev, self.dim_critic))
+
+    def _critic_cost(self, w_critic):
+        """rcognita/controllers.py:1216-1245 (rcg_critic_cost) on the current buffers."""
+        self._sync_critic_state()
+        out = self._eng.critic_cost(self._b(w_critic, self.dim_critic)).astype(float)
+        return out if self._batched else float(out[0])
+
+    def _critic_optimizer(self):
+        """Replacement of rcognita/controllers.py:1248-1271: native bounded least squares on the TD stack
+        of the CURRENT buffers (no push)."""
+        self._sync_critic_state()
+        # rcg_critic_update pushes before it fits: pre-shift the rows so the push restores them
+        ob = self._eng.get_field(N.FIELD_OBS_BUF)
+        ab = self._eng.get_field(N.FIELD_ACT_BUF)
+        self._eng.set_field(N.FIELD_OBS_BUF, np.concatenate([ob[:, :1] * 0, ob[:, :-1]], axis=1))
+        self._eng.set_field(N.FIELD_ACT_BUF, np.concatenate([ab[:, :1] * 0, ab[:, :-1]], axis=1))
+        self._eng.set_field(N.FIELD_STATE, ob[:, -1])
+        self._eng.set_field(N.FIELD_ACTION, ab[:, -1])
+        self._eng.critic_update(do_fit=True)
+        w = self._eng.get_field(N.FIELD_W_CRITIC).astype(float)
+        return w if self._batched else w[0]
+
+    def _actor_cost(self, action_sqn, observation):
+        """rcognita/controllers.py:1273-1328 (rcg_actor_cost).  ``action_sqn`` is the reference's flat
+        ``[N*du]`` vector, or ``[K, N*du]`` / ``[B, K, N*du]`` for many candidates at once."""
+        a = np.asarray(action_sqn, dtype=float)
+        single = a.ndim == 1
+        if a.ndim == 1:
+            a = a[None, None]
+        elif a.ndim == 2:
+            a = a[None]
+        a = np.broadcast_to(a, (self.B,) + a.shape[1:]).reshape(self.B, -1, self.Nactor, self.dim_input)
+        w = self._b(self.w_critic, self.dim_critic) if self.mode != "MPC" else None
+        J = self._eng.actor_cost(a, obs=self._b(observation, self.dim_output),
+                                 state_sys=self._b(self.state_sys, self.dim_output), w=w).astype(float)
+        if single:
+            return J[:, 0] if self._batched else float(J[0, 0])
+        return J if self._batched else J[0]
+
+    # ------------------------------------------------------------------ actor search
+    def _initial_candidates(self):
+        """Round 0: start sequence, shifted previous optimum, constant level grid, uniform fill."""
+        B, K, Nh, du = self.B, self.n_candidates, self.Nactor, self.dim_input
+        lo, hi = self.action_min, self.action_max
+        c = self._rng.uniform(lo, hi, size=(B, K, Nh, du))
+        k = 0
+        c[:, k] = self.action_sqn_init.reshape(Nh, du)  # the reference's (only) start point, controllers.py:1379
+        k += 1
+        if self._prev_opt is not None and k < K:
+            c[:, k, :-1] = self._prev_opt[:, 1:]
+            c[:, k, -1] = self._prev_opt[:, -1]
+            k += 1
+        g = int(np.floor((K // 2) ** (1.0 / du)))
+        if g >= 2:
+            axes = [np.linspace(lo[i], hi[i], g) for i in range(du)]
+            grid = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, du)
+            n = min(len(grid), K - k)
+            c[:, k:k + n] = grid[:n, None, :][None]
+        return c
+
+    def _actor_optimizer(self, observation):
+        """Replacement of rcognita/controllers.py:1330-1427.  Returns the first action of the best sequence."""
+        obs = self._b(observation, self.dim_output)
+        xs = self._b(self.state_sys, self.dim_output)
+        w = None
+        if self.mode != "MPC":
+            self._eng.set_field(N.FIELD_W_CRITIC, self._b(self.w_critic, self.dim_critic))
+        if self.candidates is not None:
+            cand = self.candidates
+            cand = np.broadcast_to(cand if cand.ndim == 4 else cand[None], (self.B,) + cand.shape[-3:])
+            act, bj, bi = self._eng.actor_argmin(cand, obs=obs, state_sys=xs)
+            self._prev_opt = cand[np.arange(self.B), bi]
+        else:
+            lo, hi = self.action_min, self.action_max
+            cand = self._initial_candidates()
+            best_seq, bj = None, None
+            for r in range(max(self.rounds, 1)):
+                if r > 0:
+                    sigma = 0.25 * (hi - lo) * (0.45 ** (r - 1))
+                    noise = self._rng.standard_normal(cand.shape) * sigma
+                    # half of the perturbations are constant over the horizon, half are per step
+                    half = cand.shape[1] // 2
+                    noise[:, :half] = noise[:, :half, :1]
+                    cand = np.clip(best_seq[:, None] + noise, lo, hi)
+                    cand[:, 0] = best_seq  # keep the incumbent: the search is monotone
+                act, bj, bi = self._eng.actor_argmin(cand, obs=obs, state_sys=xs)
+                best_seq = cand[np.arange(self.B), bi]
+            self._prev_opt = best_seq
+        self.last_J, self.last_idx = bj.astype(float), bi
+        act = act.astype(float)
+        return act if self._batched else act[0]
+
+    def compute_action(self, t, observation):
+        """Main method (rcognita/controllers.py:1429-1493)."""
+        time_in_sample = t - self.ctrl_clock
+        if time_in_sample >= self.sampling_time * (1 - 1e-9):  # new sample
+            self.ctrl_clock = t
+            if self.mode in ("RQL", "SQL"):
+                time_in_critic_period = t - self.critic_clock
+                # push_vec of both buffers (controllers.py:1463-1464); one shared buffer per controller in
+                # the un-batched case, [B, buffer_size, d] when batched
+                a, y = np.asarray(self.action_curr, dtype=float), np.asarray(observation, dtype=float)
+                if self._batched:
+                    if self.action_buffer.ndim == 2:
+                        self.action_buffer = np.broadcast_to(self.action_buffer, (self.B,) + self.action_buffer.shape).copy()
+                        self.observation_buffer = np.broadcast_to(self.observation_buffer,
+                                                                  (self.B,) + self.observation_buffer.shape).copy()
+                    self.action_buffer = np.concatenate([self.action_buffer[:, 1:], a[:, None]], axis=1)
+                    self.observation_buffer = np.concatenate([self.observation_buffer[:, 1:], y[:, None]], axis=1)
+                else:
+                    self.action_buffer = np.vstack([self.action_buffer[1:], a])
+                    self.observation_buffer = np.vstack([self.observation_buffer[1:], y])
+                if time_in_critic_period >= self.critic_period * (1 - 1e-9):
+                    self.critic_clock = t
+                    self.w_critic = self._critic_optimizer()
+                    self.w_critic_prev = self.w_critic
+                else:
+                    self.w_critic = self.w_critic_prev
+            action = self._actor_optimizer(observation)
+            self.action_curr = action
+            return action
+        return self.action_curr

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "rcg_critic_fit.hpp"
 #include "rcg_kernels.hpp"
 
 using namespace rcg;
@@ -24,6 +25,7 @@ struct rcg_handle {
   void* f[RCG_FIELD_COUNT_];
   size_t fbytes[RCG_FIELD_COUNT_];
   double* d_summary;
+  long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
   void* d_rfull;  // [2][49] real: full R1, R2 (read by the non-diagonal stage cost only)
   KParams<float> p32;
   KParams<double> p64;
@@ -104,6 +106,9 @@ static int fail(rcg_handle* h, int code, const char* fmt, ...) {
   } while (0)
 
 static const int kDims[3][3] = {{5, 2, 2}, {3, 2, 0}, {2, 1, 5}};  // ds, du, np
+// layout of the per-handle constant block in HBM (see rcg_create)
+static constexpr size_t kConstR64 = 512, kConstW = 1296, kConstBytes = 2256;
+static constexpr int kFitMaxRows = 8;  // Ncritic - 1 <= 8 for the native critic fit
 
 static int dim_critic(int cs, int dy, int du) {
   const int n = dy + du;
@@ -345,6 +350,7 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->stream = nullptr;
   h->d_summary = nullptr;
   h->prof = false;
+  h->tick_count = 0;
   memset(h->prof_ms, 0, sizeof h->prof_ms);
   memset(h->prof_n, 0, sizeof h->prof_n);
   if (h->cfg.buffer_size > 0) {
@@ -356,17 +362,24 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   if (!any_bnd) h->cfg.flags |= RCG_FLAG_NO_CLIP;  // `if self.ctrl_bnds.any()` (systems.py:241)
   h->d_rfull = nullptr;
   {
-    if (hipMalloc(&h->d_rfull, 2 * 49 * sizeof(double)) != hipSuccess) {
-      fail(nullptr, RCG_ERR_HIP, "rcg_create: allocating the stage-cost matrices");
+    // one small constant block: [0,392) R1|R2 as f32, [512,1296) R1|R2 as f64, [1296,2256) w_init|w_min|w_max
+    if (hipMalloc(&h->d_rfull, kConstBytes) != hipSuccess) {
+      fail(nullptr, RCG_ERR_HIP, "rcg_create: allocating the constant block");
       delete h;
       return RCG_ERR_HIP;
     }
-    float r32[98];
-    double r64[98];
-    build_params<float>(h, &h->p32, r32);
-    build_params<double>(h, &h->p64, r64);
-    hipError_t er = cfg->dtype == RCG_F64 ? hipMemcpy(h->d_rfull, r64, sizeof r64, hipMemcpyHostToDevice)
-                                          : hipMemcpy(h->d_rfull, r32, sizeof r32, hipMemcpyHostToDevice);
+    unsigned char blk[kConstBytes];
+    memset(blk, 0, sizeof blk);
+    build_params<float>(h, &h->p32, reinterpret_cast<float*>(blk));
+    build_params<double>(h, &h->p64, reinterpret_cast<double*>(blk + kConstR64));
+    h->p64.Rfull = reinterpret_cast<const double*>((unsigned char*)h->d_rfull + kConstR64);
+    double* wc = reinterpret_cast<double*>(blk + kConstW);
+    for (int i = 0; i < 40; ++i) {
+      wc[i] = cfg->w_init[i];
+      wc[40 + i] = cfg->w_min[i];
+      wc[80 + i] = cfg->w_max[i];
+    }
+    hipError_t er = hipMemcpy(h->d_rfull, blk, sizeof blk, hipMemcpyHostToDevice);
     if (er != hipSuccess) {
       fail(nullptr, RCG_ERR_HIP, "rcg_create: uploading the stage-cost matrices: %s", hipGetErrorString(er));
       (void)hipFree(h->d_rfull);
@@ -632,13 +645,42 @@ int rcg_sim_step(rcg_handle* h, int32_t n_substeps) {
 int rcg_critic_update(rcg_handle* h, int32_t do_fit) {
   if (!h) return RCG_ERR_BAD_ARG;
   if (!h->f[RCG_FIELD_OBS_BUF]) return fail(h, RCG_ERR_BAD_ARG, "rcg_critic_update: handle has no critic buffers (buffer_size = 0)");
-  if (do_fit) return fail(h, RCG_ERR_UNSUPPORTED, "rcg_critic_update: critic fit is not built yet");
+  const int m = h->cfg.n_critic - 1;
+  if (do_fit && (m < 1 || m > kFitMaxRows))
+    return fail(h, RCG_ERR_UNSUPPORTED, "rcg_critic_update: the native critic fit needs 1 <= Ncritic-1 <= %d (got %d)",
+                kFitMaxRows, m);
   return dispatch(h, [&](auto sys, auto r) {
     using Sys = decltype(sys);
     using real = decltype(r);
-    hipLaunchKernelGGL((k_critic_push<Sys, real>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream,
-                       (real*)h->f[RCG_FIELD_OBS_BUF], (real*)h->f[RCG_FIELD_ACT_BUF], (const real*)h->f[RCG_FIELD_STATE],
-                       (const real*)h->f[RCG_FIELD_ACTION], params<real>(h));
+    {
+      ProfScope prof_scope(h, RCG_KERNEL_CRITIC);
+      hipLaunchKernelGGL((k_critic_push<Sys, real>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream,
+                         (real*)h->f[RCG_FIELD_OBS_BUF], (real*)h->f[RCG_FIELD_ACT_BUF],
+                         (const real*)h->f[RCG_FIELD_STATE], (const real*)h->f[RCG_FIELD_ACTION], params<real>(h));
+      if (do_fit) {
+        FitArgs<real> F;
+        F.w_critic = (real*)h->f[RCG_FIELD_W_CRITIC];
+        F.w_prev = (real*)h->f[RCG_FIELD_W_PREV];
+        F.obs_buf = (const real*)h->f[RCG_FIELD_OBS_BUF];
+        F.act_buf = (const real*)h->f[RCG_FIELD_ACT_BUF];
+        F.wcfg = reinterpret_cast<const double*>((unsigned char*)h->d_rfull + kConstW);
+        const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
+#define RCG_FIT(CS)                                                                                         \
+  do {                                                                                                      \
+    if (m <= 3)                                                                                             \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, 3>), grid, block, 0, h->stream, F, h->p64);           \
+    else                                                                                                    \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, h->stream, F, h->p64); \
+  } while (0)
+        switch (h->cfg.critic_struct) {
+          case RCG_CRITIC_QUAD_LIN: RCG_FIT(RCG_CRITIC_QUAD_LIN); break;
+          case RCG_CRITIC_QUADRATIC: RCG_FIT(RCG_CRITIC_QUADRATIC); break;
+          case RCG_CRITIC_QUAD_NOMIX: RCG_FIT(RCG_CRITIC_QUAD_NOMIX); break;
+          default: RCG_FIT(RCG_CRITIC_QUAD_MIX); break;
+        }
+#undef RCG_FIT
+      }
+    }
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
@@ -649,9 +691,12 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
   int rc = rcg_sim_step(h, h->cfg.substeps_per_tick);
   if (rc) return rc;
   if (h->cfg.mode != RCG_MODE_MPC) {
-    rc = rcg_critic_update(h, 1);
+    // critic_period = critic_every_ticks * sampling_time (controllers.py:1466-1477)
+    const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
+    rc = rcg_critic_update(h, (h->tick_count % every) == 0 ? 1 : 0);
     if (rc) return rc;
   }
+  h->tick_count += 1;
   return dispatch(h, [&](auto sys, auto r) {
     return launch_actor<decltype(sys), decltype(r)>(h, "rcg_control_tick", cand, K, nullptr, nullptr, nullptr, nullptr,
                                                     h->f[RCG_FIELD_ACTION], h->f[RCG_FIELD_BEST_J],

@@ -33,6 +33,7 @@ class EngineConfig:
     Ncritic: int = 4
     buffer_size: int = 0  # 0: no critic buffers (MPC)
     substeps_per_tick: int = 1
+    critic_every_ticks: int = 1  # critic_period / sampling_time (controllers.py:1466)
     dt_sim: float = 0.01
     sampling_time: float = 0.01
     pred_step_size: float = 0.02
@@ -60,6 +61,7 @@ class EngineConfig:
         c.critic_struct = N.CRITIC_IDS[self.critic_struct]
         c.n_critic, c.buffer_size = int(self.Ncritic), int(self.buffer_size)
         c.substeps_per_tick = int(self.substeps_per_tick)
+        c.critic_every_ticks = int(self.critic_every_ticks)
         c.dt_sim, c.sampling_time = float(self.dt_sim), float(self.sampling_time)
         c.pred_step_size, c.gamma = float(self.pred_step_size), float(self.gamma)
         flags = 0

@@ -1,0 +1,102 @@
+"""Simulator with the reference's interface (rcognita/simulator.py), backed by librcg.
+
+``Simulator.sim_step`` integrates ``closed_loop_rhs`` with the build's fixed-step classical RK4
+(``rcg_sim_step``) instead of scipy's adaptive RK45: one call advances exactly ``dt`` (``n_substeps``
+RK4 substeps of ``dt / n_substeps``), time is ``t0 + k*dt`` with an integer step counter, so tick and
+episode indexing is exact.  ``max_step, first_step, atol, rtol`` are accepted for signature
+compatibility and ignored (the reference itself ignores ``max_step``, rcognita/simulator.py:150).
+Against the reference's RK45 loop under a constant action the trajectories agree to < 1e-5 relative
+(tests/test_hip_parity.py::test_F6_hip_rk4_vs_reference_rk45).
+
+``state_init`` may be ``[ds]`` (one env, as in the reference) or ``[B, ds]`` (a batch of envs).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native as N
+from .engine import Engine, EngineConfig
+from .systems import System
+
+
+class Simulator:
+    def __init__(self, sys_type, closed_loop_rhs, sys_out, state_init, disturb_init=[], action_init=[], t0=0, t1=1,
+                 dt=1e-2, max_step=0.5e-2, first_step=1e-6, atol=1e-5, rtol=1e-3, is_disturb=0, is_dyn_ctrl=0,
+                 n_substeps=1, dtype="f64", device=0):
+        if sys_type != "diff_eqn":
+            raise NotImplementedError("only sys_type='diff_eqn' is on the native path (SURVEY.md 8a row 2)")
+        if is_disturb or is_dyn_ctrl:
+            raise NotImplementedError("is_disturb / is_dyn_ctrl are out of scope (SURVEY.md 8a rows 1, 8)")
+        sys_obj = getattr(closed_loop_rhs, "__self__", None)
+        if not isinstance(sys_obj, System):
+            raise TypeError(
+                "closed_loop_rhs must be the bound method of a rcognita_amd System (e.g. my_sys.closed_loop_rhs): "
+                "arbitrary Python callables cannot run on the native path and there is no CPU fallback")
+        self.sys = sys_obj
+        self.sys_type = sys_type
+        self.closed_loop_rhs = closed_loop_rhs
+        self.sys_out = sys_out
+        self.dt = dt
+        self.t0, self.t1 = t0, t1
+        self.n_substeps = int(n_substeps)
+
+        state_init = np.asarray(state_init, dtype=float)
+        self._batched = state_init.ndim == 2
+        self.dim_state = state_init.shape[-1]
+        x0 = state_init.reshape(-1, self.dim_state)
+        self.B = x0.shape[0]
+        spec = sys_obj.native_spec()
+        a0 = np.zeros(sys_obj.dim_input) if len(action_init) == 0 else np.asarray(action_init, dtype=float)
+        self._eng = Engine(EngineConfig(sys_id=spec["sys_id"], batch=self.B, dtype=dtype, device=device,
+                                        pars=spec["pars"], ctrl_bnds=spec["ctrl_bnds"],
+                                        dt_sim=float(dt) / self.n_substeps, sampling_time=float(dt),
+                                        action_init=a0.reshape(-1)[: sys_obj.dim_input]))
+        self._eng.set_state(x0)
+        self.state_full_init = state_init.copy()
+        self.step_idx = 0  # int: sim steps done in the current episode
+        self.episode_idx = 0
+        self.t = t0
+        self.state_full = state_init.copy()
+        self.state = self.state_full
+        self.observation = self.sys_out(self.state)
+
+    def _shape(self, a):
+        return a if self._batched else a[0]
+
+    def sim_step(self):
+        """One simulation step of length ``dt`` (rcognita/simulator.py:156-168): the action held by the
+        system object is clipped to the control bounds and applied over the whole step."""
+        act = np.broadcast_to(np.asarray(self.sys.action, dtype=float), (self.B, self.sys.dim_input))
+        self._eng.set_field(N.FIELD_ACTION, act)
+        self._eng.sim_step(self.n_substeps)
+        self.step_idx += 1
+        self.t = self.t0 + self.step_idx * self.dt
+        st = self._eng.get_state().astype(float)
+        self.state_full = self._shape(st)
+        self.state = self.state_full
+        self.observation = self.sys_out(self.state)
+        # what System.closed_loop_rhs leaves behind in the reference: the clipped action and the
+        # state of the last RHS evaluation (rcognita/systems.py:241-251)
+        if self.sys.ctrl_bnds.any():
+            b = self.sys.ctrl_bnds
+            self.sys.action = np.clip(np.asarray(self.sys.action, dtype=float), b[:, 0], b[:, 1])
+        self.sys._state = self.state
+
+    def get_sim_step_data(self):
+        """rcognita/simulator.py:187-195."""
+        return self.t, self.state, self.observation, self.state_full
+
+    def status(self):
+        """Per-env status words (bit 0: a non-finite state was produced; the env is frozen)."""
+        return self._eng.get_field(N.FIELD_STATUS)
+
+    def reset(self):
+        """Episode reset (rcognita/simulator.py:197-204, whose ``.observation`` assignment never resets
+        the solver state - SURVEY.md 3.4): here the state really returns to ``state_init``."""
+        self._eng.episode_reset()
+        self.step_idx = 0
+        self.episode_idx += 1
+        self.t = self.t0
+        self.state_full = self.state_full_init.copy()
+        self.state = self.state_full
+        self.observation = self.sys_out(self.state)

@@ -1,0 +1,126 @@
+"""RQL/SQL side of the path on the GPU: buffer push, critic fit (replacement of the reference's SLSQP
+_critic_optimizer) and the fused control tick with a learned terminal/stacked critic.  ``gpu`` marked."""
+import numpy as np
+import pytest
+
+from oracle import rcg_oracle as O
+from tests.conftest import load_golden
+from tests.helpers import SYSTEMS, both, rand_actions, rand_states, rel_err_norm
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_buffers(eng, N, obs_buf, act_buf, w_prev):
+    """Arrange the handle so that ONE push (rcg_critic_update) leaves exactly (obs_buf, act_buf):
+    rows shifted down by one, the newest row supplied through STATE / ACTION."""
+    B, bs, _ = obs_buf.shape
+    ob = np.concatenate([np.zeros_like(obs_buf[:, :1]), obs_buf[:, :-1]], axis=1)
+    ab = np.concatenate([np.zeros_like(act_buf[:, :1]), act_buf[:, :-1]], axis=1)
+    eng.set_field(N.FIELD_OBS_BUF, ob)
+    eng.set_field(N.FIELD_ACT_BUF, ab)
+    eng.set_field(N.FIELD_STATE, obs_buf[:, -1])
+    eng.set_field(N.FIELD_ACTION, act_buf[:, -1])
+    eng.set_field(N.FIELD_W_PREV, w_prev)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_critic_fit_vs_oracle_and_reference_slsqp(name, dtype):
+    """TD stacks of the golden F8 fixture: (a) HIP fit == oracle fit (same algorithm, float64 inside);
+    (b) the cost reached is never worse than what the reference's SLSQP reached, nor than the start."""
+    from rcognita_amd import _native as N
+
+    meta, z = load_golden(f"F8_slsqp_critic_{name}")
+    for c in meta["cases"]:
+        cs = c["tag"]
+        ob, ab, wp = z[f"{cs}__obs_buf"], z[f"{cs}__act_buf"], z[f"{cs}__w_prev"]
+        B = ob.shape[0]
+        eng, cfg = both(name, B, dtype, mode=O.MODE_RQL, gamma=c["gamma"], critic_struct=O.CRITIC_IDS[cs],
+                        n_critic=c["Ncritic"], buffer_size=c["buffer_size"])
+        _load_buffers(eng, N, ob, ab, wp)
+        eng.critic_update(do_fit=True)
+        np.testing.assert_array_equal(eng.get_field(N.FIELD_OBS_BUF), ob.astype(eng.real))  # push_vec
+        np.testing.assert_array_equal(eng.get_field(N.FIELD_ACT_BUF), ab.astype(eng.real))
+        w = eng.get_field(N.FIELD_W_CRITIC).astype(np.float64)
+        np.testing.assert_array_equal(eng.get_field(N.FIELD_W_PREV).astype(np.float64), w)
+        # the oracle sees the same (dtype-rounded) buffers the device holds
+        rb = lambda a: a.astype(eng.real).astype(np.float64)
+        w_or = O.critic_fit(cfg, rb(wp), rb(ob), rb(ab))
+        Jc = O.critic_cost(w, rb(wp), rb(ob), rb(ab), cfg)
+        Jc_or = O.critic_cost(w_or, rb(wp), rb(ob), rb(ab), cfg)
+        J0, Js = z[f"{cs}__Jc_init"], z[f"{cs}__Jc_fit"]
+        lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
+        assert np.all(w >= lo - 1e-4) and np.all(w <= hi + 1e-3), cs
+        tolw = 1e-6 if dtype == "f64" else 2e-4  # f32: w is stored rounded to float
+        assert rel_err_norm(w, w_or) < tolw, (cs, rel_err_norm(w, w_or))
+        assert np.all(np.abs(Jc - Jc_or) <= 1e-5 * J0 + 1e-9), cs
+        slack = 1e-6 if dtype == "f64" else 1e-4
+        assert np.all(Jc <= Js * (1 + slack) + slack * J0), (cs, float(np.max((Jc - Js) / J0)))
+        assert np.all(Jc <= J0 * (1 + slack)), cs
+
+
+@pytest.mark.parametrize("m_rows", [1, 2, 5, 8])
+def test_critic_fit_row_counts(m_rows):
+    """Ncritic - 1 = 1 .. 8 rows (both kernel instantiations), random stacks, vs the oracle."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(40 + m_rows)
+    B, bs = 33, 12
+    eng, cfg = both("2tank", B, "f64", mode=O.MODE_SQL, gamma=0.95, critic_struct=O.CRITIC_QUADRATIC,
+                    n_critic=m_rows + 1, buffer_size=bs)
+    ob = np.stack([rand_states(rng, "2tank", bs) for _ in range(B)])
+    ab = rand_actions(rng, "2tank", (B, bs))
+    wp = rng.uniform(0.5, 1.5, (B, cfg.dc))
+    _load_buffers(eng, N, ob, ab, wp)
+    eng.critic_update(do_fit=True)
+    w = eng.get_field(N.FIELD_W_CRITIC)
+    w_or = O.critic_fit(cfg, wp, ob, ab)
+    assert rel_err_norm(w, w_or) < 1e-6
+    np.testing.assert_allclose(eng.critic_cost(), O.critic_cost(w_or, w_or, ob, ab, cfg), rtol=1e-5, atol=1e-12)
+
+
+def test_critic_fit_too_many_rows_is_refused():
+    from rcognita_amd import _native as N
+
+    eng, _ = both("2tank", 4, "f64", mode=O.MODE_RQL, n_critic=12, buffer_size=20)
+    with pytest.raises(N.NativeError) as ei:
+        eng.critic_update(do_fit=True)
+    assert ei.value.code == N.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name,mode,cs,K,every", [
+    ("2tank", O.MODE_RQL, O.CRITIC_QUADRATIC, 32, 1),      # BASELINE configs[2] shape (small batch)
+    ("2tank", O.MODE_SQL, O.CRITIC_QUAD_NOMIX, 16, 2),
+    ("3wrobotNI", O.MODE_RQL, O.CRITIC_QUAD_MIX, 64, 1),
+    ("3wrobot", O.MODE_SQL, O.CRITIC_QUAD_NOMIX, 16, 3),
+])
+def test_rql_sql_control_tick_vs_oracle(name, mode, cs, K, every, dtype):
+    """Fused tick with critic: sim -> push -> fit (every `every` ticks) -> actor argmin with Q_w."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(17 + K)
+    B, Nh = 19, 5
+    T = 9 if dtype == "f64" else 3
+    eng, cfg = both(name, B, dtype, n_actor=Nh, mode=mode, critic_struct=cs, gamma=0.95, n_critic=4,
+                    buffer_size=6, critic_every_ticks=every)
+    x0 = rand_states(rng, name, B)
+    eng.set_state(x0)
+    env = O.new_batch(cfg, x0)
+    cand = O.grid_candidates(cfg, K)
+    checked = 0
+    for t in range(T):
+        eng.control_tick(None, K=K)
+        O.control_tick(cfg, env, cand)
+        w = eng.get_field(N.FIELD_W_CRITIC).astype(np.float64)
+        bi = eng.get_field(N.FIELD_BEST_IDX)
+        if dtype == "f32" and (not np.array_equal(bi, env.best_idx) or rel_err_norm(w, env.w_critic) > 1e-3):
+            break  # f32 rounding of the buffers moved the fit / flipped a near-tie: stop comparing
+        assert rel_err_norm(w, env.w_critic) < (1e-6 if dtype == "f64" else 1e-3), t
+        np.testing.assert_array_equal(bi, env.best_idx)
+        tol = 1e-9 if dtype == "f64" else 1e-4
+        assert rel_err_norm(eng.get_state(), env.state) < tol
+        assert rel_err_norm(eng.get_field(N.FIELD_ACCUM), env.accum, floor=float(np.max(np.abs(env.accum)))) < tol
+        np.testing.assert_allclose(eng.get_field(N.FIELD_OBS_BUF), env.obs_buf, rtol=tol * 10, atol=tol)
+        checked += 1
+    assert checked >= (T if dtype == "f64" else 1)
