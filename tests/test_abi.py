@@ -62,10 +62,24 @@ def test_create_argument_validation_and_no_cpu_fallback():
 
 def test_product_package_never_imports_the_oracle():
     """The oracle is test infrastructure; nothing under rcognita_amd/ may reference it."""
+    import ast
+
     pkg = os.path.join(ROOT, "rcognita_amd")
     for dp, _, fns in os.walk(pkg):
         for fn in fns:
-            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
-                txt = open(os.path.join(dp, fn), errors="replace").read()
-                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, fn)
-                assert "rcg_oracle" not in txt and "liboracle" not in txt, os.path.join(dp, fn)
+            path = os.path.join(dp, fn)
+            if fn.endswith(".py"):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        mods = [node.module or ""]
+                    assert not any(m.split(".")[0] == "oracle" or "rcg_oracle" in m or "c_oracle" in m for m in mods), path
+                    if isinstance(node, ast.Constant) and isinstance(node.value, str) and len(node.value) < 200:
+                        assert "liboracle" not in node.value and "oracle/_build" not in node.value, path
+            elif fn.endswith((".hip", ".hpp", ".h", ".cpp")):
+                txt = open(path, errors="replace").read()
+                code = re.sub(r"//.*?$|/\*.*?\*/", "", txt, flags=re.S | re.M)  # comments may CITE the oracle
+                assert "oracle" not in code, path  # no #include, dlopen or symbol of the oracle in product code
