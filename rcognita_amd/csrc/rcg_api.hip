@@ -334,7 +334,7 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(nullptr, RCG_ERR_NO_DEVICE,
-                "rcg_create: no HIP device visible; librcg has no CPU fallback (the CPU oracle lives under oracle/)");
+                "rcg_create: no HIP device visible; librcg has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev)
     return fail(nullptr, RCG_ERR_BAD_ARG, "rcg_create: device %d out of range (%d visible)", cfg->device, ndev);
   HIPCHK(nullptr, hipSetDevice(cfg->device));
