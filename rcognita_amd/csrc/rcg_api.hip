@@ -8,8 +8,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rcg_critic_fit.hpp"
@@ -271,6 +273,53 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
   const KParams<real>& P = params<real>(h);
   ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+
+  // Production shape (f32, MPC + diagonal R1, K a multiple of 64, 16-B granular rows of <= 8 KiB per tile)
+  // -> k_actor_dma.  Development knobs, read per launch: RCG_ACTOR_KERNEL=plain forces k_actor,
+  // RCG_GPW=<n> sets the envs per persistent wave, RCG_DBG=1 selects the timing-only variant.
+  const int nrow = (int)(row_bytes / 16);
+  if (const char* e = getenv("RCG_DBG")) A.dbg = atoi(e);
+  const char* ksel = getenv("RCG_ACTOR_KERNEL");
+  const bool force_plain = ksel && !strcmp(ksel, "plain");
+  if constexpr (std::is_same<real, float>::value) {
+    if (cand && A.vec_ok && K >= 64 && (K % 64) == 0 && nrow >= 1 && nrow <= 8 && !generic && !force_plain) {
+      long gpw = B / (256L * 20);  // about one round of fully resident waves on 256 CUs
+      if (const char* e = getenv("RCG_GPW")) gpw = atol(e);
+      gpw = gpw < 1 ? 1 : (gpw > 8 ? 8 : gpw);
+      A.gpw = (int)gpw;
+      const long pw = (B + gpw - 1) / gpw;
+      const unsigned pblocks = (unsigned)((pw + wpb - 1) / wpb);
+      const bool same = A.obs == A.state_sys;  // tick mode without ref_lag: one state array
+#define RCG_LAUNCH_DMA2(TG, NR)                                                                                   \
+  do {                                                                                                            \
+    if (same)                                                                                                     \
+      hipLaunchKernelGGL((k_actor_dma<Sys, TG, NR, true>), dim3(pblocks), dim3(64 * wpb), lds, h->stream, A, P);  \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_actor_dma<Sys, TG, NR, false>), dim3(pblocks), dim3(64 * wpb), lds, h->stream, A, P); \
+  } while (0)
+#define RCG_LAUNCH_DMA(NR)     \
+  case NR:                     \
+    if (tgt)                   \
+      RCG_LAUNCH_DMA2(true, NR);  \
+    else                       \
+      RCG_LAUNCH_DMA2(false, NR); \
+    break;
+      switch (nrow) {
+        RCG_LAUNCH_DMA(1)
+        RCG_LAUNCH_DMA(2)
+        RCG_LAUNCH_DMA(3)
+        RCG_LAUNCH_DMA(4)
+        RCG_LAUNCH_DMA(5)
+        RCG_LAUNCH_DMA(6)
+        RCG_LAUNCH_DMA(7)
+        RCG_LAUNCH_DMA(8)
+      }
+#undef RCG_LAUNCH_DMA
+#undef RCG_LAUNCH_DMA2
+      HIPCHK(h, hipGetLastError());
+      return RCG_OK;
+    }
+  }
 #define RCG_LAUNCH_ACTOR(GEN, TGT, STR) \
   hipLaunchKernelGGL((k_actor<Sys, real, GEN, TGT, STR>), dim3(blocks), dim3(64 * wpb), lds, h->stream, A, P)
 #define RCG_LAUNCH_ACTOR2(GEN, TGT) \

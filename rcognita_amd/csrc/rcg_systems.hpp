@@ -3,7 +3,9 @@
 // Each policy gives the dimensions and the open-loop right-hand side `Sys*._state_dyn` of the
 // reference (disturbance-free branch; is_disturb = 0 in every preset).
 // `Pre` holds per-env values derived once from the parameter vector (e.g. 1/m), so the rollout's
-// inner loop does no divisions.
+// inner loop does no divisions.  `rhs<real, HW>`: HW = true selects the hardware sin/cos form
+// (rcg_math.hpp, f32 only) used by the streamed rollout fast path; everything else - the simulator's
+// RK4 in particular - uses the accurate polynomial form.
 #pragma once
 #include "rcg_math.hpp"
 
@@ -20,10 +22,10 @@ struct Sys3WRobot {
   __device__ __forceinline__ static Pre<real> prepare(const real* p) {
     return {(real)1 / p[0], (real)1 / p[1]};
   }
-  template <typename real>
+  template <typename real, bool HW = false>
   __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
     real s, c;
-    sincos_r<real>(x[2], &s, &c);
+    sincos_sel<real, HW>(x[2], &s, &c);
     d[0] = x[3] * c;
     d[1] = x[3] * s;
     d[2] = x[4];
@@ -41,10 +43,10 @@ struct Sys3WRobotNI {
   __device__ __forceinline__ static Pre<real> prepare(const real*) {
     return {};
   }
-  template <typename real>
+  template <typename real, bool HW = false>
   __device__ __forceinline__ static void rhs(const Pre<real>&, const real* x, const real* u, real* d) {
     real s, c;
-    sincos_r<real>(x[2], &s, &c);
+    sincos_sel<real, HW>(x[2], &s, &c);
     d[0] = u[0] * c;
     d[1] = u[0] * s;
     d[2] = u[1];
@@ -62,7 +64,7 @@ struct Sys2Tank {
   __device__ __forceinline__ static Pre<real> prepare(const real* p) {
     return {(real)1 / p[0], (real)1 / p[1], p[2], p[3], p[4]};
   }
-  template <typename real>
+  template <typename real, bool HW = false>
   __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
     d[0] = q.inv_tau1 * (-x[0] + q.K1 * u[0]);
     d[1] = q.inv_tau2 * (-x[1] + q.K2 * x[0] + q.K3 * (x[1] * x[1]));
