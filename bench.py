@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--profile-stride", type=int, default=8,
+                   help="bracket every n-th kernel launch of the timed region with HIP events (0 = none)")
     return p.parse_args()
 
 
@@ -64,13 +66,15 @@ def synth_state(rank, B):
                      rng.uniform(-1, 1, B), rng.uniform(-1, 1, B)], axis=-1)
 
 
-def actor_bytes_per_launch(B, K, N, du, ds, esz, streamed):
-    """Algorithmic HBM bytes of one k_actor launch in tick mode (DESIGN.md 'Bytes')."""
+def actor_bytes_per_launch(B, K, N, du, ds, esz, streamed, fused_sim):
+    """Algorithmic HBM bytes of one actor launch in tick mode (DESIGN.md 'Bytes')."""
     per_env = ds * esz  # state read (obs == state_sys)
     per_env += du * esz + esz + 4  # action, best_J, best_idx writes
     per_env += 2 * esz + 2 * 4  # accum and step_idx read-modify-write
     if streamed:
         per_env += K * N * du * esz  # the candidate rows
+    if fused_sim:  # env step inside the launch: held action + status read, state + state_prev written
+        per_env += du * esz + 4 + 2 * ds * esz
     return B * per_env
 
 
@@ -154,7 +158,10 @@ def main():
     returns_dev = torch.empty(B, device="cuda", dtype=tdtype)
     gathered = [torch.empty_like(returns_dev) for _ in range(world)] if dist is not None else None
 
-    eng.profile(True)  # HIP events around k_sim / k_actor on the engine's stream, inside the timed region
+    # HIP events around the kernels of the tick on the engine's own stream, inside the timed region; sampled
+    # (every n-th launch) because each event is a marker packet on the stream.
+    if args.profile_stride > 0:
+        eng.profile((N.KERNEL_ACTOR, N.KERNEL_SIM), stride=args.profile_stride)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -186,7 +193,8 @@ def main():
     units = world * B * args.steps
     value = units / dt
     streamed = args.regime == "streamed"
-    bytes_launch = actor_bytes_per_launch(B, K, Nh, du, ds, esz, streamed)
+    fused_sim = False  # the env step is its own launch (k_sim); kept as a parameter of the byte model
+    bytes_launch = actor_bytes_per_launch(B, K, Nh, du, ds, esz, streamed, fused_sim)
     actor_avg_s = (actor_ms / max(actor_n, 1)) * 1e-3
     achieved = bytes_launch / actor_avg_s if actor_avg_s > 0 else 0.0
     traffic = None
@@ -214,10 +222,12 @@ def main():
                                f"K={K} {args.regime} candidates (BASELINE configs[1])",
                    "envs_per_gpu": B, "candidates": K, "nactor": Nh, "regime": args.regime,
                    "parallelism": f"env-shard x{world}", "actor_cost_evals_per_s": value * K},
-        "roofline": {"bound": "hbm", "kernel": "k_actor", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "k_actor_dma" if (streamed and args.dtype == "f32" and K % 64 == 0) else "k_actor",
+                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": actor_avg_s * 1e3,
-                     "launches": actor_n, "sim_kernel_avg_ms": sim_ms / max(sim_n, 1),
+                     "launches_timed": actor_n, "event_stride": args.profile_stride,
+                     "sim_kernel_avg_ms": (sim_ms / sim_n) if sim_n else None,
                      "note": ("streamed regime: HBM-bound" if streamed else
                               "generated regime is VALU-bound; the HBM fraction is reported for completeness only")},
         "returns_summary": total,
@@ -243,7 +253,7 @@ def main():
         # (2) pure env step: RK4 of closed_loop_rhs only (Simulator.sim_step), 64 B/env algorithmic
         for _ in range(5):
             eng2.sim_step(1)
-        eng2.profile(True)
+        eng2.profile((N.KERNEL_SIM,))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         n3 = 200
@@ -254,7 +264,7 @@ def main():
         ms3, c3 = eng2.profile_read(N.KERNEL_SIM)
         eng2.profile(False)
         sec["sim_step_only"] = {"env_steps_per_s_wall": B * n3 / d3, "kernel_avg_us": ms3 / max(c3, 1) * 1e3,
-                                "kernel_GBps": B * (2 * ds + du + 1) * esz * 2 / 2 / max(ms3 / max(c3, 1) * 1e-3, 1e-12) / 1e9}
+                                "kernel_GBps": B * ((3 * ds + du) * esz + 4) / max(ms3 / max(c3, 1) * 1e-3, 1e-12) / 1e9}
         eng2.close()
         out["secondary"] = sec
 

@@ -1,0 +1,115 @@
+// rcg_handle.hpp - host-side state shared by the translation units of librcg.so.
+//
+// The library is split so that hipcc can build it in parallel: rcg_api.hip holds the C ABI and the
+// system-independent kernels; rcg_sys_<system>.hip each instantiate every system-templated kernel and
+// launcher for one environment (rcg_sysops.hpp) and export them through a SysVTable.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rcg_kernels.hpp"
+
+struct rcg_handle {
+  rcg_cfg cfg;
+  int ds, du, np, dc, nchi;
+  size_t esz;  // sizeof(real)
+  hipStream_t stream;
+  void* f[RCG_FIELD_COUNT_];
+  size_t fbytes[RCG_FIELD_COUNT_];
+  double* d_summary;
+  long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
+  void* d_const;    // constant block in HBM, layout kConst* below
+  rcg::KParams<float> p32;
+  rcg::KParams<double> p64;
+  const struct SysVTable* sys;
+  std::string err;
+  // measurement (rcg_profile): event pairs recorded on `stream`, drained into totals on demand
+  unsigned prof_mask;  // bit k: bracket launches of rcg_kernel k
+  unsigned prof_stride;                    // ... every prof_stride-th launch (>= 1)
+  uint64_t prof_seen[RCG_KERNEL_COUNT_];   // launches seen since rcg_profile()
+  std::vector<hipEvent_t> ev_free;
+  struct Pending {
+    hipEvent_t a, b;
+    int kernel;
+  };
+  std::vector<Pending> ev_pending;
+  double prof_ms[RCG_KERNEL_COUNT_];
+  int64_t prof_n[RCG_KERNEL_COUNT_];
+};
+
+// [0,392) R1|R2 as f32, [512,1296) R1|R2 as f64, [1296,2256) w_init|w_min|w_max as f64
+static constexpr size_t kConstR64 = 512, kConstW = 1296, kConstBytes = 2256;
+static constexpr int kFitMaxRows = 8;  // Ncritic - 1 <= 8 for the native critic fit
+
+// sets the handle's (or, for h == nullptr, the thread's) error text and returns `code`
+int rcg_fail(rcg_handle* h, int code, const char* fmt, ...);
+
+#define HIPCHK(h, call)                                                                                 \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return rcg_fail((h), RCG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                      __LINE__);                                                                        \
+  } while (0)
+
+// RAII bracket: records start/stop events around the launches made while it is alive
+struct ProfScope {
+  rcg_handle* h;
+  hipEvent_t a, b;
+  int kernel;
+  bool on;
+  ProfScope(rcg_handle* h_, int kernel_)
+      : h(h_), a(nullptr), b(nullptr), kernel(kernel_), on((h_->prof_mask >> kernel_) & 1u) {
+    if (!on) return;
+    // sampled: only every prof_stride-th launch of this kernel is bracketed (each event is a marker packet
+    // on the stream; bracketing every launch of a ~230 us kernel costs a few percent of throughput)
+    if ((h->prof_seen[kernel]++ % h->prof_stride) != 0) {
+      on = false;
+      return;
+    }
+    for (hipEvent_t* e : {&a, &b}) {
+      if (!h->ev_free.empty()) {
+        *e = h->ev_free.back();
+        h->ev_free.pop_back();
+      } else if (hipEventCreate(e) != hipSuccess) {
+        on = false;
+        return;
+      }
+    }
+    (void)hipEventRecord(a, h->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, h->stream);
+    h->ev_pending.push_back({a, b, kernel});
+  }
+};
+
+template <typename real>
+inline const rcg::KParams<real>& params(const rcg_handle* h);
+template <>
+inline const rcg::KParams<float>& params<float>(const rcg_handle* h) {
+  return h->p32;
+}
+template <>
+inline const rcg::KParams<double>& params<double>(const rcg_handle* h) {
+  return h->p64;
+}
+
+static inline unsigned blocks_for(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// Everything that depends on the system type, one table per environment (rcg_sys_*.hip).
+struct SysVTable {
+  int (*rhs)(rcg_handle*, const void* state, const void* action, void* dstate, void* clipped, int32_t n, int32_t clip);
+  int (*stage_obj)(rcg_handle*, const void* obs, const void* act, void* out, int32_t n);
+  int (*critic)(rcg_handle*, const void* obs, const void* act, const void* w, void* out, int32_t n);
+  int (*critic_cost)(rcg_handle*, const void* w, void* Jc);
+  int (*actor)(rcg_handle*, const char* who, const void* cand, int K, const void* obs, const void* state_sys,
+               const void* w, void* J, void* action, void* best_J, int32_t* best_idx, bool tick, bool sim_first);
+  int (*sim_step)(rcg_handle*, int32_t n_substeps);
+  int (*critic_update)(rcg_handle*, int32_t do_fit);
+};
+extern const SysVTable kVt3WRobot, kVt3WRobotNI, kVt2Tank;

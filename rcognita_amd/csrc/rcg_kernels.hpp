@@ -146,6 +146,29 @@ __device__ __forceinline__ typename Sys::template Pre<real> load_pre(const KPara
   return Sys::template prepare<real>(pv);
 }
 
+// One classical RK4 step of the closed loop under a held (already clipped) action u: the build's
+// replacement of scipy RK45 inside Simulator.sim_step (simulator.py:156-168).  Same operation order as
+// oracle rk4_step: x + h/6 * (((k1 + 2 k2) + 2 k3) + k4).
+template <typename Sys, typename real>
+__device__ __forceinline__ void rk4_step(const typename Sys::template Pre<real>& pre, real* x, const real* u,
+                                         real dt) {
+  constexpr int DS = Sys::DS;
+  const real h = dt, hh = (real)0.5 * dt, h6 = dt / (real)6;
+  real k1[DS], k2[DS], k3[DS], k4[DS], t[DS];
+  Sys::template rhs<real>(pre, x, u, k1);
+#pragma unroll
+  for (int c = 0; c < DS; ++c) t[c] = fma_r(hh, k1[c], x[c]);
+  Sys::template rhs<real>(pre, t, u, k2);
+#pragma unroll
+  for (int c = 0; c < DS; ++c) t[c] = fma_r(hh, k2[c], x[c]);
+  Sys::template rhs<real>(pre, t, u, k3);
+#pragma unroll
+  for (int c = 0; c < DS; ++c) t[c] = fma_r(h, k3[c], x[c]);
+  Sys::template rhs<real>(pre, t, u, k4);
+#pragma unroll
+  for (int c = 0; c < DS; ++c) x[c] = fma_r(h6, ((k1[c] + (real)2 * k2[c]) + (real)2 * k3[c]) + k4[c], x[c]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_actor
 // ---------------------------------------------------------------------------------------------
@@ -168,7 +191,7 @@ struct ActorArgs {
   int n_tiles;            // ceil(K / 64) (K >= 64), else 1
   int grid_g;             // generated grid: levels per input
   int vec_ok;             // rows are 16-B granular: stage with dwordx4
-  int gpw;                // k_actor_pipe: consecutive envs per (persistent) wave
+  int gpw;                // k_actor_dma: consecutive envs per (persistent) wave
   int dbg;                // development only (env RCG_DBG): bit0 = skip the rollout (timing-only build)
 };
 
@@ -414,7 +437,6 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
     for (int j = 0; j < NROW; ++j)
       __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 64), (lds_void*)(tile + j * 1024), 16, 0, 2 /* nt */);
   };
-  issue_dma(gv);
 
   // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
   // "pointer ? load : default" selects (a default written into a register with a load in flight would
@@ -434,6 +456,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
     }
   };
   fetch_env(env0);
+  issue_dma(gv);  // after the env request: retiring the env state must not drain the first tile
 
   const real h = P.h_pred;
   long b = env0;
@@ -582,26 +605,12 @@ __global__ __launch_bounds__(256) void k_sim(const SimArgs<real> A, const KParam
     u[c] = P.clip ? clamp_r<real>(a, P.lo[c], P.hi[c]) : a;  // systems.py:241-243
   }
   const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
-  const real h = P.dt_sim, hh = (real)0.5 * P.dt_sim, h6 = P.dt_sim / (real)6;
   real acc = 0;
 
   for (int s = 0; s < A.n_sub; ++s) {
-    real k1[DS], k2[DS], k3[DS], k4[DS], t[DS];
 #pragma unroll
     for (int c = 0; c < DS; ++c) xp[c] = x[c];
-    Sys::template rhs<real>(pre, x, u, k1);
-#pragma unroll
-    for (int c = 0; c < DS; ++c) t[c] = fma_r(hh, k1[c], x[c]);
-    Sys::template rhs<real>(pre, t, u, k2);
-#pragma unroll
-    for (int c = 0; c < DS; ++c) t[c] = fma_r(hh, k2[c], x[c]);
-    Sys::template rhs<real>(pre, t, u, k3);
-#pragma unroll
-    for (int c = 0; c < DS; ++c) t[c] = fma_r(h, k3[c], x[c]);
-    Sys::template rhs<real>(pre, t, u, k4);
-#pragma unroll
-    for (int c = 0; c < DS; ++c)
-      x[c] = fma_r(h6, ((k1[c] + (real)2 * k2[c]) + (real)2 * k3[c]) + k4[c], x[c]);
+    rk4_step<Sys, real>(pre, x, u, P.dt_sim);
     if (P.accum_every_substep) {
       real chi[NCHI];
       make_chi<DS, DU, TGT, real>(P, x, u, chi);

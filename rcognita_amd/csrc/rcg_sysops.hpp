@@ -1,0 +1,300 @@
+// rcg_sysops.hpp - host launchers of every system-templated kernel, instantiated once per environment
+// by rcg_sys_<system>.hip through make_vtable<Sys>().
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "rcg_critic_fit.hpp"
+#include "rcg_handle.hpp"
+
+namespace rcg {
+
+// f(real{}) for the handle's dtype
+template <typename F>
+static int by_dtype(rcg_handle* h, F&& f) {
+  return h->cfg.dtype == RCG_F64 ? f(double{}) : f(float{});
+}
+
+template <typename Sys>
+static int op_rhs(rcg_handle* h, const void* state, const void* action, void* dstate, void* clipped, int32_t n,
+                  int32_t clip) {
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    const real* pe = (h->f[RCG_FIELD_PARS] && n == h->cfg.batch) ? (const real*)h->f[RCG_FIELD_PARS] : nullptr;
+    hipLaunchKernelGGL((k_rhs<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const real*)state,
+                       (const real*)action, (real*)dstate, (real*)clipped, pe, (long)n, (int)clip, params<real>(h));
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+template <typename Sys>
+static int op_stage_obj(rcg_handle* h, const void* obs, const void* act, void* out, int32_t n) {
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    hipLaunchKernelGGL((k_stage_obj<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const real*)obs,
+                       (const real*)act, (real*)out, (long)n, params<real>(h));
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+template <typename Sys>
+static int op_critic(rcg_handle* h, const void* obs, const void* act, const void* w, void* out, int32_t n) {
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    hipLaunchKernelGGL((k_critic<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const real*)obs,
+                       (const real*)act, (const real*)w, (real*)out, (long)n, params<real>(h));
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+template <typename Sys>
+static int op_critic_cost(rcg_handle* h, const void* w, void* Jc) {
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    hipLaunchKernelGGL((k_critic_cost<Sys, real>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream,
+                       w ? (const real*)w : (const real*)h->f[RCG_FIELD_W_CRITIC], (const real*)h->f[RCG_FIELD_W_PREV],
+                       (const real*)h->f[RCG_FIELD_OBS_BUF], (const real*)h->f[RCG_FIELD_ACT_BUF], (real*)Jc,
+                       params<real>(h));
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+template <typename Sys>
+static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    SimArgs<real> A;
+    A.state = (real*)h->f[RCG_FIELD_STATE];
+    A.state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
+    A.action = (const real*)h->f[RCG_FIELD_ACTION];
+    A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    A.accum = (real*)h->f[RCG_FIELD_ACCUM];
+    A.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+    A.n_sub = n_substeps;
+    ProfScope prof_scope(h, RCG_KERNEL_SIM);
+    if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
+      hipLaunchKernelGGL((k_sim<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, A,
+                         params<real>(h));
+    else
+      hipLaunchKernelGGL((k_sim<Sys, real, false>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, A,
+                         params<real>(h));
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+template <typename Sys>
+static int op_critic_update(rcg_handle* h, int32_t do_fit) {
+  const int m = h->cfg.n_critic - 1;
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    ProfScope prof_scope(h, RCG_KERNEL_CRITIC);
+    hipLaunchKernelGGL((k_critic_push<Sys, real>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream,
+                       (real*)h->f[RCG_FIELD_OBS_BUF], (real*)h->f[RCG_FIELD_ACT_BUF],
+                       (const real*)h->f[RCG_FIELD_STATE], (const real*)h->f[RCG_FIELD_ACTION], params<real>(h));
+    if (do_fit) {
+      FitArgs<real> F;
+      F.w_critic = (real*)h->f[RCG_FIELD_W_CRITIC];
+      F.w_prev = (real*)h->f[RCG_FIELD_W_PREV];
+      F.obs_buf = (const real*)h->f[RCG_FIELD_OBS_BUF];
+      F.act_buf = (const real*)h->f[RCG_FIELD_ACT_BUF];
+      F.wcfg = reinterpret_cast<const double*>((unsigned char*)h->d_const + kConstW);
+      const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
+#define RCG_FIT(CS)                                                                                         \
+  do {                                                                                                      \
+    if (m <= 3)                                                                                             \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, 3>), grid, block, 0, h->stream, F, h->p64);           \
+    else                                                                                                    \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, h->stream, F, h->p64); \
+  } while (0)
+      switch (h->cfg.critic_struct) {
+        case RCG_CRITIC_QUAD_LIN: RCG_FIT(RCG_CRITIC_QUAD_LIN); break;
+        case RCG_CRITIC_QUADRATIC: RCG_FIT(RCG_CRITIC_QUADRATIC); break;
+        case RCG_CRITIC_QUAD_NOMIX: RCG_FIT(RCG_CRITIC_QUAD_NOMIX); break;
+        default: RCG_FIT(RCG_CRITIC_QUAD_MIX); break;
+      }
+#undef RCG_FIT
+    }
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+// ---- k_actor / k_actor_dma ---------------------------------------------------------------------
+// `sim_first`: rcg_control_tick (MPC) - run the env step of the tick before the decision.
+template <typename Sys, typename real>
+static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K, const void* obs,
+                        const void* state_sys, const void* w, void* J, void* action, void* best_J, int32_t* best_idx,
+                        bool tick, bool sim_first) {
+  constexpr int DU = Sys::DU;
+  const rcg_cfg& c = h->cfg;
+  if (K < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: K must be >= 1", who);
+  ActorArgs<real> A;
+  memset(&A, 0, sizeof A);
+  A.cand = (const real*)cand;
+  A.obs = obs ? (const real*)obs : (const real*)h->f[RCG_FIELD_STATE];
+  if (state_sys)
+    A.state_sys = (const real*)state_sys;
+  else if (obs)
+    A.state_sys = (const real*)obs;
+  else
+    A.state_sys = (const real*)h->f[(tick && (c.flags & RCG_FLAG_REF_LAG)) ? RCG_FIELD_STATE_PREV : RCG_FIELD_STATE];
+  A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+  A.w = w ? (const real*)w : (const real*)h->f[RCG_FIELD_W_CRITIC];
+  if (c.mode != RCG_MODE_MPC && !A.w)
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: RQL/SQL need critic weights (buffer_size > 0 or an explicit w)", who);
+  A.J = (real*)J;
+  A.action_out = (real*)action;
+  A.best_J = (real*)best_J;
+  A.best_idx = best_idx;
+  A.accum = (tick && !(c.flags & RCG_FLAG_ACCUM_EVERY_SUBSTEP)) ? (real*)h->f[RCG_FIELD_ACCUM] : nullptr;
+  A.step_idx = tick ? (int32_t*)h->f[RCG_FIELD_STEP_IDX] : nullptr;
+  A.K = K;
+  if (K >= 64) {
+    A.Kp = 64;
+    A.G = 1;
+    A.n_tiles = (K + 63) / 64;
+  } else {
+    int kp = 1;
+    while (kp < K) kp <<= 1;
+    A.Kp = kp;
+    A.G = 64 / kp;
+    A.n_tiles = 1;
+  }
+  A.grid_g = 0;
+  if (!cand) {
+    if (DU == 1) {
+      A.grid_g = K;
+    } else {
+      int g = (int)std::floor(std::sqrt((double)K) + 1e-9);
+      if (g * g != K)
+        return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: generated grid for du = 2 needs a square K (got %d)", who, K);
+      A.grid_g = g;
+    }
+  }
+  const int R = c.n_actor * DU;
+  const size_t row_bytes = (size_t)R * sizeof(real);
+  A.vec_ok = (cand && row_bytes % 16 == 0 && ((uintptr_t)cand % 16) == 0) ? 1 : 0;
+  const long B = c.batch;
+  const long n_waves = (B + A.G - 1) / A.G;
+  int wpb = 4;  // waves per workgroup
+  size_t lds_per_wave = cand ? 64 * row_bytes : 0;
+  while (wpb > 1 && lds_per_wave * wpb > 64 * 1024) wpb >>= 1;
+  const size_t lds = lds_per_wave * wpb;
+  const unsigned blocks = (unsigned)((n_waves + wpb - 1) / wpb);
+  const KParams<real>& P = params<real>(h);
+  const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
+  const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
+
+  // Production shape (f32, MPC + diagonal R1, K a multiple of 64, 16-B granular rows of <= 8 KiB per tile)
+  // -> k_actor_dma.  Development knobs, read per launch: RCG_ACTOR_KERNEL=plain forces k_actor,
+  // RCG_GPW=<n> sets the envs per persistent wave, RCG_DBG=1 selects the timing-only variant.
+  const int nrow = (int)(row_bytes / 16);
+  if (const char* e = getenv("RCG_DBG")) A.dbg = atoi(e);
+  const char* ksel = getenv("RCG_ACTOR_KERNEL");
+  const bool force_plain = ksel && !strcmp(ksel, "plain");
+  bool dma_ok = false;
+  if constexpr (std::is_same<real, float>::value)
+    dma_ok = cand && A.vec_ok && K >= 64 && (K % 64) == 0 && nrow >= 1 && nrow <= 8 && !generic && !force_plain;
+  const bool same = A.obs == A.state_sys;  // control tick without ref_lag: one state array
+  if (sim_first) {  // the env step of the tick (Simulator.sim_step) precedes the decision
+    int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
+    if (rc) return rc;
+  }
+  ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+  if constexpr (std::is_same<real, float>::value) {
+    if (dma_ok) {
+      // envs per persistent wave: measured on C2 (B = 65536, K = 256), 1 and 2 are equal within noise and
+      // 8 is ~3 % slower (fewer, longer waves leave a longer tail), so persistence is only used to keep the
+      // wave count bounded for very large batches
+      long gpw = B > (1L << 20) ? (B >> 20) : 1;
+      if (const char* e = getenv("RCG_GPW")) gpw = atol(e);
+      gpw = gpw < 1 ? 1 : (gpw > 8 ? 8 : gpw);
+      A.gpw = (int)gpw;
+      const long pw = (B + gpw - 1) / gpw;
+      const unsigned pblocks = (unsigned)((pw + wpb - 1) / wpb);
+#define RCG_LAUNCH_DMA3(TG, NR, SM) \
+  hipLaunchKernelGGL((k_actor_dma<Sys, TG, NR, SM>), dim3(pblocks), dim3(64 * wpb), lds, h->stream, A, P)
+#define RCG_LAUNCH_DMA2(TG, NR)      \
+  do {                               \
+    if (same)                        \
+      RCG_LAUNCH_DMA3(TG, NR, true); \
+    else                             \
+      RCG_LAUNCH_DMA3(TG, NR, false); \
+  } while (0)
+#define RCG_LAUNCH_DMA(NR)        \
+  case NR:                        \
+    if (tgt)                      \
+      RCG_LAUNCH_DMA2(true, NR);  \
+    else                          \
+      RCG_LAUNCH_DMA2(false, NR); \
+    break;
+      switch (nrow) {
+        RCG_LAUNCH_DMA(1)
+        RCG_LAUNCH_DMA(2)
+        RCG_LAUNCH_DMA(3)
+        RCG_LAUNCH_DMA(4)
+        RCG_LAUNCH_DMA(5)
+        RCG_LAUNCH_DMA(6)
+        RCG_LAUNCH_DMA(7)
+        RCG_LAUNCH_DMA(8)
+      }
+#undef RCG_LAUNCH_DMA
+#undef RCG_LAUNCH_DMA2
+#undef RCG_LAUNCH_DMA3
+      HIPCHK(h, hipGetLastError());
+      return RCG_OK;
+    }
+  }
+#define RCG_LAUNCH_ACTOR(GEN, TGT, STR) \
+  hipLaunchKernelGGL((k_actor<Sys, real, GEN, TGT, STR>), dim3(blocks), dim3(64 * wpb), lds, h->stream, A, P)
+#define RCG_LAUNCH_ACTOR2(GEN, TGT)      \
+  do {                                   \
+    if (cand)                            \
+      RCG_LAUNCH_ACTOR(GEN, TGT, true);  \
+    else                                 \
+      RCG_LAUNCH_ACTOR(GEN, TGT, false); \
+  } while (0)
+  if (generic) {
+    if (tgt)
+      RCG_LAUNCH_ACTOR2(true, true);
+    else
+      RCG_LAUNCH_ACTOR2(true, false);
+  } else {
+    if (tgt)
+      RCG_LAUNCH_ACTOR2(false, true);
+    else
+      RCG_LAUNCH_ACTOR2(false, false);
+  }
+#undef RCG_LAUNCH_ACTOR2
+#undef RCG_LAUNCH_ACTOR
+  HIPCHK(h, hipGetLastError());
+  return RCG_OK;
+}
+
+template <typename Sys>
+static int op_actor(rcg_handle* h, const char* who, const void* cand, int K, const void* obs, const void* state_sys,
+                    const void* w, void* J, void* action, void* best_J, int32_t* best_idx, bool tick, bool sim_first) {
+  return by_dtype(h, [&](auto r) {
+    return launch_actor<Sys, decltype(r)>(h, who, cand, K, obs, state_sys, w, J, action, best_J, best_idx, tick,
+                                          sim_first);
+  });
+}
+
+// Explicitly instantiated once per environment (rcg_sys_*.hip): pulls in every launcher above and,
+// through their launch expressions, every kernel.
+template <typename Sys>
+struct SysInstances {
+  static SysVTable table() {
+    return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,       &op_critic_cost<Sys>,
+                     &op_actor<Sys>, &op_sim_step<Sys>,  &op_critic_update<Sys>};
+  }
+};
+
+}  // namespace rcg

@@ -385,9 +385,18 @@ class Engine:
         return {k: getattr(s, k) for k in ("count", "sum", "sumsq", "min", "max", "n_failed")}, out
 
     # ------------------------------------------------------------------ measurement
-    def profile(self, enable=True):
-        """Bracket the kernels with HIP events on the engine's own stream (rcg_profile)."""
-        N.check(N.lib().rcg_profile(self._h, 1 if enable else 0), self._h)
+    def profile(self, kernels=(N.KERNEL_ACTOR, N.KERNEL_SIM, N.KERNEL_CRITIC), stride=1):
+        """Bracket every ``stride``-th launch of the given kernels with HIP events on the engine's own
+        stream (rcg_profile); ``False`` / empty stops recording."""
+        mask = 0
+        if kernels is True:
+            mask = 7
+        elif kernels:
+            for k in kernels:
+                mask |= 1 << int(k)
+        if mask:
+            mask |= max(int(stride), 1) << 8
+        N.check(N.lib().rcg_profile(self._h, mask), self._h)
 
     def profile_read(self, kernel=N.KERNEL_ACTOR):
         """(total device ms, launches) of one kernel since ``profile(True)``."""
