@@ -483,7 +483,6 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
     }
     // 2. tile g has landed (every older vector-memory operation has retired) -> my row into registers
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (A.dbg & 2) __builtin_amdgcn_s_setprio(3);  // experiment: re-arm the prefetch ahead of other waves' VALU
     v4f cur[NROW];
 #pragma unroll
     for (int j = 0; j < NROW; ++j) cur[j] = myrow[j];
@@ -495,7 +494,6 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
       if (t == T - 1) fetch_env(b + 1);
       issue_dma(gv);
     }
-    if (A.dbg & 2) __builtin_amdgcn_s_setprio(0);
 
     // 4. _actor_cost of this lane's row (controllers.py:1284-1306), registers only
     real x[DS], y[DS];

@@ -1,0 +1,111 @@
+"""Mixed preset pool: a ragged batch of different systems (BASELINE configs[4]: 3wrobot + 3wrobot_NI +
+2tank) driven as one job.
+
+Environments never interact, and a wave must not mix system types (the dynamics are compile-time
+policies of the kernels), so the pool sorts its envs by type into homogeneous *segments*, one
+:class:`~rcognita_amd.engine.Engine` per segment.  A pool tick issues one ``rcg_control_tick`` per
+segment; the segments run on separate HIP streams when the caller provides them, since nothing orders
+them.  Episode statistics are merged exactly as across GPUs (:func:`rcognita_amd.parallel.merge_summaries`).
+Across ranks the pool is sharded *within each type* (:func:`rcognita_amd.parallel.shard_by_type`) so every
+rank sees the same mix.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .engine import Engine, EngineConfig
+from .parallel import merge_summaries, shard_by_type
+
+# the reference presets' constants (presets/main_3wrobot.py:45-47,207-215; main_3wrobot_NI.py:45-48,207-211;
+# main_2tank.py:45-48,199-211): parameters, control bounds, R1 diagonal, dt, prediction step multiplier,
+# observation target
+PRESETS = {
+    "3wrobot": dict(sys_id=N.SYS_3WROBOT, pars=[10.0, 1.0], ctrl_bnds=[[-300.0, 300.0], [-100.0, 100.0]],
+                    R1=[1.0, 10.0, 1.0, 0, 0, 0, 0], dt=0.01, mult=2.0, target=None,
+                    state_init=[5.0, 5.0, -3 * np.pi / 4, 0.0, 0.0]),
+    "3wrobotNI": dict(sys_id=N.SYS_3WROBOT_NI, pars=[], ctrl_bnds=[[-25.0, 25.0], [-5.0, 5.0]],
+                      R1=[1.0, 10.0, 1.0, 0, 0], dt=0.01, mult=1.0, target=None,
+                      state_init=[5.0, 5.0, -3 * np.pi / 4]),
+    "2tank": dict(sys_id=N.SYS_2TANK, pars=[18.4, 24.4, 1.3, 1.0, 0.2], ctrl_bnds=[[0.0, 1.0]],
+                  R1=[10.0, 10.0, 1.0], dt=0.1, mult=2.0, target=[0.5, 0.5], state_init=[2.0, -2.0]),
+}
+
+
+def preset_engine_config(name: str, batch: int, **over) -> EngineConfig:
+    """EngineConfig carrying one preset's constants; keyword overrides use EngineConfig's field names."""
+    p = PRESETS[name]
+    kw = dict(sys_id=p["sys_id"], batch=batch, pars=p["pars"], ctrl_bnds=np.array(p["ctrl_bnds"]),
+              R1=np.diag(np.array(p["R1"], dtype=float)), observation_target=p["target"], dt_sim=p["dt"],
+              sampling_time=p["dt"], pred_step_size=p["dt"] * p["mult"])
+    kw.update(over)
+    return EngineConfig(**kw)
+
+
+@dataclass
+class Segment:
+    name: str
+    engine: Engine
+    lo: int  # global env range of this segment within its type
+    hi: int
+
+
+class MixedPool:
+    """``counts``: {preset name: global number of envs}.  With ``rank/world`` given, this process owns the
+    shard ``shard_by_type(counts, rank, world)`` of every type."""
+
+    def __init__(self, counts: Dict[str, int], rank: int = 0, world: int = 1, device: int = 0, dtype: str = "f32",
+                 Nactor: int = 15, mode: str = "MPC", **over):
+        self.counts = dict(counts)
+        self.segments: List[Segment] = []
+        spans = shard_by_type(counts, rank, world)
+        buffer_size = over.pop("buffer_size", 10) if mode != "MPC" else over.pop("buffer_size", 0)
+        for name in sorted(counts):  # deterministic segment order
+            lo, hi = spans[name]
+            if hi <= lo:
+                continue
+            eng = Engine(preset_engine_config(name, hi - lo, device=device, dtype=dtype, Nactor=Nactor, mode=mode,
+                                              buffer_size=buffer_size, **over))
+            self.segments.append(Segment(name, eng, lo, hi))
+
+    @property
+    def n_envs(self) -> int:
+        return sum(s.hi - s.lo for s in self.segments)
+
+    def set_streams(self, stream_ptrs: Sequence[Optional[int]]):
+        """One HIP stream per segment (e.g. ``torch.cuda.Stream().cuda_stream``): the segments are independent."""
+        for s, p in zip(self.segments, stream_ptrs):
+            s.engine.set_stream(p)
+
+    def set_states(self, states: Dict[str, np.ndarray]):
+        """``states[name]``: [n_local, ds] initial states of this rank's envs of that type."""
+        for s in self.segments:
+            s.engine.set_state(states[s.name])
+
+    def control_tick(self, K: int, cand: Optional[Dict[str, object]] = None):
+        """One env.control-step for every env of the pool: generated level grid of K candidates, or per-type
+        candidate tensors ``cand[name] [n_local, K, N, du]``."""
+        for s in self.segments:
+            s.engine.control_tick(None if cand is None else cand[s.name], K=K)
+
+    def synchronize(self):
+        for s in self.segments:
+            s.engine.synchronize()
+
+    def episode_reset(self):
+        for s in self.segments:
+            s.engine.episode_reset()
+
+    def episode_stats(self, from_accum=False):
+        """(whole-pool summary, {type: summary}) for this rank's shard."""
+        per = {}
+        for s in self.segments:
+            per[s.name], _ = s.engine.episode_stats(from_accum=from_accum)
+        return merge_summaries(per.values()), per
+
+    def close(self):
+        for s in self.segments:
+            s.engine.close()

@@ -197,3 +197,25 @@ def test_batched_dropin_matches_single_env_objects():
         fi, ai = run(x0[i])
         np.testing.assert_allclose(fb[i], fi, rtol=1e-12)
         np.testing.assert_allclose(ab[i], ai, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name,argv", [
+    ("3wrobot", ["--ctrl_mode", "MPC", "--t1", "0.2", "--Nactor", "6", "--n_candidates", "64", "--rounds", "2"]),
+    ("3wrobotNI", ["--ctrl_mode", "MPC", "--t1", "0.2", "--batch", "5", "--n_candidates", "64", "--rounds", "2"]),
+    ("2tank", ["--ctrl_mode", "RQL", "--t1", "2.0", "--critic_struct", "quadratic", "--n_candidates", "64", "--rounds", "2"]),
+    ("2tank", ["--ctrl_mode", "manual", "--t1", "1.0", "--action_manual", "0.7"]),
+])
+def test_preset_scripts_run(name, argv, tmp_path, monkeypatch):
+    """presets/main_*.py with the reference's flags (shared implementation rcognita_amd.presets.run)."""
+    from rcognita_amd.presets import SPEC, run
+
+    monkeypatch.chdir(tmp_path)
+    out = run(name, argv + ["--is_print_sim_step", "", "--is_log_data", "1", "--dtype", "f64"])
+    dt = SPEC[name]["dt"]
+    t1 = float(argv[argv.index("--t1") + 1])
+    assert out["ticks"] == int(round(t1 / dt)) and abs(out["t"] - t1) < 1e-9
+    assert np.all(np.isfinite(out["state"])) and np.all(np.isfinite(out["accum_obj"]))
+    logs = list((tmp_path / "simdata").glob("*.csv"))
+    assert len(logs) == 1 and len(open(logs[0]).read().splitlines()) == out["ticks"] + 1
+    if "manual" in argv:
+        np.testing.assert_allclose(out["action"], [0.7])

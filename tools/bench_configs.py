@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one MI355X for the BASELINE configs that are parity cases rather than the
+bench line: configs[2] (Sys2Tank B=131072, Nactor=20, RQL + quadratic critic TD fit every tick) and the
+per-GPU shard of configs[4] (mixed pool, Nactor=15, 256 generated candidates).  Prints one JSON object.
+
+    python tools/bench_configs.py [--steps 50]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    a = ap.parse_args()
+    from rcognita_amd import Engine
+    from rcognita_amd import _native as N
+    from rcognita_amd.pool import MixedPool, preset_engine_config
+
+    out = {}
+    rng = np.random.default_rng(1234)
+
+    # ---- configs[2] ----------------------------------------------------------------------------------
+    B, K, Nh = 131072, 256, 20
+    for mode in ("MPC", "RQL", "SQL"):
+        kw = dict(Nactor=Nh, mode=mode, critic_struct="quadratic", Ncritic=4, buffer_size=10 if mode != "MPC" else 0)
+        eng = Engine(preset_engine_config("2tank", B, **kw))
+        eng.set_state(np.stack([rng.uniform(0, 2, B), rng.uniform(-2, 2, B)], axis=-1))
+        for _ in range(a.warmup):
+            eng.control_tick(None, K=K)
+        eng.profile(True)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.control_tick(None, K=K)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        am, an = eng.profile_read(N.KERNEL_ACTOR)
+        cm, cn = eng.profile_read(N.KERNEL_CRITIC)
+        sm, sn = eng.profile_read(N.KERNEL_SIM)
+        summ, _ = eng.episode_stats(from_accum=True)
+        out[f"C3_2tank_B{B}_N{Nh}_K{K}_{mode}"] = {
+            "env_control_steps_per_s": B * a.steps / dt, "ms_per_tick": dt / a.steps * 1e3,
+            "actor_ms": am / max(an, 1), "critic_push_fit_ms": cm / max(cn, 1) if cn else None,
+            "sim_ms": sm / max(sn, 1), "n_failed": summ["n_failed"], "candidates": "generated 256-level grid"}
+        eng.close()
+
+    # ---- configs[4], one GPU's shard -----------------------------------------------------------------
+    total = 65536
+    counts = {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
+    pool = MixedPool(counts, Nactor=15, dtype="f32")
+    from tests.helpers import rand_states
+
+    pool.set_states({s.name: rand_states(rng, s.name, s.hi - s.lo) for s in pool.segments})
+    for _ in range(a.warmup):
+        pool.control_tick(256)
+    pool.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pool.control_tick(256)
+    pool.synchronize()
+    dt = time.perf_counter() - t0
+    summ, _ = pool.episode_stats(from_accum=True)
+    out["C5_mixed_pool_65536_N15_K256_generated"] = {"env_control_steps_per_s": pool.n_envs * a.steps / dt,
+                                                    "ms_per_tick": dt / a.steps * 1e3, "n_failed": summ["n_failed"]}
+    pool.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
