@@ -42,6 +42,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                   help="nccl = RCCL over xGMI (the real thing); gloo only to exercise the N>1 code path on one GPU")
+    p.add_argument("--single-device", action="store_true",
+                   help="debug: every rank uses cuda:0 (with --dist-backend gloo), to test the N>1 path on a 1-GPU box")
     p.add_argument("--profile-stride", type=int, default=8,
                    help="bracket every n-th kernel launch of the timed region with HIP events (0 = none)")
     return p.parse_args()
@@ -120,14 +124,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    coll_dev = torch.device("cuda", local_rank)  # where collective payloads live
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=coll_dev)
+        else:
+            coll_dev = torch.device("cpu")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from rcognita_amd import _native as N
     from rcognita_amd.parallel import gather_summaries
@@ -156,7 +166,7 @@ def main():
     for _ in range(args.warmup):
         eng.control_tick(cand, K=K)
     returns_dev = torch.empty(B, device="cuda", dtype=tdtype)
-    gathered = [torch.empty_like(returns_dev) for _ in range(world)] if dist is not None else None
+    gathered = [torch.empty(B, device=coll_dev, dtype=tdtype) for _ in range(world)] if dist is not None else None
 
     # HIP events around the kernels of the tick on the engine's own stream, inside the timed region; sampled
     # (every n-th launch) because each event is a marker packet on the stream.
@@ -169,11 +179,11 @@ def main():
     if dist is not None:
         # episode-end exchange: ONE all_gather of the per-env running returns over RCCL
         N.check(N.lib().rcg_get_field(eng._h, N.FIELD_ACCUM, returns_dev.data_ptr(), N.DEVICE), eng._h)
-        dist.all_gather(gathered, returns_dev)
+        dist.all_gather(gathered, returns_dev if coll_dev.type == "cuda" else returns_dev.cpu())
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     actor_ms, actor_n = eng.profile_read(N.KERNEL_ACTOR)
@@ -181,7 +191,7 @@ def main():
     eng.profile(False)
 
     summ, _ = eng.episode_stats(from_accum=True)
-    total = gather_summaries(summ, dist)  # per-shard summaries -> whole-job summary (6 doubles per rank)
+    total = gather_summaries(summ, dist, device=coll_dev)  # per-shard summaries -> whole-job summary
     steps_idx = eng.get_field(N.FIELD_STEP_IDX)
     assert int(steps_idx.min()) == int(steps_idx.max()) == args.warmup + args.steps, "step counter mismatch"
 
