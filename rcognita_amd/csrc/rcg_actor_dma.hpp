@@ -1,0 +1,195 @@
+// rcg_actor_dma.hpp - k_actor_dma: the production kernel of the streamed rollout
+// (CtrlOptPred._actor_cost for K candidates per env + argmin + tick epilogue; controllers.py:1273-1427).
+//
+// Shape it serves: f32, MPC with a diagonal R1 (every reference preset), K a multiple of 64, candidate rows
+// of R = N*du <= 32 floats, rollout started from the observation (state_sys == obs: the control tick without
+// ref_lag).  Everything else goes to k_actor (rcg_kernels.hpp).
+//
+//   per tile of 64 candidate rows (256*R bytes, contiguous in HBM):
+//     1. direct-to-LDS loads: R/4 x global_load_lds_dwordx4 (64 lanes x 16 B = 1 KiB each) plus R%4 x
+//        global_load_lds_dword (256 B each), `nt` (the tensor is read once per tick) - fully coalesced, written
+//        by the memory pipeline straight into this wave's LDS tile, no VGPR staging;
+//     2. the lane pulls ITS row LDS -> registers (R floats at lane*R*4: ds_read_b128 when R % 4 == 0, b64 when
+//        R is even, b32 otherwise; R = 20 is conflict-free, any residual conflict is noise next to the rollout);
+//     3. as soon as the row is in registers the SAME LDS tile is free again: the next tile's loads are issued
+//        here, before the rollout, so they are in flight during all of step 4;
+//     4. the rollout runs on registers only, the horizon fully unrolled (N = R/du is a template constant): no
+//        wait of any kind.  Trig: hardware v_sin/v_cos behind an exact reduction (rcg_math.hpp::sincos_hw).
+// The only vmcnt wait is the one in front of step 2 of the NEXT tile, which is exactly the data it needs.
+// vmcnt retires in issue order, so whatever else the next iteration needs from memory (the next env's state)
+// is requested BEFORE the tile loads and never drains them; the tick epilogue's read-modify-writes of ACCUM and
+// STEP_IDX are no-return atomics (one adder per address: still deterministic) and need no wait at all.
+// No s_barrier anywhere: a wave only reads LDS it filled itself.
+// Measured on C2 (B = 65536, K = 256, N = 10): 222-227 us per launch = 5.9-6.05 TB/s; with the rollout skipped
+// (A.dbg bit 0, timing-only build) 204-214 us; this access pattern alone reads at 7.0 TB/s (tools/bw_probe.hip).
+#pragma once
+#include "rcg_kernels.hpp"
+
+namespace rcg {
+
+template <typename Sys, int R, bool TGT>
+__global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, const KParams<float> P) {
+  typedef float real;
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
+  static_assert(R % DU == 0 && R >= DU && R <= 32, "row = N*du floats, at most 32");
+  constexpr int N = R / DU;
+  constexpr int NFULL = R / 4, NREM = R % 4;  // 1-KiB and 256-B direct-to-LDS loads per tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+
+  const int lane = threadIdx.x & 63;
+  // readfirstlane: provably wave-uniform, so tile bases live in SGPRs and the control flow is scalar
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+  const long B = P.B;
+  const int K = A.K;
+  const int T = K >> 6;  // tiles per env
+  const long env0 = wave * A.gpw;
+  if (env0 >= B) return;
+  const long env1 = env0 + A.gpw < B ? env0 + A.gpw : B;
+  const long n_tiles = (env1 - env0) * T;
+
+  unsigned char* const tile = smem_raw + (size_t)wave_in_wg * (256 * R);  // this wave's LDS tile
+  const real* const myrow = reinterpret_cast<const real*>(tile) + lane * R;
+  const unsigned char* gb = reinterpret_cast<const unsigned char*>(A.cand) + (size_t)env0 * K * (4 * R);
+
+  auto issue_tile = [&](const unsigned char* g) {
+#pragma unroll
+    for (int j = 0; j < NFULL; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0,
+                                       2 /* nt */);
+#pragma unroll
+    for (int j = 0; j < NREM; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void*)(g + NFULL * 1024 + j * 256 + lane * 4),
+                                       (lds_void*)(tile + NFULL * 1024 + j * 256), 4, 0, 2 /* nt */);
+  };
+
+  // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
+  // "pointer ? load : default" selects (a default written into a register with a load in flight would force a
+  // vmcnt(0) on the spot).
+  real y0[DS], yn[DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) pn[i] = P.pars[i];
+  auto fetch_env = [&](long b) {
+#pragma unroll
+    for (int c = 0; c < DS; ++c) yn[c] = A.obs[(long)c * B + b];
+    if (A.pars_env) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) pn[i] = A.pars_env[(long)i * B + b];
+    }
+  };
+  fetch_env(env0);
+  issue_tile(gb);  // after the env request: retiring the env state must not drain the first tile
+
+  const real h = P.h_pred;
+  long b = env0;
+  int t = 0;
+  auto pre_env = Sys::template prepare<real>(pn);
+  real bestJ = inf_r<real>();
+  int bestI = 0x7fffffff;
+  real bu[DU];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) bu[c] = 0;
+
+  for (long g = 0; g < n_tiles; ++g) {
+    if (t == 0) {  // first tile of env b: adopt the state requested one tile ago
+#pragma unroll
+      for (int c = 0; c < DS; ++c) y0[c] = yn[c];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) pv[i] = pn[i];
+      pre_env = Sys::template prepare<real>(pv);
+      bestJ = inf_r<real>();
+      bestI = 0x7fffffff;
+    }
+    // 2. tile g has landed (every older vector-memory operation has retired) -> my row into registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    real cur[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) cur[i] = myrow[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane's row is out of LDS (in-order per wave)
+    __builtin_amdgcn_wave_barrier();
+    // 3. the LDS tile is free: request what the next iteration needs, the tile loads last
+    gb += 256 * R;
+    if (g + 1 < n_tiles) {
+      if (t == T - 1) fetch_env(b + 1);
+      issue_tile(gb);
+    }
+
+    // 4. _actor_cost of this lane's row (controllers.py:1284-1306), registers only
+    real x[DS], y[DS];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) x[c] = y[c] = y0[c];  // state_sys == observation (see the launcher)
+    real J = 0, gk = 1;
+    if (A.dbg & 1) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
+#pragma unroll
+      for (int i = 0; i < R; ++i) J += cur[i];
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < N; ++kk) {
+        if (kk > 0) {
+          real d[DS];
+          Sys::template rhs<real, true>(pre_env, x, &cur[(kk - 1) * DU], d);  // unclipped: sys_rhs([], state, u[k-1])
+#pragma unroll
+          for (int c = 0; c < DS; ++c) {
+            x[c] = fma_r(h, d[c], x[c]);
+            y[c] = x[c];  // sys_out is the identity
+          }
+        }
+        real chi[NCHI];
+#pragma unroll
+        for (int c = 0; c < DS; ++c) chi[c] = TGT ? y[c] - P.target[c] : y[c];
+#pragma unroll
+        for (int c = 0; c < DU; ++c) chi[DS + c] = cur[kk * DU + c];
+        J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
+        gk *= P.gamma;
+      }
+    }
+
+    const int k = t * 64 + lane;
+    if (A.J) A.J[b * K + k] = J;
+    const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
+    if (Jc < bestJ || bestI == 0x7fffffff) {
+      bestJ = Jc;
+      bestI = k;
+#pragma unroll
+      for (int c = 0; c < DU; ++c) bu[c] = cur[c];  // the sequence's first action
+    }
+
+    if (++t == T) {  // env b complete: wave argmin (lower J, then lower index) + tick epilogue
+      for (int m = 1; m < 64; m <<= 1) {
+        const real oJ = __shfl_xor(bestJ, m, 64);
+        const int oI = __shfl_xor(bestI, m, 64);
+        real oU[DU];
+#pragma unroll
+        for (int c = 0; c < DU; ++c) oU[c] = __shfl_xor(bu[c], m, 64);
+        if ((oJ < bestJ) || (oJ == bestJ && oI < bestI)) {
+          bestJ = oJ;
+          bestI = oI;
+#pragma unroll
+          for (int c = 0; c < DU; ++c) bu[c] = oU[c];
+        }
+      }
+      if (lane == 0) {  // stores and no-return atomics only: nothing here waits on memory
+#pragma unroll
+        for (int c = 0; c < DU; ++c)
+          if (A.action_out) A.action_out[(long)c * B + b] = bu[c];
+        if (A.best_J) A.best_J[b] = bestJ;
+        if (A.best_idx) A.best_idx[b] = bestI;
+        if (A.accum) {  // upd_accum_obj (controllers.py:1086-1093)
+          real chi[NCHI];
+#pragma unroll
+          for (int c = 0; c < DS; ++c) chi[c] = TGT ? y0[c] - P.target[c] : y0[c];
+#pragma unroll
+          for (int c = 0; c < DU; ++c) chi[DS + c] = bu[c];
+          atomicAdd(&A.accum[b], stage_diag<NCHI, real>(P, chi) * P.sampling_time);
+        }
+        if (A.step_idx) atomicAdd(&A.step_idx[b], 1);
+      }
+      t = 0;
+      ++b;
+    }
+  }
+}
+
+}  // namespace rcg

@@ -385,195 +385,6 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_actor_dma: the streamed production shape with direct-to-LDS loads (f32, MPC, diagonal R1).
-//   per tile of 64 rows (NROW KiB, contiguous in HBM):
-//     1. NROW x global_load_lds_dwordx4 (nt): 64 lanes x 16 B per instruction, fully coalesced, written by
-//        the memory pipeline straight into this wave's LDS tile - no VGPR staging;
-//     2. the lane pulls ITS row LDS -> registers with NROW ds_read_b128 (lane stride NROW*16 B: conflict-free
-//        for NROW = 5; any residual conflict is noise next to the ~350 VALU ops of a rollout);
-//     3. as soon as the row is in registers the SAME LDS tile is free again: the next tile's DMA is issued
-//        here, before the rollout, so it is in flight during all of step 4;
-//     4. the rollout runs on registers only (horizon fully unrolled, N = NROW*4/du) - no wait of any kind.
-// The only vmcnt wait is the one in front of step 2 of the NEXT tile, which is exactly the data it needs.
-// vmcnt retires in issue order, so whatever else the next iteration needs from memory (the next env's state)
-// is requested BEFORE the DMA is issued and never drains it; the tick epilogue's read-modify-writes of ACCUM
-// and STEP_IDX are no-return atomics (one adder per address, so still deterministic) and need no wait at all.
-// A wave is persistent over `gpw` consecutive envs = one contiguous gpw*K*NROW*16 B stream.
-// SAME: obs and state_sys are the same array (control tick without ref_lag) - one state vector per env.
-// Trig: hardware v_sin/v_cos behind an exact reduction (rcg_math.hpp::sincos_hw, 3.7e-7 abs).
-// Pattern measured in isolation (tools/bw_probe.hip, "tiles nt"): 7.0 TB/s.
-// ---------------------------------------------------------------------------------------------
-#ifndef RCG_ROLLOUT_HW_TRIG
-#define RCG_ROLLOUT_HW_TRIG 1
-#endif
-
-template <typename Sys, bool TGT, int NROW, bool SAME>
-__global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, const KParams<float> P) {
-  typedef float real;
-  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
-  constexpr int N = NROW * 4 / DU;
-  constexpr bool HW = RCG_ROLLOUT_HW_TRIG != 0;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-
-  const int lane = threadIdx.x & 63;
-  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
-  const long B = P.B;
-  const int K = A.K;
-  const int T = K >> 6;
-  const long env0 = wave * A.gpw;
-  if (env0 >= B) return;
-  const long env1 = env0 + A.gpw < B ? env0 + A.gpw : B;
-  const long n_tiles = (env1 - env0) * T;
-
-  unsigned char* const tile = smem_raw + (size_t)wave_in_wg * NROW * 1024;  // this wave's LDS tile
-  const v4f* const myrow = reinterpret_cast<const v4f*>(tile) + lane * NROW;
-  const v4f* gv = reinterpret_cast<const v4f*>(A.cand) + env0 * (long)K * NROW + lane;  // lane <-> 16 B
-
-  auto issue_dma = [&](const v4f* g) {
-#pragma unroll
-    for (int j = 0; j < NROW; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 64), (lds_void*)(tile + j * 1024), 16, 0, 2 /* nt */);
-  };
-
-  // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
-  // "pointer ? load : default" selects (a default written into a register with a load in flight would
-  // force a vmcnt(0) on the spot).
-  real y0[DS], yn[DS], xs[SAME ? 1 : DS], xn[SAME ? 1 : DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) pn[i] = P.pars[i];
-  auto fetch_env = [&](long b) {
-#pragma unroll
-    for (int c = 0; c < DS; ++c) {
-      yn[c] = A.obs[(long)c * B + b];
-      if (!SAME) xn[c] = A.state_sys[(long)c * B + b];
-    }
-    if (A.pars_env) {
-#pragma unroll
-      for (int i = 0; i < NP; ++i) pn[i] = A.pars_env[(long)i * B + b];
-    }
-  };
-  fetch_env(env0);
-  issue_dma(gv);  // after the env request: retiring the env state must not drain the first tile
-
-  const real h = P.h_pred;
-  long b = env0;
-  int t = 0;
-  auto pre_env = Sys::template prepare<real>(pn);
-  real bestJ = inf_r<real>();
-  int bestI = 0x7fffffff;
-  real bu[DU];
-#pragma unroll
-  for (int c = 0; c < DU; ++c) bu[c] = 0;
-
-  for (long g = 0; g < n_tiles; ++g) {
-    if (t == 0) {  // first tile of env b: adopt the state requested one tile ago
-#pragma unroll
-      for (int c = 0; c < DS; ++c) {
-        y0[c] = yn[c];
-        if (!SAME) xs[c] = xn[c];
-      }
-#pragma unroll
-      for (int i = 0; i < NP; ++i) pv[i] = pn[i];
-      pre_env = Sys::template prepare<real>(pv);
-      bestJ = inf_r<real>();
-      bestI = 0x7fffffff;
-    }
-    // 2. tile g has landed (every older vector-memory operation has retired) -> my row into registers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    v4f cur[NROW];
-#pragma unroll
-    for (int j = 0; j < NROW; ++j) cur[j] = myrow[j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane's row is out of LDS (in-order per wave)
-    __builtin_amdgcn_wave_barrier();
-    // 3. the LDS tile is free: request what the next iteration needs, the DMA last
-    gv += NROW * 64;
-    if (g + 1 < n_tiles) {
-      if (t == T - 1) fetch_env(b + 1);
-      issue_dma(gv);
-    }
-
-    // 4. _actor_cost of this lane's row (controllers.py:1284-1306), registers only
-    real x[DS], y[DS];
-#pragma unroll
-    for (int c = 0; c < DS; ++c) {
-      x[c] = SAME ? y0[c] : xs[c];
-      y[c] = y0[c];
-    }
-    real J = 0, gk = 1;
-    if (A.dbg & 1) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
-#pragma unroll
-      for (int j = 0; j < NROW; ++j) J += cur[j][0] + cur[j][1] + cur[j][2] + cur[j][3];
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < N; ++kk) {
-        real u[DU];
-#pragma unroll
-        for (int c = 0; c < DU; ++c) u[c] = cur[(kk * DU + c) >> 2][(kk * DU + c) & 3];
-        if (kk > 0) {
-          real up[DU], d[DS];
-#pragma unroll
-          for (int c = 0; c < DU; ++c) up[c] = cur[((kk - 1) * DU + c) >> 2][((kk - 1) * DU + c) & 3];
-          Sys::template rhs<real, HW>(pre_env, x, up, d);  // unclipped, as sys_rhs([], state, u[k-1])
-#pragma unroll
-          for (int c = 0; c < DS; ++c) {
-            x[c] = fma_r(h, d[c], x[c]);
-            y[c] = x[c];  // sys_out is the identity
-          }
-        }
-        real chi[NCHI];
-        make_chi<DS, DU, TGT, real>(P, y, u, chi);
-        J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
-        gk *= P.gamma;
-      }
-    }
-
-    const int k = t * 64 + lane;
-    if (A.J) A.J[b * K + k] = J;
-    const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
-    if (Jc < bestJ || bestI == 0x7fffffff) {
-      bestJ = Jc;
-      bestI = k;
-#pragma unroll
-      for (int c = 0; c < DU; ++c) bu[c] = cur[c >> 2][c & 3];  // the sequence's first action
-    }
-
-    if (++t == T) {  // env b complete: wave argmin (lower J, then lower index) + tick epilogue
-      for (int m = 1; m < 64; m <<= 1) {
-        const real oJ = __shfl_xor(bestJ, m, 64);
-        const int oI = __shfl_xor(bestI, m, 64);
-        real oU[DU];
-#pragma unroll
-        for (int c = 0; c < DU; ++c) oU[c] = __shfl_xor(bu[c], m, 64);
-        if ((oJ < bestJ) || (oJ == bestJ && oI < bestI)) {
-          bestJ = oJ;
-          bestI = oI;
-#pragma unroll
-          for (int c = 0; c < DU; ++c) bu[c] = oU[c];
-        }
-      }
-      if (lane == 0) {  // stores and no-return atomics only: nothing here waits on memory
-#pragma unroll
-        for (int c = 0; c < DU; ++c)
-          if (A.action_out) A.action_out[(long)c * B + b] = bu[c];
-        if (A.best_J) A.best_J[b] = bestJ;
-        if (A.best_idx) A.best_idx[b] = bestI;
-        if (A.accum) {  // upd_accum_obj (controllers.py:1086-1093)
-          real chi[NCHI];
-          make_chi<DS, DU, TGT, real>(P, y0, bu, chi);
-          atomicAdd(&A.accum[b], stage_diag<NCHI, real>(P, chi) * P.sampling_time);
-        }
-        if (A.step_idx) atomicAdd(&A.step_idx[b], 1);
-      }
-      t = 0;
-      ++b;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_sim: closed_loop_rhs (systems.py:213-253) under classical RK4, lane == env
 // ---------------------------------------------------------------------------------------------
 template <typename real>

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "rcg_actor_dma.hpp"
 #include "rcg_critic_fit.hpp"
 #include "rcg_handle.hpp"
 
@@ -127,6 +128,28 @@ static int op_critic_update(rcg_handle* h, int32_t do_fit) {
 }
 
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
+// Pick the k_actor_dma<Sys, R> instance for a runtime row length (R = N*du floats, 1..32, multiple of du).
+template <typename Sys, int R>
+static bool launch_dma_r(int r, bool tgt, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<float>& A,
+                         const KParams<float>& P) {
+  if constexpr (R > 32) {
+    return false;
+  } else {
+    if (r == R) {
+      if constexpr (R % Sys::DU == 0) {
+        if (tgt)
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, true>), grid, block, lds, s, A, P);
+        else
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, false>), grid, block, lds, s, A, P);
+        return true;
+      } else {
+        return false;
+      }
+    }
+    return launch_dma_r<Sys, R + 1>(r, tgt, grid, block, lds, s, A, P);
+  }
+}
+
 // `sim_first`: rcg_control_tick (MPC) - run the env step of the tick before the decision.
 template <typename Sys, typename real>
 static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K, const void* obs,
@@ -192,17 +215,16 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
 
-  // Production shape (f32, MPC + diagonal R1, K a multiple of 64, 16-B granular rows of <= 8 KiB per tile)
-  // -> k_actor_dma.  Development knobs, read per launch: RCG_ACTOR_KERNEL=plain forces k_actor,
-  // RCG_GPW=<n> sets the envs per persistent wave, RCG_DBG=1 selects the timing-only variant.
-  const int nrow = (int)(row_bytes / 16);
+  // Production shape (f32, MPC + diagonal R1, K a multiple of 64, rows of R <= 32 floats) -> k_actor_dma.
+  // Development knobs, read per launch: RCG_ACTOR_KERNEL=plain forces k_actor, RCG_GPW=<n> sets the envs per
+  // persistent wave, RCG_DBG=1 selects the timing-only variant.
   if (const char* e = getenv("RCG_DBG")) A.dbg = atoi(e);
   const char* ksel = getenv("RCG_ACTOR_KERNEL");
   const bool force_plain = ksel && !strcmp(ksel, "plain");
   bool dma_ok = false;
   if constexpr (std::is_same<real, float>::value)
-    dma_ok = cand && A.vec_ok && K >= 64 && (K % 64) == 0 && nrow >= 1 && nrow <= 8 && !generic && !force_plain;
-  const bool same = A.obs == A.state_sys;  // control tick without ref_lag: one state array
+    dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= 32 && !generic &&
+             A.obs == A.state_sys && !force_plain;
   if (sim_first) {  // the env step of the tick (Simulator.sim_step) precedes the decision
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
     if (rc) return rc;
@@ -218,36 +240,9 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       gpw = gpw < 1 ? 1 : (gpw > 8 ? 8 : gpw);
       A.gpw = (int)gpw;
       const long pw = (B + gpw - 1) / gpw;
-      const unsigned pblocks = (unsigned)((pw + wpb - 1) / wpb);
-#define RCG_LAUNCH_DMA3(TG, NR, SM) \
-  hipLaunchKernelGGL((k_actor_dma<Sys, TG, NR, SM>), dim3(pblocks), dim3(64 * wpb), lds, h->stream, A, P)
-#define RCG_LAUNCH_DMA2(TG, NR)      \
-  do {                               \
-    if (same)                        \
-      RCG_LAUNCH_DMA3(TG, NR, true); \
-    else                             \
-      RCG_LAUNCH_DMA3(TG, NR, false); \
-  } while (0)
-#define RCG_LAUNCH_DMA(NR)        \
-  case NR:                        \
-    if (tgt)                      \
-      RCG_LAUNCH_DMA2(true, NR);  \
-    else                          \
-      RCG_LAUNCH_DMA2(false, NR); \
-    break;
-      switch (nrow) {
-        RCG_LAUNCH_DMA(1)
-        RCG_LAUNCH_DMA(2)
-        RCG_LAUNCH_DMA(3)
-        RCG_LAUNCH_DMA(4)
-        RCG_LAUNCH_DMA(5)
-        RCG_LAUNCH_DMA(6)
-        RCG_LAUNCH_DMA(7)
-        RCG_LAUNCH_DMA(8)
-      }
-#undef RCG_LAUNCH_DMA
-#undef RCG_LAUNCH_DMA2
-#undef RCG_LAUNCH_DMA3
+      const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
+      if (!launch_dma_r<Sys, 1>(R, tgt, grid, block, (size_t)4 * 256 * R, h->stream, A, P))
+        return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d floats", who, R);
       HIPCHK(h, hipGetLastError());
       return RCG_OK;
     }

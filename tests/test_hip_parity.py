@@ -168,7 +168,9 @@ def test_F6_hip_rk4_vs_reference_rk45(name):
 # HIP vs oracle on seeded random inputs: tile shapes, ragged sizes, ties, NaN
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("name,N", [("3wrobot", 10), ("3wrobot", 7), ("3wrobotNI", 15), ("2tank", 20), ("2tank", 5)])
+@pytest.mark.parametrize("name,N", [("3wrobot", 10), ("3wrobot", 7), ("3wrobotNI", 15), ("2tank", 20), ("2tank", 5),
+                                    ("3wrobot", 5), ("3wrobotNI", 3), ("3wrobot", 16), ("2tank", 32), ("2tank", 1),
+                                    ("3wrobot", 20)])  # preset defaults, the largest DMA rows, and one beyond them
 @pytest.mark.parametrize("K", [1, 3, 16, 33, 64, 100, 256])
 def test_actor_cost_and_argmin_vs_oracle(name, N, K, dtype):
     """Streamed candidates: J vs oracle; argmin bit-exact vs numpy on the SAME J; winner's first action."""
