@@ -112,6 +112,31 @@ def cpu_baseline(args, seconds):
             "sample": f"{Bc} envs x {ticks + 1} ticks, K={K}, Nactor={args.nactor}, C oracle f64 + OpenMP, {dt:.1f} s"}
 
 
+def cpu_reference_algorithm(args, seconds):
+    """The reference ALGORITHM on one host core: one env, SciPy RK45 + SLSQP over the oracle's operators
+    (oracle/ref_loop.py, pinned on traces captured from the reference).  Bounded by wall time."""
+    from oracle import rcg_oracle as O
+    from oracle.ref_loop import RefLoop
+
+    bnds = np.array([[-300.0, 300.0], [-100.0, 100.0]])
+    cfg = O.OracleCfg(sys_id=O.SYS_3WROBOT, n_actor=args.nactor, pars=[10.0, 1.0], ctrl_bnds=bnds,
+                      R1=np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0]), gamma=1.0, dt_sim=0.01, sampling_time=0.01,
+                      pred_step_size=0.02)
+    loop = RefLoop(cfg, np.array([5.0, 5.0, -3 * np.pi / 4, 0.0, 0.0]), t1=1e9)
+    t0 = time.perf_counter()
+    ticks, last = 0, None
+    while time.perf_counter() - t0 < seconds:
+        row = loop.step()
+        act = tuple(row[1 + cfg.ds:1 + cfg.ds + cfg.du])
+        if last is not None and act != last:
+            ticks += 1
+        last = act
+    dt = time.perf_counter() - t0
+    return {"value": ticks / dt, "unit": "env-control-steps/s", "cores": 1, "kind": "reference algorithm "
+            "(SciPy RK45 + SLSQP over the oracle's operators, preset main_3wrobot)",
+            "sample": f"1 env, {ticks} control ticks, {loop.nfev_actor} _actor_cost evaluations, {dt:.1f} s"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -281,6 +306,10 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        try:
+            out["cpu_baseline"]["reference_algorithm"] = cpu_reference_algorithm(args, min(args.cpu_seconds, 8.0))
+        except ImportError as e:  # SciPy missing on the box: the port above is the baseline
+            out["cpu_baseline"]["reference_algorithm"] = {"error": str(e)}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
