@@ -89,7 +89,8 @@ typedef enum rcg_field {
   RCG_FIELD_OBS_BUF = 13,    /* [buffer_size][dy][B] real, newest row last (utilities.py:78)      */
   RCG_FIELD_ACT_BUF = 14,    /* [buffer_size][du][B] real                                         */
   RCG_FIELD_RETURNS = 15,    /* [B]      real    accum_obj of the last finished episode           */
-  RCG_FIELD_COUNT_ = 16
+  RCG_FIELD_ACTION_SQN = 16, /* [B][N][du] real  last optimised action sequence, one row per env  */
+  RCG_FIELD_COUNT_ = 17
 } rcg_field;
 
 /* Plain-old-data configuration.  All reals are double here and are converted to the handle's
@@ -206,6 +207,17 @@ int rcg_actor_argmin(rcg_handle* h, const void* cand, int32_t K, const void* obs
  * candidates -> ACTION := winner's first action -> ACCUM += stage_obj(obs, action)*sampling_time ->
  * STEP_IDX += 1.  cand as rcg_actor_argmin. */
 int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
+/* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398), MPC with a
+ * diagonal R1: `iters` iterations of {adjoint gradient of _actor_cost w.r.t. the whole sequence, box-scaled
+ * projected line search over 64 step lengths}.  obs / state_sys as rcg_actor_cost; u_init [B][N][du] (NULL:
+ * action_sqn_init = action_init tiled, as the reference starts every call); outputs, each may be NULL:
+ * u_opt [B][N][du], action [du][B] (first du entries, controllers.py:1427), best_J [B], n_iter [B] int32. */
+int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
+                       void* u_opt, void* action, void* best_J, int32_t* n_iter);
+/* rcg_control_tick with rcg_actor_optimize as the decision: sim_step -> optimise -> ACTION, ACTION_SQN, BEST_J ->
+ * ACCUM, STEP_IDX.  warm_start != 0: start from the previous tick's optimum shifted by one step (the reference
+ * always restarts from action_sqn_init: warm_start = 0). */
+int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start);
 /* RQL/SQL bookkeeping of CtrlOptPred.compute_action (controllers.py:1458-1477): push (ACTION, obs)
  * into the buffers and, if do_fit != 0, refit W_CRITIC by bounded least squares on the TD stack of
  * _critic_cost (replacement of _critic_optimizer, controllers.py:1248-1271); W_PREV := W_CRITIC. */

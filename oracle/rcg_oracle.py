@@ -471,6 +471,119 @@ def control_tick(cfg: OracleCfg, env: EnvBatch, cand):
 
 
 # ----------------------------------------------------------------------------------------------
+# Build-defined actor optimiser (replacement of the SLSQP call in
+# CtrlOptPred._actor_optimizer, controllers.py:1330-1427): adjoint gradient + projected line search
+# ----------------------------------------------------------------------------------------------
+OPT_NALPHA = 64  # step lengths tried per iteration = lanes of the wave that owns the env
+
+
+def state_jac_T(sys_id, x, u, pars, lam):
+    """(A^T lam, B^T lam) with A = d f/d x, B = d f/d u of ``_state_dyn`` at (x, u); single env."""
+    if sys_id == SYS_3WROBOT:
+        s, c = np.sin(x[2]), np.cos(x[2])
+        ax = np.array([0.0, 0.0, x[3] * (lam[1] * c - lam[0] * s), lam[0] * c + lam[1] * s, lam[2]])
+        bu = np.array([lam[3] * (1 / pars[0]), lam[4] * (1 / pars[1])])
+    elif sys_id == SYS_3WROBOT_NI:
+        s, c = np.sin(x[2]), np.cos(x[2])
+        ax = np.array([0.0, 0.0, u[0] * (lam[1] * c - lam[0] * s)])
+        bu = np.array([lam[0] * c + lam[1] * s, lam[2]])
+    else:
+        tau1, tau2, K1, K2, K3 = pars
+        ax = np.array([-lam[0] * (1 / tau1) + lam[1] * (1 / tau2) * K2, lam[1] * (1 / tau2) * (-1 + 2 * K3 * x[1])])
+        bu = np.array([lam[0] * (1 / tau1) * K1])
+    return ax, bu
+
+
+def actor_grad(u, obs, state_sys, cfg: OracleCfg, pars=None):
+    """Gradient of the MPC ``_actor_cost`` (diagonal R1) w.r.t. the whole action sequence ``u [N, du]`` by one
+    forward Euler rollout and one reverse (adjoint) sweep.  Returns ``(J, g [N, du])``."""
+    assert cfg.mode == MODE_MPC and cfg.stage_obj_struct == STAGE_QUADRATIC
+    N, du, ds, h = cfg.n_actor, cfg.du, cfg.ds, cfg.pred_step_size
+    pars = cfg.pars if pars is None else pars
+    Rd = np.diag(cfg.R1)
+    tgt = np.zeros(ds) if cfg.target is None else cfg.target
+    X = [np.asarray(state_sys, dtype=np.float64)]
+    for k in range(1, N):
+        X.append(X[-1] + h * state_dyn(cfg.sys_id, X[-1], u[k - 1], pars))
+    Y = [np.asarray(obs, dtype=np.float64)] + X[1:]
+    J, gk = 0.0, 1.0
+    gks = []
+    for k in range(N):
+        chi = np.concatenate([Y[k] - tgt, u[k]])
+        J += gk * float(np.sum(Rd * chi * chi))
+        gks.append(gk)
+        gk *= cfg.gamma
+    g = np.zeros((N, du))
+    lam = np.zeros(ds)  # d J / d x_{k+1}
+    for k in range(N - 1, -1, -1):
+        g[k] = gks[k] * 2.0 * Rd[ds:] * u[k]
+        if k < N - 1:
+            ax, bu = state_jac_T(cfg.sys_id, X[k], u[k], pars, lam)
+            g[k] = g[k] + h * bu
+            lam_k = lam + h * ax
+        else:
+            lam_k = np.zeros(ds)
+        if k >= 1:  # y_0 is the observation, not a function of the actions
+            lam_k = lam_k + gks[k] * 2.0 * Rd[:ds] * (Y[k] - tgt)
+        lam = lam_k
+    return J, g
+
+
+def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None):
+    """Projected, box-scaled steepest descent with a 64-way line search.
+
+    Per iteration: g = grad J(u); d = g * (hi - lo)^2 (the box-width metric makes the inputs commensurable);
+    the 64 candidates ``clip(u - alpha_l d)`` with ``alpha_l = 2^(2 - l/2) / max|d / (hi - lo)|``, l = 0..63 (from four
+    box widths down by sqrt(2) per lane) are evaluated with ``_actor_cost``; the best one (lower J, then lower l)
+    replaces u if it improves J, otherwise the search stops.  Returns ``(u [N, du], J, iterations used)``."""
+    lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
+    w = hi - lo
+    u = np.array(u_init, dtype=np.float64).reshape(cfg.n_actor, cfg.du)
+    J = float(actor_cost(u, obs, state_sys, cfg, pars=pars))
+    used = 0
+    for _ in range(int(iters)):
+        _, g = actor_grad(u, obs, state_sys, cfg, pars=pars)
+        d = g * w * w
+        gn = float(np.max(np.abs(d) / w))
+        if not (gn > 0.0) or not np.isfinite(gn):
+            break
+        alphas = (1.0 / gn) * np.exp2(2.0 - 0.5 * np.arange(OPT_NALPHA))
+        cand = np.minimum(np.maximum(u[None] - alphas[:, None, None] * d[None], lo), hi)
+        Js = actor_cost(cand, obs, state_sys, cfg, pars=pars)
+        bj, bi = argmin_first(Js[None])
+        if not (bj[0] < J):
+            break
+        u, J = cand[int(bi[0])], float(bj[0])
+        used += 1
+    return u, J, used
+
+
+def actor_optimize(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None):
+    """Batched wrapper: ``obs/state_sys [B, ds]``, ``u_init [B, N, du]`` or ``[N, du]`` ->
+    ``(u [B, N, du], J [B], iterations [B] int32)``."""
+    obs = np.asarray(obs, dtype=np.float64).reshape(-1, cfg.ds)
+    xs = np.asarray(state_sys, dtype=np.float64).reshape(-1, cfg.ds)
+    B = obs.shape[0]
+    u0 = np.broadcast_to(np.asarray(u_init, dtype=np.float64).reshape(-1, cfg.n_actor, cfg.du)
+                         if np.ndim(u_init) == 3 else np.asarray(u_init, dtype=np.float64)[None], (B, cfg.n_actor, cfg.du))
+    U, Js, its = [], [], []
+    for b in range(B):
+        p = None if pars is None else np.asarray(pars)[b]
+        u, J, n = actor_optimize_single(cfg, obs[b], xs[b], u0[b], iters, pars=p)
+        U.append(u)
+        Js.append(J)
+        its.append(n)
+    return np.stack(U), np.array(Js), np.array(its, dtype=np.int32)
+
+
+def action_sqn_init(cfg: OracleCfg, action_init=None):
+    """``action_sqn_init`` of the reference: ``action_min / 10`` (or ``action_init``) tiled over the horizon
+    (controllers.py:973-978)."""
+    a = cfg.ctrl_bnds[:, 0] / 10.0 if action_init is None else np.asarray(action_init, dtype=np.float64)
+    return np.tile(a, (cfg.n_actor, 1))
+
+
+# ----------------------------------------------------------------------------------------------
 # Build-defined critic fit (replacement of CtrlOptPred._critic_optimizer, controllers.py:1248-1271)
 # ----------------------------------------------------------------------------------------------
 FIT_MU_REL = 1e-8   # Tikhonov weight relative to trace(A A^T)/m
@@ -585,6 +698,28 @@ def critic_fit(cfg: OracleCfg, w_prev, obs_buf, act_buf, w_init=None):
     lo, hi = critic_bounds(cfg.critic_struct, cfg.dc)
     w0 = np.ones(cfg.dc) if w_init is None else np.asarray(w_init, dtype=np.float64)
     return np.stack([critic_fit_single(A[i], b[i], w0, lo, hi) for i in range(B)])
+
+
+def control_tick_opt(cfg: OracleCfg, env: EnvBatch, iters: int, warm_start: bool = False, action_init=None):
+    """``control_tick`` with :func:`actor_optimize` as the decision (twin of rcg_control_tick_opt): sim_step ->
+    optimise from ``action_sqn_init`` (or, with ``warm_start`` after the first tick, from the previous optimum shifted
+    by one step with the last step repeated) -> action = first ``du`` entries -> accum, step_idx."""
+    sim_substeps(cfg, env, cfg.substeps_per_tick)
+    obs = env.state
+    state_sys = env.state_prev if cfg.ref_lag else env.state
+    B = obs.shape[0]
+    prev = getattr(env, "action_sqn", None)
+    if warm_start and env.tick_count > 0 and prev is not None:
+        u0 = np.concatenate([prev[:, 1:], prev[:, -1:]], axis=1)
+    else:
+        u0 = np.broadcast_to(action_sqn_init(cfg, action_init), (B, cfg.n_actor, cfg.du))
+    env.tick_count += 1
+    U, J, its = actor_optimize(cfg, obs, state_sys, u0, iters, pars=env.pars if env.pars.ndim == 2 else None)
+    env.action_sqn, env.best_J, env.best_idx = U, J, its
+    env.action = U[:, 0, :].copy()
+    if not cfg.accum_every_substep:
+        env.accum = env.accum + stage_obj(obs, env.action, cfg) * cfg.sampling_time
+    env.step_idx = env.step_idx + np.int32(1)
 
 
 def critic_update(cfg: OracleCfg, env: EnvBatch, do_fit=True):

@@ -26,7 +26,7 @@ FLAG_HAS_TARGET, FLAG_PER_ENV_PARS, FLAG_REF_LAG, FLAG_ACCUM_EVERY_SUBSTEP, FLAG
 
 (FIELD_STATE, FIELD_ACTION, FIELD_ACCUM, FIELD_STEP_IDX, FIELD_EPISODE_IDX, FIELD_STATUS, FIELD_PARS,
  FIELD_STATE_INIT, FIELD_STATE_PREV, FIELD_BEST_J, FIELD_BEST_IDX, FIELD_W_CRITIC, FIELD_W_PREV, FIELD_OBS_BUF,
- FIELD_ACT_BUF, FIELD_RETURNS) = range(16)
+ FIELD_ACT_BUF, FIELD_RETURNS, FIELD_ACTION_SQN) = range(17)
 
 MODE_IDS = {"MPC": MODE_MPC, "RQL": MODE_RQL, "SQL": MODE_SQL}
 STAGE_IDS = {"quadratic": STAGE_QUADRATIC, "biquadratic": STAGE_BIQUADRATIC}
@@ -41,7 +41,7 @@ SYMBOLS = [
     "rcg_synchronize", "rcg_dev_alloc", "rcg_dev_free", "rcg_memcpy_h2d", "rcg_memcpy_d2h", "rcg_set_field",
     "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
-    "rcg_critic_update", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
+    "rcg_critic_update", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 
@@ -112,6 +112,8 @@ def lib():
         "rcg_actor_argmin": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp]),
         "rcg_control_tick": (C.c_int, [vp, vp, i32]),
         "rcg_critic_update": (C.c_int, [vp, i32]),
+        "rcg_actor_optimize": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
         "rcg_episode_reset": (C.c_int, [vp]),
         "rcg_episode_stats": (C.c_int, [vp, i32, vp, C.POINTER(RcgSummary)]),
         "rcg_profile": (C.c_int, [vp, i32]),

@@ -223,6 +223,7 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->fbytes[RCG_FIELD_BEST_J] = B * e;
   h->fbytes[RCG_FIELD_BEST_IDX] = B * 4;
   h->fbytes[RCG_FIELD_RETURNS] = B * e;
+  h->fbytes[RCG_FIELD_ACTION_SQN] = (size_t)cfg->n_actor * du * B * e;
   if (cfg->buffer_size > 0) {
     h->fbytes[RCG_FIELD_W_CRITIC] = h->dc * B * e;
     h->fbytes[RCG_FIELD_W_PREV] = h->dc * B * e;
@@ -434,6 +435,25 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
   h->tick_count += 1;
   return h->sys->actor(h, "rcg_control_tick", cand, K, nullptr, nullptr, nullptr, nullptr, h->f[RCG_FIELD_ACTION],
                        h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, sim_first);
+}
+
+int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
+                       void* u_opt, void* action, void* best_J, int32_t* n_iter) {
+  if (!h || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_actor_optimize: iters must be >= 0");
+  return h->sys->optimize(h, iters, obs, state_sys, u_init, 0, u_opt, action, best_J, n_iter, false);
+}
+
+int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start) {
+  if (!h || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_tick_opt: iters must be >= 0");
+  if (h->cfg.mode != RCG_MODE_MPC)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_opt: MPC only (RQL/SQL use rcg_control_tick)");
+  int rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
+  if (rc) return rc;
+  const bool warm = warm_start && h->tick_count > 0;  // nothing to shift before the first decision
+  h->tick_count += 1;
+  void* sqn = h->f[RCG_FIELD_ACTION_SQN];
+  return h->sys->optimize(h, iters, nullptr, nullptr, warm ? sqn : nullptr, warm ? 1 : 0, sqn, h->f[RCG_FIELD_ACTION],
+                          h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true);
 }
 
 int rcg_episode_reset(rcg_handle* h) {

@@ -111,5 +111,7 @@ struct SysVTable {
                const void* w, void* J, void* action, void* best_J, int32_t* best_idx, bool tick, bool sim_first);
   int (*sim_step)(rcg_handle*, int32_t n_substeps);
   int (*critic_update)(rcg_handle*, int32_t do_fit);
+  int (*optimize)(rcg_handle*, int32_t iters, const void* obs, const void* state_sys, const void* u_init, int shift,
+                  void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick);
 };
 extern const SysVTable kVt3WRobot, kVt3WRobotNI, kVt2Tank;

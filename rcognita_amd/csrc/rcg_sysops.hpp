@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "rcg_actor_dma.hpp"
+#include "rcg_actor_opt.hpp"
 #include "rcg_critic_fit.hpp"
 #include "rcg_handle.hpp"
 
@@ -282,13 +283,56 @@ static int op_actor(rcg_handle* h, const char* who, const void* cand, int K, con
   });
 }
 
+template <typename Sys>
+static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
+                       int shift, void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick) {
+  const rcg_cfg& c = h->cfg;
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    const KParams<real>& P = params<real>(h);
+    if (c.mode != RCG_MODE_MPC || P.stage_kind != 0)
+      return rcg_fail(h, RCG_ERR_UNSUPPORTED,
+                      "rcg_actor_optimize: the native optimiser covers MPC with a diagonal quadratic stage cost");
+    OptArgs<real> A;
+    memset(&A, 0, sizeof A);
+    A.obs = obs ? (const real*)obs : (const real*)h->f[RCG_FIELD_STATE];
+    if (state_sys)
+      A.state_sys = (const real*)state_sys;
+    else if (obs)
+      A.state_sys = (const real*)obs;
+    else
+      A.state_sys = (const real*)h->f[(tick && (c.flags & RCG_FLAG_REF_LAG)) ? RCG_FIELD_STATE_PREV : RCG_FIELD_STATE];
+    A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    A.u_init = (const real*)u_init;
+    A.u_opt = (real*)u_opt;
+    A.action_out = (real*)action;
+    A.best_J = (real*)best_J;
+    A.n_iter = n_iter;
+    A.accum = (tick && !(c.flags & RCG_FLAG_ACCUM_EVERY_SUBSTEP)) ? (real*)h->f[RCG_FIELD_ACCUM] : nullptr;
+    A.step_idx = tick ? (int32_t*)h->f[RCG_FIELD_STEP_IDX] : nullptr;
+    for (int i = 0; i < Sys::DU; ++i) A.u0[i] = (real)c.action_init[i];
+    A.iters = iters;
+    A.shift = shift;
+    const int N = c.n_actor, R = N * Sys::DU;
+    const size_t lds = 4 * (size_t)(2 * R + N * Sys::DS + N) * sizeof(real);
+    const dim3 grid(blocks_for(c.batch, 4)), block(256);
+    ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+    if (c.flags & RCG_FLAG_HAS_TARGET)
+      hipLaunchKernelGGL((k_actor_opt<Sys, real, true>), grid, block, lds, h->stream, A, P);
+    else
+      hipLaunchKernelGGL((k_actor_opt<Sys, real, false>), grid, block, lds, h->stream, A, P);
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
 // Explicitly instantiated once per environment (rcg_sys_*.hip): pulls in every launcher above and,
 // through their launch expressions, every kernel.
 template <typename Sys>
 struct SysInstances {
   static SysVTable table() {
     return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,       &op_critic_cost<Sys>,
-                     &op_actor<Sys>, &op_sim_step<Sys>,  &op_critic_update<Sys>};
+                     &op_actor<Sys>, &op_sim_step<Sys>,  &op_critic_update<Sys>, &op_optimize<Sys>};
   }
 };
 

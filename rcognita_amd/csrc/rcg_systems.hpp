@@ -32,6 +32,20 @@ struct Sys3WRobot {
     d[3] = q.inv_m * u[0];  // 1/m * action[0]
     d[4] = q.inv_I * u[1];  // 1/I * action[1]
   }
+  // (A^T lam, B^T lam), A = d f/d x, B = d f/d u at (x, u): the adjoint sweep of k_actor_opt
+  template <typename real>
+  __device__ __forceinline__ static void jac_T(const Pre<real>& q, const real* x, const real*, const real* lam,
+                                               real* ax, real* bu) {
+    real s, c;
+    sincos_r<real>(x[2], &s, &c);
+    ax[0] = 0;
+    ax[1] = 0;
+    ax[2] = x[3] * (lam[1] * c - lam[0] * s);
+    ax[3] = lam[0] * c + lam[1] * s;
+    ax[4] = lam[2];
+    bu[0] = lam[3] * q.inv_m;
+    bu[1] = lam[4] * q.inv_I;
+  }
 };
 
 // rcognita/systems.py:370-382  state = (x, y, alpha), action = (v, omega), no pars
@@ -51,6 +65,17 @@ struct Sys3WRobotNI {
     d[1] = u[0] * s;
     d[2] = u[1];
   }
+  template <typename real>
+  __device__ __forceinline__ static void jac_T(const Pre<real>&, const real* x, const real* u, const real* lam,
+                                               real* ax, real* bu) {
+    real s, c;
+    sincos_r<real>(x[2], &s, &c);
+    ax[0] = 0;
+    ax[1] = 0;
+    ax[2] = u[0] * (lam[1] * c - lam[0] * s);
+    bu[0] = lam[0] * c + lam[1] * s;
+    bu[1] = lam[2];
+  }
 };
 
 // rcognita/systems.py:412-419  state = (h1, h2), action = (u), pars = (tau1, tau2, K1, K2, K3)
@@ -68,6 +93,13 @@ struct Sys2Tank {
   __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
     d[0] = q.inv_tau1 * (-x[0] + q.K1 * u[0]);
     d[1] = q.inv_tau2 * (-x[1] + q.K2 * x[0] + q.K3 * (x[1] * x[1]));
+  }
+  template <typename real>
+  __device__ __forceinline__ static void jac_T(const Pre<real>& q, const real* x, const real*, const real* lam,
+                                               real* ax, real* bu) {
+    ax[0] = -lam[0] * q.inv_tau1 + lam[1] * q.inv_tau2 * q.K2;
+    ax[1] = lam[1] * q.inv_tau2 * ((real)-1 + (real)2 * q.K3 * x[1]);
+    bu[0] = lam[0] * q.inv_tau1 * q.K1;
   }
 };
 

@@ -239,6 +239,8 @@ class Engine:
         """(device shape, dtype, host->device transform, device->host transform)."""
         dt = self._FIELD_INT.get(f, self.real)
         B = self.B
+        if f == N.FIELD_ACTION_SQN:  # one row per env, the reference's flat step-major layout
+            return (B, self.N, self.du), dt, (lambda a: a.reshape(B, self.N, self.du)), (lambda a: a)
         if f in (N.FIELD_OBS_BUF, N.FIELD_ACT_BUF):
             d = self.dy if f == N.FIELD_OBS_BUF else self.du
             return (self.buffer_size, d, B), dt, (lambda a: a.reshape(B, self.buffer_size, d).transpose(1, 2, 0)), (
@@ -369,6 +371,25 @@ class Engine:
         N.check(N.lib().rcg_control_tick(self._h, pc, K), self._h)
         if keep:  # temporaries were uploaded for this call: finish before they are freed
             self.synchronize()
+
+    def actor_optimize(self, iters=10, obs=None, state_sys=None, u_init=None):
+        """On-device actor optimiser (rcg_actor_optimize): adjoint gradient + 64-way projected line search.
+        ``u_init [B, N, du]`` (None: the reference's ``action_sqn_init``).  Returns
+        ``(action [B, du], u_opt [B, N, du], best_J [B], n_iter [B] int32)``."""
+        keep = []
+        pu = self._in(None if u_init is None else np.broadcast_to(
+            np.asarray(u_init, dtype=self.real).reshape(-1, self.N, self.du), (self.B, self.N, self.du)), keep)
+        uo, act = self.empty((self.B, self.N, self.du)), self.empty((self.du, self.B))
+        bj, ni = self.empty((self.B,)), self.empty((self.B,), np.int32)
+        N.check(N.lib().rcg_actor_optimize(self._h, int(iters), self._in(obs, keep, lambda a: a.reshape(self.B, self.dy).T),
+                                           self._in(state_sys, keep, lambda a: a.reshape(self.B, self.ds).T), pu,
+                                           C.c_void_p(uo.ptr), C.c_void_p(act.ptr), C.c_void_p(bj.ptr),
+                                           C.c_void_p(ni.ptr)), self._h)
+        return act.to_host().T.copy(), uo.to_host(), bj.to_host(), ni.to_host()
+
+    def control_tick_opt(self, iters=10, warm_start=False):
+        """One env.control-step with the on-device optimiser as the decision (rcg_control_tick_opt)."""
+        N.check(N.lib().rcg_control_tick_opt(self._h, int(iters), 1 if warm_start else 0), self._h)
 
     def critic_update(self, do_fit=True):
         N.check(N.lib().rcg_critic_update(self._h, 1 if do_fit else 0), self._h)

@@ -71,7 +71,7 @@ def both(name, batch, dtype="f64", **kw):
     """(Engine, OracleCfg) built from the same keyword set (oracle naming)."""
     from rcognita_amd import Engine
 
-    okw = {k: v for k, v in kw.items() if k not in ("per_env_pars",)}
+    okw = {k: v for k, v in kw.items() if k not in ("per_env_pars", "action_init")}
     return Engine(engine_cfg(name, batch, dtype, **kw)), oracle_cfg(name, **okw)
 
 
