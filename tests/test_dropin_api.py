@@ -140,22 +140,26 @@ def test_reference_headless_loop_runs_and_controls(name, mode):
     assert my_ctrl.last_J is not None and np.all(np.isfinite(my_ctrl.last_J))
 
 
+@pytest.mark.parametrize("actor_opt", ["gradient", "sampling"])
 @pytest.mark.parametrize("name", ["3wrobot", "3wrobotNI", "2tank"])
-def test_actor_search_quality_vs_reference_slsqp(name):
+def test_actor_search_quality_vs_reference_slsqp(name, actor_opt):
     """Quality parity of the optimiser replacement (SURVEY.md hard part 1): on the states of the golden
     F8 fixture the candidate search must beat the reference's start point and come close to the cost
     SLSQP reaches with the reference's own _actor_cost."""
     meta, z = load_golden(f"F8_slsqp_actor_{name}")
     x = z["state"]
     B = x.shape[0]
-    my_sys, my_ctrl, _ = build(name, Nactor=meta["N"], state_init=x, n_candidates=256, rounds=8)
+    my_sys, my_ctrl, _ = build(name, Nactor=meta["N"], state_init=x, n_candidates=256, rounds=8, actor_opt=actor_opt)
     my_ctrl.receive_sys_state(x)
     my_ctrl._actor_optimizer(x)
     J = my_ctrl.last_J
     assert np.all(J <= z["J_init"] * (1 + 1e-9))
     ratio = J / np.maximum(z["J_opt"], 1e-12)
-    print(f"{name}: J_search / J_slsqp  median {np.median(ratio):.4f}  max {np.max(ratio):.4f}")
-    assert np.median(ratio) < 1.05 and np.max(ratio) < 1.5
+    print(f"{name} {actor_opt}: J_search / J_slsqp  median {np.median(ratio):.4f}  max {np.max(ratio):.4f}")
+    if actor_opt == "gradient":  # on-device optimiser: SLSQP's cost to 0.2 %
+        assert np.median(ratio) < 1.0005 and np.max(ratio) < 1.002
+    else:  # derivative-free candidate rounds
+        assert np.median(ratio) < 1.05 and np.max(ratio) < 1.5
     # and the winning sequence really has that cost under the oracle's _actor_cost
     cfg = oracle_cfg(name, n_actor=meta["N"], gamma=meta["gamma"], pred_step_size=meta["pred_step_size"])
     J_or = O.actor_cost(my_ctrl._prev_opt, x, x, cfg)

@@ -54,6 +54,27 @@ def main():
             "sim_ms": sm / max(sn, 1), "n_failed": summ["n_failed"], "candidates": "generated 256-level grid"}
         eng.close()
 
+    # ---- on-device optimiser tick on the C2 shape ------------------------------------
+    B2 = 65536
+    for iters in (5, 10):
+        eng = Engine(preset_engine_config("3wrobot", B2, Nactor=10))
+        eng.set_state(np.stack([rng.uniform(-10, 10, B2), rng.uniform(-10, 10, B2), rng.uniform(-np.pi, np.pi, B2),
+                                rng.uniform(-1, 1, B2), rng.uniform(-1, 1, B2)], axis=-1))
+        for _ in range(a.warmup):
+            eng.control_tick_opt(iters=iters)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.control_tick_opt(iters=iters)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        used = eng.get_field(N.FIELD_BEST_IDX)
+        out[f"C2_3wrobot_B{B2}_N10_optimizer_iters{iters}"] = {
+            "env_control_steps_per_s": B2 * a.steps / dt, "ms_per_tick": dt / a.steps * 1e3,
+            "mean_iterations_used": float(used.mean()),
+            "note": "adjoint gradient + 64-way line search per iteration (about 65 _actor_cost evaluations each)"}
+        eng.close()
+
     # ---- configs[4], one GPU's shard -----------------------------------------------------------------
     total = 65536
     counts = {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
