@@ -586,21 +586,27 @@ def action_sqn_init(cfg: OracleCfg, action_init=None):
 # ----------------------------------------------------------------------------------------------
 # Build-defined critic fit (replacement of CtrlOptPred._critic_optimizer, controllers.py:1248-1271)
 # ----------------------------------------------------------------------------------------------
-FIT_MU_REL = 1e-8   # Tikhonov weight relative to trace(A A^T)/m
-FIT_ITERS = 40      # semismooth-Newton iterations (fixed cap: deterministic work per env)
-FIT_LS = 20         # Armijo halvings per iteration
-FIT_GTOL = 1e-12
+FIT_MU_REL = 1e-8     # Tikhonov weight relative to trace(A A^T)/m
+FIT_KKT_TOL = 1e-10   # a bound variable is released only if its multiplier has the wrong sign beyond this (relative)
 
 
-def _chol_solve(H, rhs):
+def fit_max_iters(dc: int) -> int:
+    """Iteration cap of the active-set loop (one m x m Cholesky solve per iteration)."""
+    return 3 * dc + 10
+
+
+def _chol_solve(H, rhs, floor=0.0):
     """Solve the SPD system ``H x = rhs`` by an unpivoted Cholesky factorisation, written out in the
-    same operation order as the HIP kernel (rcg_critic_fit.hpp) so both take the same Newton steps."""
+    same operation order as the HIP kernel (rcg_critic_fit.hpp) so both take the same steps.  Pivots
+    are floored at ``floor`` (only reached when rounding makes a pivot of a near-singular H non-positive)."""
     m = H.shape[0]
     L = np.array(H, dtype=np.float64)
     for j in range(m):
         dj = L[j, j]
         for k in range(j):
             dj -= L[j, k] * L[j, k]
+        if not dj > floor:
+            dj = floor
         dj = np.sqrt(dj)
         L[j, j] = dj
         for i in range(j + 1, m):
@@ -622,7 +628,7 @@ def _chol_solve(H, rhs):
     return x
 
 
-def critic_fit_single(A, b, w0, lo, hi):
+def critic_fit_single(A, b, w0, lo, hi, stats=None):
     """Bounded least squares of the TD stack for ONE env.
 
     The reference minimises ``Jc(w) = 1/2 |A w - b|^2`` over the box ``[Wmin, Wmax]`` with SLSQP started
@@ -633,62 +639,117 @@ def critic_fit_single(A, b, w0, lo, hi):
         1/2 |A w - b|^2 + mu/2 |w - w_init|^2   s.t.  lo <= w <= hi,   mu = FIT_MU_REL * trace(A A^T) / m
 
     (for mu -> 0 and inactive bounds: the least-squares solution closest to w_init, which is also where
-    a quasi-Newton method started at w_init with an identity Hessian converges).  It is computed in the
-    m-dimensional dual: ``w(y) = clip(w_init - A^T y / mu, lo, hi)``, maximise the concave, piecewise
-    quadratic dual by a semismooth Newton method with Armijo backtracking on the dual objective.
-    Safeguard: the feasible iterate with the smallest ``Jc`` (w_init included) is returned, so the fit
-    never increases ``Jc`` over the start point.  The HIP kernel k_critic_fit mirrors this line by line,
-    in float64 whatever the handle's dtype.
+    a quasi-Newton method started at w_init with an identity Hessian converges).  It is computed by a
+    primal active-set method (bounded-variable least squares in the manner of Stark & Parker): every
+    iteration solves the equality-constrained problem on the free variables exactly through the m x m
+    system ``(A_F A_F^T + mu I) lam = b - A_B w_B - A_F w0_F``, ``z_F = w0_F + A_F^T lam``; if ``z``
+    leaves the box the iterate moves towards it until the first bound is hit and that variable is fixed,
+    otherwise ``w_F = z`` and the bound variable whose multiplier has the most wrong sign is released
+    (none: optimal).  The objective never increases, the iterate is always feasible, and a released
+    variable that is pushed straight back (rounding on a degenerate stack) is kept fixed until the
+    iterate moves.  Safeguard: ``w_init`` is returned if the result does not have ``Jc <= Jc(w_init)``
+    (non-finite buffers).  The HIP kernel k_critic_fit mirrors this statement by statement, in float64
+    whatever the handle's dtype.  ``stats`` (a list) receives the number of iterations used.
     """
     A = np.asarray(A, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     w0 = np.asarray(w0, dtype=np.float64)
-    m = A.shape[0]
+    lo = np.asarray(lo, dtype=np.float64)
+    hi = np.asarray(hi, dtype=np.float64)
+    m, dc = A.shape
     tr = 0.0
     for r in range(m):
-        tr += float(A[r] @ A[r])
-    mu = FIT_MU_REL * (tr / m) + 1e-300
-    inv_mu = 1.0 / mu
+        for i in range(dc):
+            tr += A[r, i] * A[r, i]
+    mu = FIT_MU_REL * (tr / m)
+    if not mu > 1e-30:
+        mu = 1e-30
 
-    def w_of(y):
-        z = w0 - (A.T @ y) * inv_mu
-        return np.minimum(np.maximum(z, lo), hi), (z > lo) & (z < hi)
+    w = np.minimum(np.maximum(w0, lo), hi)
+    free = (w > lo) & (w < hi)
+    at_hi = (~free) & (w >= hi)
+    blocked = np.zeros(dc, dtype=bool)
+    last_freed = -1
+    z = np.zeros(dc)
+    iters = 0
+    for _ in range(fit_max_iters(dc)):
+        iters += 1
+        rhs = np.zeros(m)
+        M = np.zeros((m, m))
+        for r in range(m):
+            s = b[r]
+            for i in range(dc):
+                s -= A[r, i] * (w0[i] if free[i] else w[i])
+            rhs[r] = s
+            for q in range(r + 1):
+                acc = 0.0
+                for i in range(dc):
+                    if free[i]:
+                        acc += A[r, i] * A[q, i]
+                M[r, q] = M[q, r] = acc + (mu if r == q else 0.0)
+        lam = _chol_solve(M, rhs, floor=mu * 1e-6)
+        alpha, jmin = 2.0, -1
+        for i in range(dc):
+            if not free[i]:
+                continue
+            c = 0.0
+            for r in range(m):
+                c += A[r, i] * lam[r]
+            z[i] = w0[i] + c
+            a = 2.0
+            if z[i] < lo[i]:
+                a = (lo[i] - w[i]) / (z[i] - w[i])
+            elif z[i] > hi[i]:
+                a = (hi[i] - w[i]) / (z[i] - w[i])
+            if a < alpha:
+                alpha, jmin = a, i
+        if jmin >= 0:  # move towards z until the first bound, fix that variable
+            if not alpha > 0.0:
+                alpha = 0.0
+            for i in range(dc):
+                if free[i]:
+                    w[i] = min(max(w[i] + alpha * (z[i] - w[i]), lo[i]), hi[i])
+            at_hi[jmin] = z[jmin] > hi[jmin]
+            w[jmin] = hi[jmin] if at_hi[jmin] else lo[jmin]
+            free[jmin] = False
+            if alpha > 0.0:
+                blocked[:] = False
+            elif jmin == last_freed:
+                blocked[jmin] = True
+            last_freed = -1
+            continue
+        res = -b.copy()
+        for i in range(dc):
+            if free[i]:
+                w[i] = z[i]
+            for r in range(m):
+                res[r] += A[r, i] * w[i]
+        best, best_score = -1, 0.0
+        for i in range(dc):
+            if free[i] or blocked[i]:
+                continue
+            g = mu * (w[i] - w0[i])
+            scale = abs(g)
+            for r in range(m):
+                t = A[r, i] * res[r]
+                g += t
+                scale += abs(t)
+            score = g if at_hi[i] else -g
+            if score > FIT_KKT_TOL * scale and score > best_score:
+                best, best_score = i, score
+        if best < 0:
+            break
+        free[best] = True
+        last_freed = best
+    if stats is not None:
+        stats.append(iters)
 
-    def negdual(y):
-        w, _ = w_of(y)
-        c = A.T @ y
-        return 0.5 * float(y @ y) + float(b @ y) - float(np.sum(0.5 * mu * (w - w0) ** 2 + c * w))
-
-    def primal(w):
-        r = A @ w - b
+    def primal(v):
+        r = A @ v - b
         return 0.5 * float(r @ r)
 
-    y = np.zeros(m)
-    f = negdual(y)
-    best_w, best_P = w0.copy(), primal(w0)
-    bnorm = float(np.sqrt(b @ b))
-    for _ in range(FIT_ITERS):
-        w, free = w_of(y)
-        P = primal(w)
-        if P < best_P:
-            best_P, best_w = P, w.copy()
-        g = -(A @ w - b - y)
-        if float(np.sqrt(g @ g)) <= FIT_GTOL * (bnorm + 1.0):
-            break
-        Af = A[:, free]
-        H = (Af @ Af.T) * inv_mu + np.eye(m)
-        d = _chol_solve(H, -g)
-        slope = float(g @ d)
-        t = 1.0
-        fn = f
-        for _ in range(FIT_LS):
-            fn = negdual(y + t * d)
-            if fn <= f + 1e-4 * t * slope:
-                break
-            t *= 0.5
-        y = y + t * d
-        f = fn
-    return best_w
+    wi = np.minimum(np.maximum(w0, lo), hi)
+    return w if primal(w) <= primal(wi) else wi
 
 
 def critic_fit(cfg: OracleCfg, w_prev, obs_buf, act_buf, w_init=None):

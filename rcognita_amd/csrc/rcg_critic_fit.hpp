@@ -8,19 +8,23 @@
 // on the OLDEST Ncritic buffer rows.  The reference runs SLSQP from w_init = ones; its iterates are
 // path dependent, so the build defines the fit as the unique minimiser of
 //   1/2 |A w - b|^2 + mu/2 |w - w_init|^2   in the box,  mu = 1e-8 * trace(A A^T) / m,
-// computed by a semismooth Newton method on the m-dimensional dual with Armijo backtracking, and
-// returns the feasible iterate with the smallest Jc (never worse than w_init).  This mirrors
+// computed by a primal active-set method (bounded-variable least squares): each iteration solves the
+// problem on the free variables exactly through the m x m system (A_F A_F^T + mu I) lam = rhs
+// (Cholesky), then either moves towards that point until the first bound is hit and fixes that
+// variable, or accepts it and releases the bound variable with the most wrong-signed multiplier
+// (none: optimal).  Feasible and monotone, so the result is never worse than w_init.  This mirrors
 // oracle/rcg_oracle.py::critic_fit_single statement by statement; all arithmetic is float64 whatever
-// the handle's dtype (the systems are tiny - m <= 8, dc <= 35 - and badly scaled).
+// the handle's dtype (the systems are tiny - m <= 8, dc <= 35 - and badly scaled).  The active set is
+// held in 64-bit lane-private masks and every loop over variables is unrolled with a predicate, so no
+// array is indexed dynamically.
 #pragma once
 #include "rcg_kernels.hpp"
 
 namespace rcg {
 
 constexpr double FIT_MU_REL = 1e-8;
-constexpr int FIT_ITERS = 40;
-constexpr int FIT_LS = 20;
-constexpr double FIT_GTOL = 1e-12;
+constexpr double FIT_KKT_TOL = 1e-10;
+__host__ __device__ constexpr int fit_max_iters(int dc) { return 3 * dc + 10; }
 
 template <int CS, int DS, int DU>
 struct CriticDim {
@@ -124,92 +128,47 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
   for (int r = 0; r < MAXM; ++r)
 #pragma unroll
     for (int i = 0; i < DC; ++i) tr = fma_r(A[r][i], A[r][i], tr);  // rows >= m are zero
-  const double mu = FIT_MU_REL * (tr / (double)m) + 1e-300;
-  const double inv_mu = 1.0 / mu;
-  double bnorm = 0.0;
-#pragma unroll
-  for (int r = 0; r < MAXM; ++r) bnorm = fma_r(bv[r], bv[r], bnorm);
-  bnorm = sqrt(bnorm);
+  double mu = FIT_MU_REL * (tr / (double)m);
+  if (!(mu > 1e-30)) mu = 1e-30;
 
-  // w(y) = clip(w0 - A^T y / mu); returns -dual(y); optionally the primal cost, w and the free mask
-  auto eval = [&](const double* yv, double* w_out, unsigned long long* free_out, double* primal_out) -> double {
-    double acc = 0.0, res[MAXM];
-    unsigned long long fm = 0ull;
+  double w[DC], z[DC];
+  unsigned long long fm = 0ull, at_hi = 0ull, blocked = 0ull;  // free / fixed-at-upper / not-to-release masks
 #pragma unroll
-    for (int r = 0; r < MAXM; ++r) res[r] = -bv[r];
-#pragma unroll
-    for (int i = 0; i < DC; ++i) {
-      double c = 0.0;
-#pragma unroll
-      for (int r = 0; r < MAXM; ++r) c = fma_r(A[r][i], yv[r], c);
-      const double z = w0[i] - c * inv_mu;
-      const double w = z < lo[i] ? lo[i] : (z > hi[i] ? hi[i] : z);
-      if (z > lo[i] && z < hi[i]) fm |= (1ull << i);
-      const double dw = w - w0[i];
-      acc += 0.5 * mu * dw * dw + c * w;
-      if (w_out) w_out[i] = w;
-#pragma unroll
-      for (int r = 0; r < MAXM; ++r) res[r] = fma_r(A[r][i], w, res[r]);
-    }
-    double yy = 0.0, by = 0.0, pr = 0.0;
+  for (int i = 0; i < DC; ++i) {
+    w[i] = w0[i] < lo[i] ? lo[i] : (w0[i] > hi[i] ? hi[i] : w0[i]);
+    z[i] = w[i];
+    if (w[i] > lo[i] && w[i] < hi[i])
+      fm |= 1ull << i;
+    else if (w[i] >= hi[i])
+      at_hi |= 1ull << i;
+  }
+  int last_freed = -1;
+
+  for (int it = 0; it < fit_max_iters(DC); ++it) {
+    // rhs = b - A_B w_B - A_F w0_F,  M = A_F A_F^T + mu I  (rows >= m: M = mu I, rhs = 0 -> lam = 0)
+    double L[MAXM][MAXM], lam[MAXM];
 #pragma unroll
     for (int r = 0; r < MAXM; ++r) {
-      yy = fma_r(yv[r], yv[r], yy);
-      by = fma_r(bv[r], yv[r], by);
-      pr = fma_r(res[r], res[r], pr);
-    }
-    if (free_out) *free_out = fm;
-    if (primal_out) *primal_out = 0.5 * pr;
-    return 0.5 * yy + by - acc;
-  };
-
-  double yv[MAXM], w[DC], best_w[DC];
+      double s = bv[r];
 #pragma unroll
-  for (int r = 0; r < MAXM; ++r) yv[r] = 0.0;
-  unsigned long long fm;
-  double Pw;
-  double f = eval(yv, w, &fm, &Pw);  // y = 0  ->  w = w0 (w_init lies inside the box)
-  double best_P = Pw;
+      for (int i = 0; i < DC; ++i) s = fma_r(-A[r][i], ((fm >> i) & 1ull) ? w0[i] : w[i], s);
+      lam[r] = s;
 #pragma unroll
-  for (int i = 0; i < DC; ++i) best_w[i] = w[i];
-
-  for (int it = 0; it < FIT_ITERS; ++it) {
-    if (it > 0) {
-      eval(yv, w, &fm, &Pw);
-      if (Pw < best_P) {
-        best_P = Pw;
-#pragma unroll
-        for (int i = 0; i < DC; ++i) best_w[i] = w[i];
-      }
-    }
-    // g = -(A w - b - y)
-    double g[MAXM], gn = 0.0;
-#pragma unroll
-    for (int r = 0; r < MAXM; ++r) {
-      double s = -bv[r] - yv[r];
-#pragma unroll
-      for (int i = 0; i < DC; ++i) s = fma_r(A[r][i], w[i], s);
-      g[r] = -s;
-      gn = fma_r(s, s, gn);
-    }
-    if (sqrt(gn) <= FIT_GTOL * (bnorm + 1.0)) break;
-    // H = I + (A_F A_F^T) / mu  (rows >= m: identity), Cholesky H = L L^T, d = -H^{-1} g
-    double L[MAXM][MAXM];
-#pragma unroll
-    for (int r = 0; r < MAXM; ++r)
-#pragma unroll
-      for (int s = 0; s <= r; ++s) {
-        double q = 0.0;
+      for (int q = 0; q <= r; ++q) {
+        double acc = 0.0;
 #pragma unroll
         for (int i = 0; i < DC; ++i)
-          if ((fm >> i) & 1ull) q = fma_r(A[r][i], A[s][i], q);
-        L[r][s] = q * inv_mu + (r == s ? 1.0 : 0.0);
+          if ((fm >> i) & 1ull) acc = fma_r(A[r][i], A[q][i], acc);
+        L[r][q] = acc + (r == q ? mu : 0.0);
       }
+    }
+    const double floor_piv = mu * 1e-6;
 #pragma unroll
     for (int j = 0; j < MAXM; ++j) {
       double dj = L[j][j];
 #pragma unroll
       for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k];
+      if (!(dj > floor_piv)) dj = floor_piv;
       dj = sqrt(dj);
       L[j][j] = dj;
 #pragma unroll
@@ -220,42 +179,119 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
         L[i][j] = s / dj;
       }
     }
-    double d[MAXM];
 #pragma unroll
-    for (int i = 0; i < MAXM; ++i) {  // forward: L z = -g
-      double s = -g[i];
+    for (int i = 0; i < MAXM; ++i) {  // forward: L x = rhs
+      double s = lam[i];
 #pragma unroll
-      for (int k = 0; k < i; ++k) s -= L[i][k] * d[k];
-      d[i] = s / L[i][i];
+      for (int k = 0; k < i; ++k) s -= L[i][k] * lam[k];
+      lam[i] = s / L[i][i];
     }
 #pragma unroll
-    for (int i = MAXM - 1; i >= 0; --i) {  // backward: L^T d = z
-      double s = d[i];
+    for (int i = MAXM - 1; i >= 0; --i) {  // backward: L^T lam = x
+      double s = lam[i];
 #pragma unroll
-      for (int k = i + 1; k < MAXM; ++k) s -= L[k][i] * d[k];
-      d[i] = s / L[i][i];
+      for (int k = i + 1; k < MAXM; ++k) s -= L[k][i] * lam[k];
+      lam[i] = s / L[i][i];
     }
-    double slope = 0.0;
+    // z_F = w0_F + A_F^T lam and the ratio test towards it
+    double alpha = 2.0;
+    int jmin = -1;
 #pragma unroll
-    for (int r = 0; r < MAXM; ++r) slope = fma_r(g[r], d[r], slope);
-    double t = 1.0, fn = f;
-    double yn[MAXM];
-    for (int ls = 0; ls < FIT_LS; ++ls) {
+    for (int i = 0; i < DC; ++i) {
+      if ((fm >> i) & 1ull) {
+        double c = 0.0;
 #pragma unroll
-      for (int r = 0; r < MAXM; ++r) yn[r] = yv[r] + t * d[r];
-      fn = eval(yn, nullptr, nullptr, nullptr);
-      if (fn <= f + 1e-4 * t * slope) break;
-      t *= 0.5;
+        for (int r = 0; r < MAXM; ++r) c = fma_r(A[r][i], lam[r], c);
+        z[i] = w0[i] + c;
+        double a = 2.0;
+        if (z[i] < lo[i])
+          a = (lo[i] - w[i]) / (z[i] - w[i]);
+        else if (z[i] > hi[i])
+          a = (hi[i] - w[i]) / (z[i] - w[i]);
+        if (a < alpha) {
+          alpha = a;
+          jmin = i;
+        }
+      }
     }
+    if (jmin >= 0) {  // move towards z until the first bound, fix that variable
+      if (!(alpha > 0.0)) alpha = 0.0;
 #pragma unroll
-    for (int r = 0; r < MAXM; ++r) yv[r] = yv[r] + t * d[r];
-    f = fn;
+      for (int i = 0; i < DC; ++i) {
+        if ((fm >> i) & 1ull) {
+          double v = w[i] + alpha * (z[i] - w[i]);
+          v = v < lo[i] ? lo[i] : (v > hi[i] ? hi[i] : v);
+          if (i == jmin) {
+            const bool up = z[i] > hi[i];
+            v = up ? hi[i] : lo[i];
+            at_hi = up ? (at_hi | (1ull << i)) : (at_hi & ~(1ull << i));
+          }
+          w[i] = v;
+        }
+      }
+      fm &= ~(1ull << jmin);
+      if (alpha > 0.0)
+        blocked = 0ull;
+      else if (jmin == last_freed)
+        blocked |= 1ull << jmin;
+      last_freed = -1;
+      continue;
+    }
+    double res[MAXM];
+#pragma unroll
+    for (int r = 0; r < MAXM; ++r) res[r] = -bv[r];
+#pragma unroll
+    for (int i = 0; i < DC; ++i) {
+      if ((fm >> i) & 1ull) w[i] = z[i];
+#pragma unroll
+      for (int r = 0; r < MAXM; ++r) res[r] = fma_r(A[r][i], w[i], res[r]);
+    }
+    int best = -1;
+    double best_score = 0.0;
+#pragma unroll
+    for (int i = 0; i < DC; ++i) {
+      if (!(((fm | blocked) >> i) & 1ull)) {
+        double g = mu * (w[i] - w0[i]);
+        double scale = fabs(g);
+#pragma unroll
+        for (int r = 0; r < MAXM; ++r) {
+          const double t = A[r][i] * res[r];
+          g += t;
+          scale += fabs(t);
+        }
+        const double score = ((at_hi >> i) & 1ull) ? g : -g;
+        if (score > FIT_KKT_TOL * scale && score > best_score) {
+          best = i;
+          best_score = score;
+        }
+      }
+    }
+    if (best < 0) break;
+    fm |= 1ull << best;
+    last_freed = best;
   }
 
+  // safeguard (non-finite buffers): keep the start point unless Jc(w) <= Jc(w_init)
+  double Pw = 0.0, P0 = 0.0;
+#pragma unroll
+  for (int r = 0; r < MAXM; ++r) {
+    double s = -bv[r], s0 = -bv[r];
+#pragma unroll
+    for (int i = 0; i < DC; ++i) {
+      const double wi = w0[i] < lo[i] ? lo[i] : (w0[i] > hi[i] ? hi[i] : w0[i]);
+      s = fma_r(A[r][i], w[i], s);
+      s0 = fma_r(A[r][i], wi, s0);
+    }
+    Pw = fma_r(s, s, Pw);
+    P0 = fma_r(s0, s0, P0);
+  }
+  const bool keep = Pw <= P0;
 #pragma unroll
   for (int i = 0; i < DC; ++i) {
-    F.w_critic[(long)i * B + b] = (real)best_w[i];
-    F.w_prev[(long)i * B + b] = (real)best_w[i];  // w_critic_prev = w_critic (controllers.py:1471)
+    const double wi = w0[i] < lo[i] ? lo[i] : (w0[i] > hi[i] ? hi[i] : w0[i]);
+    const double v = keep ? w[i] : wi;
+    F.w_critic[(long)i * B + b] = (real)v;
+    F.w_prev[(long)i * B + b] = (real)v;  // w_critic_prev = w_critic (controllers.py:1471)
   }
 }
 
