@@ -3,41 +3,35 @@
 The scripts keep the reference presets' command-line flags and defaults (presets/main_3wrobot.py:55-163,
 main_3wrobot_NI.py, main_2tank.py), build the objects in the same order with the same constructor calls
 (presets/main_3wrobot.py:218-320) and run the reference's headless loop (presets/main_3wrobot.py:415-468)
-against ``rcognita_amd``.  Out of scope here, as in SURVEY.md 2: visualisation (``--is_visualization`` is
-accepted and ignored, the loop is always headless), the nominal and JACS controllers, model estimation.
+against ``rcognita_amd``, including its console / CSV log contract (``rcognita_amd/loggers.py``; with ``--batch > 1``
+env 0 is what gets printed and logged).  Out of scope here, as in SURVEY.md 2: visualisation (``--is_visualization``
+is accepted and ignored, the loop is always headless), the nominal and JACS controllers, model estimation.
 Added flags: ``--batch`` (run B perturbed copies of the env through the same objects), ``--n_candidates``,
 ``--rounds``, ``--dtype``, ``--device``, ``--seed``.
 """
 from __future__ import annotations
 
 import argparse
-import csv
 import os
 import pathlib
-from datetime import datetime
 
 import numpy as np
 
-from . import controllers, simulator, systems
+from . import controllers, loggers, simulator, systems
 
 SPEC = {
     "3wrobot": dict(cls=systems.Sys3WRobot, dim_state=5, dim_input=2, dim_disturb=2, pars=[10, 1],
                     ctrl_bnds=[[-300, 300], [-100, 100]], dt=0.01, t1=10.0, state_init=["5", "5", "-3*pi/4", "0", "0"],
                     action_manual=[-5, -3], Nactor=5, mult=2.0, R_diag=[1, 10, 1, 0, 0, 0, 0], target=[],
-                    action_init=[], modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"],
-                    cols=["t [s]", "x [m]", "y [m]", "alpha [rad]", "v [m/s]", "omega [rad/s]", "stage_obj",
-                          "accum_obj", "F [N]", "M [N m]"]),
+                    action_init=[], modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"]),
     "3wrobotNI": dict(cls=systems.Sys3WRobotNI, dim_state=3, dim_input=2, dim_disturb=2, pars=[],
                       ctrl_bnds=[[-25, 25], [-5, 5]], dt=0.01, t1=10.0, state_init=["5", "5", "-3*pi/4"],
                       action_manual=[-5, -3], Nactor=3, mult=1.0, R_diag=[1, 10, 1, 0, 0], target=[], action_init=[],
-                      modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"],
-                      cols=["t [s]", "x [m]", "y [m]", "alpha [rad]", "stage_obj", "accum_obj", "v [m/s]",
-                            "omega [rad/s]"]),
+                      modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"]),
     "2tank": dict(cls=systems.Sys2Tank, dim_state=2, dim_input=1, dim_disturb=1, pars=[18.4, 24.4, 1.3, 1, 0.2],
                   ctrl_bnds=[[0, 1]], dt=0.1, t1=100.0, state_init=["2", "-2"], action_manual=[0.5], Nactor=10,
                   mult=2.0, R_diag=[10, 10, 1], target=[0.5, 0.5], action_init=[0.5],
-                  modes=["manual", "MPC", "RQL", "SQL"],
-                  cols=["t [s]", "h1", "h2", "p", "stage_obj", "accum_obj"]),
+                  modes=["manual", "MPC", "RQL", "SQL"]),
 }
 
 
@@ -92,7 +86,8 @@ def run(name: str, argv=None):
                          "path (SURVEY.md 2, components 4-5); use manual, MPC, RQL or SQL")
     if args.is_est_model:
         raise SystemExit("--is_est_model: model estimation needs the absent `sippy` package (out of scope)")
-    state_init = np.array([eval(v.replace("pi", str(np.pi))) for v in args.state_init], dtype=float)
+    state_init_as_given = np.array([eval(v.replace("pi", str(np.pi))) for v in args.state_init])  # header cell
+    state_init = state_init_as_given.astype(float)
     dim_state, dim_input = s["dim_state"], s["dim_input"]
     assert args.t1 > args.dt > 0.0
     assert state_init.size == dim_state
@@ -125,14 +120,19 @@ def run(name: str, argv=None):
         t0=t0, t1=args.t1, dt=args.dt, max_step=args.dt / 2, first_step=1e-6, atol=1e-5, rtol=1e-3, is_disturb=0,
         is_dyn_ctrl=0, dtype=args.dtype, device=args.device)
 
-    datafile = None
+    # ---- logger: presets/main_3wrobot.py:322-368 ------------------------------------------------------
+    my_logger = loggers.LOGGERS[name]()
+    in_presets_dir = os.path.basename(os.path.normpath(os.path.abspath(os.getcwd()))) == "presets"
+    data_folder = "../simdata" if in_presets_dir else "simdata"
+    datafiles = loggers.datafile_names(data_folder, my_sys.name, args.ctrl_mode, args.Nruns)
     if args.is_log_data:
-        folder = "simdata"
-        pathlib.Path(folder).mkdir(parents=True, exist_ok=True)
-        stamp = datetime.now().strftime("%Y-%m-%d_%Hh%Mm%Ss")
-        datafile = os.path.join(folder, f"{my_sys.name}__{args.ctrl_mode}__{stamp}.csv")
-        with open(datafile, "w", newline="") as f:
-            csv.writer(f).writerow(s["cols"])
+        pathlib.Path(data_folder).mkdir(parents=True, exist_ok=True)
+        settings = {k: getattr(args, k) for k in loggers.HEADER_KEYS if k != "state_init"}
+        settings["state_init"] = state_init_as_given
+        for f in datafiles:
+            print("Logging data to:    " + f)
+            loggers.write_header(f, my_sys.name, args.ctrl_mode, settings, my_logger.columns)
+    datafile = datafiles[0]
 
     action_manual = np.array(args.action_manual, dtype=float)
     run_curr, ticks = 1, 0
@@ -146,23 +146,25 @@ def run(name: str, argv=None):
         stage_obj = my_ctrl_benchm.stage_obj(observation, action)
         accum_obj = my_ctrl_benchm.accum_obj_val
         ticks += 1
-        row0 = lambda a: np.asarray(a).reshape(-1, np.asarray(a).shape[-1])[0] if np.ndim(a) else a
-        if args.is_print_sim_step and (ticks % max(1, int(round(0.5 / args.dt))) == 0 or t >= args.t1):
-            so = float(np.ravel(stage_obj)[0])
-            ao = float(np.ravel(accum_obj)[0])
-            print(f"t={t:8.3f}  state={np.array2string(row0(state_full), precision=4)}  "
-                  f"action={np.array2string(row0(action), precision=3)}  stage_obj={so:10.4f}  accum_obj={ao:10.3f}"
-                  + (f"  (env 0 of {args.batch})" if args.batch > 1 else ""))
-        if datafile:
-            with open(datafile, "a", newline="") as f:
-                csv.writer(f).writerow([t, *row0(state_full), float(np.ravel(stage_obj)[0]),
-                                        float(np.ravel(accum_obj)[0]), *np.ravel(row0(action))])
+        # env 0 is the logged env; cells are Python floats (csv writes their shortest round-trip repr)
+        first = lambda a: np.asarray(a, dtype=float).reshape(-1, np.asarray(a).shape[-1])[0] if np.ndim(a) else float(a)
+        x0, u0 = first(state_full), first(action)
+        so, ao = float(np.ravel(stage_obj)[0]), float(np.ravel(accum_obj)[0])
+        cells = (float(t), *map(float, x0), u0, so, ao) if name == "2tank" else \
+            (float(t), *map(float, x0), so, ao, u0)
+        if args.is_print_sim_step:
+            my_logger.print_sim_step(*cells)
+        if args.is_log_data:
+            my_logger.log_data_row(datafile, *cells)
         if t >= args.t1:
             if args.is_print_sim_step:
-                print(f".....................................Run {run_curr:2d} done.....................................")
+                print(".....................................Run {run:2d} done.....................................".format(
+                    run=run_curr))
             run_curr += 1
             if run_curr > args.Nruns:
                 break
+            if args.is_log_data:
+                datafile = datafiles[run_curr - 1]
             my_simulator.reset()
             my_ctrl_benchm.reset(t0)
     return dict(t=t, state=np.array(state_full), action=np.array(action), accum_obj=np.array(accum_obj), ticks=ticks)

@@ -220,6 +220,39 @@ def test_preset_scripts_run(name, argv, tmp_path, monkeypatch):
     assert out["ticks"] == int(round(t1 / dt)) and abs(out["t"] - t1) < 1e-9
     assert np.all(np.isfinite(out["state"])) and np.all(np.isfinite(out["accum_obj"]))
     logs = list((tmp_path / "simdata").glob("*.csv"))
-    assert len(logs) == 1 and len(open(logs[0]).read().splitlines()) == out["ticks"] + 1
+    # reference log layout (presets/main_3wrobot.py:340-362): 20 header rows, the column row, one row per sim step
+    assert len(logs) == 1 and len(open(logs[0]).read().splitlines()) == out["ticks"] + 21
+    from rcognita_amd import loggers
+
+    header, cols, data = loggers.read_log(str(logs[0]))
+    assert header["System"] == name and cols == list(loggers.LOGGERS[name].columns)
+    assert data.shape == (out["ticks"], len(cols)) and abs(data[-1, 0] - t1) < 1e-9
+    row_state = np.asarray(out["state"], dtype=float).reshape(-1, SPEC[name]["dim_state"])[0]
+    np.testing.assert_array_equal(data[-1, 1:1 + SPEC[name]["dim_state"]], row_state)  # env 0, repr round trip
     if "manual" in argv:
         np.testing.assert_allclose(out["action"], [0.7])
+
+
+def test_preset_log_header_equals_reference_header(tmp_path, monkeypatch, capsys):
+    """The file a preset run writes starts with the same 21 rows, byte for byte, as the reference preset's file for
+    the same flags (tests/golden/F9_logs_3wrobotNI.json); two runs give two files (the reference dies before run 2)."""
+    import json
+    import os
+
+    from rcognita_amd.presets import run
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "F9_logs_3wrobotNI.json")) as f:
+        fx = json.load(f)
+    monkeypatch.chdir(tmp_path)
+    run("3wrobotNI", fx["argv"] + ["--n_candidates", "64", "--rounds", "1"])
+    logs = sorted((tmp_path / "simdata").glob("*.csv"))
+    assert [p.name[-9:] for p in logs] == ["run01.csv", "run02.csv"]
+    ref = fx["csv_texts"][0].split("\r\n")[:21]
+    for p in logs:
+        lines = p.read_bytes().decode().split("\r\n")
+        assert lines[:21] == ref
+        assert len(lines) == 21 + 6 + 1  # t1 = 0.06, dt = 0.01: six fixed steps per run (+ trailing newline)
+    printed = capsys.readouterr().out
+    assert printed.count("Logging data to:    simdata/3wrobotNI__MPC__") == 2
+    assert ".....................................Run  2 done....................................." in printed
+    assert printed.count("|    t [s] |") == 12  # one tabulate grid per sim step
