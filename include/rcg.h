@@ -218,6 +218,18 @@ int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
  * ACCUM, STEP_IDX.  warm_start != 0: start from the previous tick's optimum shifted by one step (the reference
  * always restarts from action_sqn_init: warm_start = 0). */
 int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start);
+/* Nominal (benchmark / safe-fallback) controllers for n points, replacing CtrlNominal3WRobot.compute_action_vanila /
+ * compute_action / compute_LF (rcognita/controllers.py:1495-1755) and CtrlNominal3WRobotNI's
+ * (controllers.py:1757-1956); the handle's system selects which.  obs: device [ds][n]; action (may be NULL): device
+ * [du][n]; lyap (may be NULL): device [n], the Lyapunov function value of compute_LF.  ctrl_pars: host (m, I) of the
+ * 3wrobot controller's constructor, NULL = the handle's pars; ignored for 3wrobotNI.  clip != 0: clip to ctrl_bnds as
+ * compute_action does.  theta* of the 3wrobot controller (SciPy trust-constr in the reference) is build-defined:
+ * 64-point scan + golden section.  Sys2Tank has no nominal controller: RCG_ERR_UNSUPPORTED. */
+int rcg_nominal_action(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double ctrl_gain,
+                       const double* ctrl_pars, int32_t clip);
+/* One control tick under the nominal controller ('--ctrl_mode nominal', presets/main_3wrobot.py:425 through
+ * ctrl_selector, controllers.py:58-59): sim_step -> ACTION := clipped nominal action of STATE -> ACCUM, STEP_IDX. */
+int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl_pars);
 /* RQL/SQL bookkeeping of CtrlOptPred.compute_action (controllers.py:1458-1477): push (ACTION, obs)
  * into the buffers and, if do_fit != 0, refit W_CRITIC by bounded least squares on the TD stack of
  * _critic_cost (replacement of _critic_optimizer, controllers.py:1248-1271); W_PREV := W_CRITIC. */

@@ -41,7 +41,8 @@ SYMBOLS = [
     "rcg_synchronize", "rcg_dev_alloc", "rcg_dev_free", "rcg_memcpy_h2d", "rcg_memcpy_d2h", "rcg_set_field",
     "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
-    "rcg_critic_update", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
+    "rcg_critic_update", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
+    "rcg_control_tick_nominal", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 
@@ -114,6 +115,8 @@ def lib():
         "rcg_critic_update": (C.c_int, [vp, i32]),
         "rcg_actor_optimize": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
+        "rcg_nominal_action": (C.c_int, [vp, vp, vp, vp, i32, C.c_double, C.POINTER(C.c_double), i32]),
+        "rcg_control_tick_nominal": (C.c_int, [vp, C.c_double, C.POINTER(C.c_double)]),
         "rcg_episode_reset": (C.c_int, [vp]),
         "rcg_episode_stats": (C.c_int, [vp, i32, vp, C.POINTER(RcgSummary)]),
         "rcg_profile": (C.c_int, [vp, i32]),

@@ -301,3 +301,83 @@ class CtrlOptPred:
             self.action_curr = action
             return action
         return self.action_curr
+
+
+class _CtrlNominal:
+    """Shared plumbing of the two nominal controllers (rcognita/controllers.py:1495-1956): sampled like the reference
+    (``compute_action`` holds ``action_curr`` between samples), arithmetic in ``rcg_nominal_action``.  ``observation``
+    may carry a leading batch axis; the device handle is created on first use for that batch size."""
+    _sys_id = None
+    _dy = 0
+
+    def _init(self, ctrl_gain, ctrl_bnds, t0, sampling_time, pars, dtype, device):
+        self.ctrl_gain = ctrl_gain
+        self.ctrl_bnds = np.asarray(ctrl_bnds, dtype=float) if len(ctrl_bnds) else np.zeros((2, 2))
+        self.ctrl_clock = t0
+        self.sampling_time = sampling_time
+        self.action_curr = np.zeros(2)
+        self._pars, self._dtype, self._device = pars, dtype, device
+        self._eng = None
+
+    def _engine(self, n):
+        if self._eng is None or self._eng.B != n:
+            if self._eng is not None:
+                self._eng.close()
+            self._eng = Engine(EngineConfig(sys_id=self._sys_id, batch=n, dtype=self._dtype, device=self._device,
+                                            pars=self._pars, ctrl_bnds=self.ctrl_bnds if self.ctrl_bnds.any() else None))
+        return self._eng
+
+    def _run(self, observation, clip, want_lyap=False):
+        y = np.asarray(observation, dtype=float)
+        batched = y.ndim == 2
+        y2 = y.reshape(-1, self._dy)
+        out = self._engine(y2.shape[0]).nominal_action(y2, self.ctrl_gain, ctrl_pars=self._pars or None,
+                                                       clip=clip and bool(self.ctrl_bnds.any()), want_lyap=want_lyap)
+        a, L = out if want_lyap else (out, None)
+        a = a.astype(float)
+        if want_lyap:
+            L = L.astype(float)
+            return L if batched else float(L[0])
+        return a if batched else a[0]
+
+    def reset(self, t0):
+        """Resets controller for use in multi-episode simulation (controllers.py:1538-1544, 1771-1777)."""
+        self.ctrl_clock = t0
+        self.action_curr = np.zeros(2)
+
+    def compute_action(self, t, observation):
+        """Sampled, clipped action (controllers.py:1693-1731, 1906-1935)."""
+        time_in_sample = t - self.ctrl_clock
+        if time_in_sample >= self.sampling_time * (1 - 1e-9):  # new sample (same clock tolerance as CtrlOptPred)
+            self.ctrl_clock = t
+            self.action_curr = self._run(observation, clip=True)
+        return self.action_curr
+
+    def compute_action_vanila(self, observation):
+        """Same without the internal clock and without the clip (controllers.py:1733-1748, 1937-1947)."""
+        self.action_curr = self._run(observation, clip=False)
+        return self.action_curr
+
+    def compute_LF(self, observation):
+        """Lyapunov function value (controllers.py:1750-1755, 1949-1955)."""
+        return self._run(observation, clip=False, want_lyap=True)
+
+
+class CtrlNominal3WRobot(_CtrlNominal):
+    """Nominal controller of the 3-wheel robot with dynamic actuators, nonsmooth backstepping
+    (rcognita/controllers.py:1495-1755).  theta* (SciPy trust-constr in the reference) comes from the build-defined
+    scan + golden-section search of rcg_nominal.hpp."""
+    _sys_id, _dy = N.SYS_3WROBOT, 5
+
+    def __init__(self, m, I, ctrl_gain=10, ctrl_bnds=[], t0=0, sampling_time=0.1, dtype="f64", device=0):
+        self.m, self.I = m, I
+        self._init(ctrl_gain, ctrl_bnds, t0, sampling_time, [float(m), float(I)], dtype, device)
+
+
+class CtrlNominal3WRobotNI(_CtrlNominal):
+    """Nominal parking controller of the 3-wheel robot with static actuators, disassembled subgradients
+    (rcognita/controllers.py:1757-1956)."""
+    _sys_id, _dy = N.SYS_3WROBOT_NI, 3
+
+    def __init__(self, ctrl_gain=10, ctrl_bnds=[], t0=0, sampling_time=0.1, dtype="f64", device=0):
+        self._init(ctrl_gain, ctrl_bnds, t0, sampling_time, [], dtype, device)

@@ -456,6 +456,24 @@ int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start) {
                           h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true);
 }
 
+int rcg_nominal_action(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double ctrl_gain,
+                       const double* ctrl_pars, int32_t clip) {
+  if (!h || !obs || (!action && !lyap) || n < 1)
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_nominal_action: obs and one of action/lyap are required, n >= 1");
+  return h->sys->nominal(h, obs, action, lyap, n, ctrl_gain, ctrl_pars, clip, false);
+}
+
+int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl_pars) {
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (h->cfg.sys_id == RCG_SYS_2TANK)  // refuse before the env is stepped
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_nominal: the reference defines no nominal controller for 2tank");
+  int rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
+  if (rc) return rc;
+  h->tick_count += 1;
+  return h->sys->nominal(h, h->f[RCG_FIELD_STATE], h->f[RCG_FIELD_ACTION], nullptr, h->cfg.batch, ctrl_gain, ctrl_pars,
+                         1, true);
+}
+
 int rcg_episode_reset(rcg_handle* h) {
   if (!h) return RCG_ERR_BAD_ARG;
   const long B = h->cfg.batch;

@@ -113,5 +113,7 @@ struct SysVTable {
   int (*critic_update)(rcg_handle*, int32_t do_fit);
   int (*optimize)(rcg_handle*, int32_t iters, const void* obs, const void* state_sys, const void* u_init, int shift,
                   void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick);
+  int (*nominal)(rcg_handle*, const void* obs, void* action, void* lyap, int32_t n, double gain, const double* ctrl_pars,
+                 int32_t clip, bool tick);
 };
 extern const SysVTable kVt3WRobot, kVt3WRobotNI, kVt2Tank;

@@ -1,0 +1,228 @@
+// rcg_nominal.hpp - k_nominal: the reference's nominal (benchmark / fallback) controllers for a batch of envs,
+// lane == env.
+//
+//   CtrlNominal3WRobotNI  rcognita/controllers.py:1757-1956  closed form: disassembled subgradient of a CLF in
+//                         non-holonomic coordinates, kappa = -cbrt(zeta . g_k), action = gain * kappa mapped back
+//   CtrlNominal3WRobot    rcognita/controllers.py:1495-1755  nonsmooth backstepping on top of it; needs
+//                         theta* = argmin_theta Fc(xNI, eta, theta)
+//
+// The reference finds theta* with SciPy trust-constr from theta = 0 (controllers.py:1625-1634).  The build defines
+// it as: scan Fc at 64 points of its period, then 40 golden-section steps around the best one, midpoint wrapped to
+// [-pi, pi] - exactly oracle/nominal_oracle.py::theta_star, which is pinned against the reference's own outputs
+// (tests/golden/F10_nominal_*.npz).  Arithmetic follows the reference's expressions term by term (including the
+// 0 * zeta products of its np.dot, which matter only for inf/NaN propagation).  The law takes cube roots of sums
+// that cancel (it is not Lipschitz there), so it is always evaluated in float64, whatever the handle's dtype: an f32
+// handle returns the f64 law of its f32 states, rounded once.  Sys2Tank has no nominal controller in the reference:
+// unsupported.
+#pragma once
+#include "rcg_kernels.hpp"
+
+namespace rcg {
+
+constexpr int NOM_N_THETA = 64;
+constexpr int NOM_GOLD_ITERS = 40;
+
+template <typename real>
+__device__ __forceinline__ real sgn_r(real v) {
+  return (real)((v > (real)0) - (v < (real)0));  // np.sign: 0 at 0 (NaN -> 0 here, harmless: it multiplies a NaN)
+}
+__device__ __forceinline__ float cbrt_r(float v) { return ::cbrtf(v); }
+__device__ __forceinline__ double cbrt_r(double v) { return ::cbrt(v); }
+__device__ __forceinline__ float sqrt_r(float v) { return ::sqrtf(v); }
+__device__ __forceinline__ double sqrt_r(double v) { return ::sqrt(v); }
+__device__ __forceinline__ float abs_r(float v) { return ::fabsf(v); }
+__device__ __forceinline__ double abs_r(double v) { return ::fabs(v); }
+
+// _Cart2NH (controllers.py:1636-1668, 1877-1893)
+template <typename real>
+__device__ __forceinline__ void nom_cart2nh(real xc, real yc, real al, real* xn, real* yc_ca_m_xc_sa) {
+  real s, c;
+  sincos_r<real>(al, &s, &c);
+  const real p = xc * c + yc * s, q = yc * c - xc * s;
+  xn[0] = al;
+  xn[1] = p;
+  xn[2] = -(real)2 * q - al * p;
+  *yc_ca_m_xc_sa = q;
+}
+
+// _kappa (controllers.py:1592-1608): kappa_k = -sign(d_k) |d_k|^(1/3), d = zeta . (1, 0, x2) / zeta . (0, 1, -x1)
+template <typename real>
+__device__ __forceinline__ void nom_kappa(const real* xn, const real* z, real* kap) {
+  const real d0 = z[0] * (real)1 + z[1] * (real)0 + z[2] * xn[1];
+  const real d1 = z[0] * (real)0 + z[1] * (real)1 + z[2] * (-xn[0]);
+  kap[0] = -cbrt_r(d0);
+  kap[1] = -cbrt_r(d1);
+}
+
+// _zeta(xNI, theta) (controllers.py:1551-1590) with sqrt|x3| and |x3|^3 precomputed
+template <typename real>
+__device__ __forceinline__ void nom_zeta_theta(const real* xn, real sq3, real a3, real ct, real st, real* z, real* sig_out) {
+  const real sig = xn[0] * ct + xn[1] * st + sq3;
+  const real sig3 = sig * sig * sig;
+  z[0] = (real)4 * xn[0] * xn[0] * xn[0] - (real)2 * a3 * ct / sig3;
+  z[1] = (real)4 * xn[1] * xn[1] * xn[1] - (real)2 * a3 * st / sig3;
+  z[2] = ((real)3 * xn[0] * ct + (real)3 * xn[1] * st + (real)2 * sq3) * (xn[2] * xn[2]) * sgn_r(xn[2]) / sig3;
+  *sig_out = sig;
+}
+
+// _Fc (controllers.py:1610-1623); non-finite -> +inf (a pole of sigma~ or 0/0)
+template <typename real>
+__device__ __forceinline__ real nom_Fc(const real* xn, const real* eta, real sq3, real a3, real x14x24, real theta) {
+  real st, ct, z[3], kap[2], sig;
+  sincos_r<real>(theta, &st, &ct);
+  nom_zeta_theta<real>(xn, sq3, a3, ct, st, z, &sig);
+  nom_kappa<real>(xn, z, kap);
+  const real e0 = eta[0] - kap[0], e1 = eta[1] - kap[1];
+  const real F = x14x24 + a3 / (sig * sig) + (real)0.5 * (e0 * e0 + e1 * e1);
+  return finite_r<real>(F) ? F : inf_r<real>();
+}
+
+template <typename Sys>
+struct Nominal {
+  static constexpr bool supported = false;
+  template <typename real>
+  __device__ static void act(const real*, real, real, real, real*, real*) {}
+};
+
+template <>
+struct Nominal<Sys3WRobotNI> {
+  static constexpr bool supported = true;
+  // compute_action_vanila (controllers.py:1937-1947) and compute_LF (:1949-1955)
+  template <typename real>
+  __device__ static void act(const real* x, real gain, real, real, real* u, real* L) {
+    real xn[3], q;
+    nom_cart2nh<real>(x[0], x[1], x[2], xn, &q);
+    const real r = sqrt_r(xn[0] * xn[0] + xn[1] * xn[1]);
+    const real ax3 = abs_r(xn[2]);
+    const real sq3 = sqrt_r(ax3), a3 = ax3 * ax3 * ax3;
+    const real sigma = r + sq3;
+    real z[3];
+    if (xn[0] == (real)0 && xn[1] == (real)0) {  // nablaF at theta = 0 (controllers.py:1816-1829)
+      real sig;
+      nom_zeta_theta<real>(xn, sq3, a3, (real)1, (real)0, z, &sig);
+    } else {  // analytic nablaL (controllers.py:1808-1812)
+      const real s3 = sigma * sigma * sigma, r3 = r * r * r;
+      const real w = a3 / s3 * (real)1 / r3 * (real)2;
+      z[0] = (real)4 * xn[0] * xn[0] * xn[0] + w * xn[0];
+      z[1] = (real)4 * xn[1] * xn[1] * xn[1] + w * xn[1];
+      z[2] = (real)3 * ax3 * ax3 * sgn_r(xn[2]) + a3 / s3 * (real)1 / sq3 * sgn_r(xn[2]);
+    }
+    real kap[2];
+    nom_kappa<real>(xn, z, kap);
+    const real n0 = gain * kap[0], n1 = gain * kap[1];
+    u[0] = n1 + (real)0.5 * n0 * (xn[2] + xn[0] * xn[1]);  // _NH2ctrl_Cart (controllers.py:1895-1904)
+    u[1] = n0;
+    *L = xn[0] * xn[0] * xn[0] * xn[0] + xn[1] * xn[1] * xn[1] * xn[1] + a3 / (sigma * sigma);
+  }
+};
+
+template <>
+struct Nominal<Sys3WRobot> {
+  static constexpr bool supported = true;
+  // compute_action_vanila (controllers.py:1733-1748) with the build's theta search; L = Fc(theta*) (compute_LF)
+  template <typename real>
+  __device__ static void act(const real* x, real gain, real m, real I, real* u, real* L) {
+    real xn[3], q, eta[2];
+    nom_cart2nh<real>(x[0], x[1], x[2], xn, &q);
+    eta[0] = x[4];
+    eta[1] = q * x[4] + x[3];
+    const real ax3 = abs_r(xn[2]);
+    const real sq3 = sqrt_r(ax3), a3 = ax3 * ax3 * ax3;
+    const real x14x24 = xn[0] * xn[0] * xn[0] * xn[0] + xn[1] * xn[1] * xn[1] * xn[1];
+    const real PI = (real)3.141592653589793238462643383279502884;
+    const real h = (real)2 * PI / (real)NOM_N_THETA;
+    real best = inf_r<real>();
+    int bj = 0;
+    for (int j = 0; j < NOM_N_THETA; ++j) {
+      const real f = nom_Fc<real>(xn, eta, sq3, a3, x14x24, -PI + (real)j * h);
+      if (f < best) {
+        best = f;
+        bj = j;
+      }
+    }
+    const real IPHI = (real)0.6180339887498949;
+    real a = -PI + (real)(bj - 1) * h, b = -PI + (real)(bj + 1) * h;
+    real t1 = b - IPHI * (b - a), t2 = a + IPHI * (b - a);
+    real f1 = nom_Fc<real>(xn, eta, sq3, a3, x14x24, t1), f2 = nom_Fc<real>(xn, eta, sq3, a3, x14x24, t2);
+    for (int it = 0; it < NOM_GOLD_ITERS; ++it) {
+      const bool left = f1 <= f2;
+      if (left) {
+        b = t2;
+        t2 = t1;
+        f2 = f1;
+        t1 = b - IPHI * (b - a);
+      } else {
+        a = t1;
+        t1 = t2;
+        f1 = f2;
+        t2 = a + IPHI * (b - a);
+      }
+      const real fn = nom_Fc<real>(xn, eta, sq3, a3, x14x24, left ? t1 : t2);
+      if (left)
+        f1 = fn;
+      else
+        f2 = fn;
+    }
+    real th = (real)0.5 * (a + b);
+    th = th > PI ? th - (real)2 * PI : (th < -PI ? th + (real)2 * PI : th);
+    real st, ct, z[3], kap[2], sig;
+    sincos_r<real>(th, &st, &ct);
+    nom_zeta_theta<real>(xn, sq3, a3, ct, st, z, &sig);
+    nom_kappa<real>(xn, z, kap);
+    const real e0 = eta[0] - kap[0], e1 = eta[1] - kap[1];
+    const real n0 = -gain * e0, n1 = -gain * e1;
+    // _NH2ctrl_Cart (controllers.py:1670-1691)
+    u[0] = m * (n1 + xn[1] * eta[0] * eta[0] + (real)0.5 * (xn[0] * xn[1] * n0 + n0 * xn[2]));
+    u[1] = I * n0;
+    *L = x14x24 + a3 / (sig * sig) + (real)0.5 * (e0 * e0 + e1 * e1);
+  }
+};
+
+template <typename real>
+struct NomArgs {
+  const real* obs;    // [ds][n]
+  real* action;       // [du][n] out (or nullptr)
+  real* lyap;         // [n] out: compute_LF (or nullptr)
+  real* accum;        // tick: accum += rho(obs, action) * sampling_time (or nullptr)
+  int32_t* step_idx;  // tick: += 1 (or nullptr)
+  long n;
+  double gain, m, I;
+  int clip;
+};
+
+template <typename Sys, typename real>
+__global__ __launch_bounds__(256) void k_nominal(const NomArgs<real> A, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n) return;
+  real x[DS], u[DU];
+  double xd[DS], ud[DU], L;
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    x[c] = A.obs[(long)c * A.n + i];
+    xd[c] = (double)x[c];
+  }
+  Nominal<Sys>::template act<double>(xd, A.gain, A.m, A.I, ud, &L);
+#pragma unroll
+  for (int c = 0; c < DU; ++c) {
+    // compute_action clips (controllers.py:1712-1714), compute_action_vanila does not
+    if (A.clip && P.clip) ud[c] = clamp_r<double>(ud[c], (double)P.lo[c], (double)P.hi[c]);
+    u[c] = (real)ud[c];
+  }
+  if (A.action) {
+#pragma unroll
+    for (int c = 0; c < DU; ++c) A.action[(long)c * A.n + i] = u[c];
+  }
+  if (A.lyap) A.lyap[i] = (real)L;
+  if (A.accum) {  // upd_accum_obj (controllers.py:1086-1093)
+    real chi[NCHI];
+    if (P.has_target)
+      make_chi<DS, DU, true, real>(P, x, u, chi);
+    else
+      make_chi<DS, DU, false, real>(P, x, u, chi);
+    A.accum[i] += stage_any<NCHI, real>(P, chi) * P.sampling_time;
+  }
+  if (A.step_idx) A.step_idx[i] += 1;
+}
+
+}  // namespace rcg

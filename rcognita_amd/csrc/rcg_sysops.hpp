@@ -10,6 +10,7 @@
 #include "rcg_actor_opt.hpp"
 #include "rcg_critic_fit.hpp"
 #include "rcg_handle.hpp"
+#include "rcg_nominal.hpp"
 
 namespace rcg {
 
@@ -326,13 +327,42 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
   });
 }
 
+// CtrlNominal3WRobot / CtrlNominal3WRobotNI for n points (tick: the handle's envs, with the tick epilogue)
+template <typename Sys>
+static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double gain,
+                      const double* ctrl_pars, int32_t clip, bool tick) {
+  if constexpr (!Nominal<Sys>::supported) {
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "nominal controller: the reference defines none for this system");
+  } else {
+    const rcg_cfg& c = h->cfg;
+    return by_dtype(h, [&](auto r) {
+      using real = decltype(r);
+      NomArgs<real> A;
+      A.obs = (const real*)obs;
+      A.action = (real*)action;
+      A.lyap = (real*)lyap;
+      A.accum = (tick && !(c.flags & RCG_FLAG_ACCUM_EVERY_SUBSTEP)) ? (real*)h->f[RCG_FIELD_ACCUM] : nullptr;
+      A.step_idx = tick ? (int32_t*)h->f[RCG_FIELD_STEP_IDX] : nullptr;
+      A.n = n;
+      A.gain = gain;
+      A.m = ctrl_pars ? ctrl_pars[0] : c.pars[0];
+      A.I = ctrl_pars ? ctrl_pars[1] : c.pars[1];
+      A.clip = clip;
+      ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+      hipLaunchKernelGGL((k_nominal<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, A, params<real>(h));
+      HIPCHK(h, hipGetLastError());
+      return (int)RCG_OK;
+    });
+  }
+}
+
 // Explicitly instantiated once per environment (rcg_sys_*.hip): pulls in every launcher above and,
 // through their launch expressions, every kernel.
 template <typename Sys>
 struct SysInstances {
   static SysVTable table() {
-    return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,       &op_critic_cost<Sys>,
-                     &op_actor<Sys>, &op_sim_step<Sys>,  &op_critic_update<Sys>, &op_optimize<Sys>};
+    return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,        &op_critic_cost<Sys>, &op_actor<Sys>,
+                     &op_sim_step<Sys>, &op_critic_update<Sys>, &op_optimize<Sys>, &op_nominal<Sys>};
   }
 };
 

@@ -391,6 +391,31 @@ class Engine:
         """One env.control-step with the on-device optimiser as the decision (rcg_control_tick_opt)."""
         N.check(N.lib().rcg_control_tick_opt(self._h, int(iters), 1 if warm_start else 0), self._h)
 
+    @staticmethod
+    def _ctrl_pars(ctrl_pars):
+        if ctrl_pars is None:
+            return None
+        m, I = (float(v) for v in ctrl_pars)
+        return (C.c_double * 2)(m, I)
+
+    def nominal_action(self, obs, ctrl_gain, ctrl_pars=None, clip=False, want_lyap=False):
+        """Nominal controller of the handle's system on ``obs [n, dy]`` (rcg_nominal_action): returns ``action [n, du]``
+        (and the Lyapunov value ``[n]`` with ``want_lyap``).  ``clip`` = the clip of ``compute_action``."""
+        obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)
+        n = obs.shape[0]
+        keep = []
+        act = self.empty((self.du, n))
+        lyap = self.empty((n,)) if want_lyap else None
+        N.check(N.lib().rcg_nominal_action(self._h, self._in(obs, keep, lambda a: a.T), C.c_void_p(act.ptr),
+                                           C.c_void_p(lyap.ptr) if want_lyap else None, n, float(ctrl_gain),
+                                           self._ctrl_pars(ctrl_pars), 1 if clip else 0), self._h)
+        a = act.to_host().T.copy()
+        return (a, lyap.to_host()) if want_lyap else a
+
+    def control_tick_nominal(self, ctrl_gain, ctrl_pars=None):
+        """One env.control-step with the nominal controller as the decision (rcg_control_tick_nominal)."""
+        N.check(N.lib().rcg_control_tick_nominal(self._h, float(ctrl_gain), self._ctrl_pars(ctrl_pars)), self._h)
+
     def critic_update(self, do_fit=True):
         N.check(N.lib().rcg_critic_update(self._h, 1 if do_fit else 0), self._h)
 

@@ -5,7 +5,7 @@ main_3wrobot_NI.py, main_2tank.py), build the objects in the same order with the
 (presets/main_3wrobot.py:218-320) and run the reference's headless loop (presets/main_3wrobot.py:415-468)
 against ``rcognita_amd``, including its console / CSV log contract (``rcognita_amd/loggers.py``; with ``--batch > 1``
 env 0 is what gets printed and logged).  Out of scope here, as in SURVEY.md 2: visualisation (``--is_visualization``
-is accepted and ignored, the loop is always headless), the nominal and JACS controllers, model estimation.
+is accepted and ignored, the loop is always headless), the JACS controller, model estimation.
 Added flags: ``--batch`` (run B perturbed copies of the env through the same objects), ``--n_candidates``,
 ``--rounds``, ``--dtype``, ``--device``, ``--seed``.
 """
@@ -81,9 +81,9 @@ def run(name: str, argv=None):
     final time, state, action and accumulated objective (per env when ``--batch > 1``)."""
     s = SPEC[name]
     args = build_parser(name).parse_args(argv)
-    if args.ctrl_mode in ("nominal", "JACS"):
-        raise SystemExit(f"--ctrl_mode {args.ctrl_mode}: nominal / JACS controllers are out of scope of the native "
-                         "path (SURVEY.md 2, components 4-5); use manual, MPC, RQL or SQL")
+    if args.ctrl_mode == "JACS":
+        raise SystemExit("--ctrl_mode JACS: the stabilising RL controller is out of scope of the native path "
+                         "(SURVEY.md 2, component 5); use manual, nominal, MPC, RQL or SQL")
     if args.is_est_model:
         raise SystemExit("--is_est_model: model estimation needs the absent `sippy` package (out of scope)")
     state_init_as_given = np.array([eval(v.replace("pi", str(np.pi))) for v in args.state_init])  # header cell
@@ -105,7 +105,7 @@ def run(name: str, argv=None):
                       dim_disturb=s["dim_disturb"], pars=list(s["pars"]), ctrl_bnds=ctrl_bnds, is_dyn_ctrl=0,
                       is_disturb=0, pars_disturb=[], dtype=args.dtype, device=args.device)
     my_ctrl_benchm = controllers.CtrlOptPred(
-        dim_input, dim_state, args.ctrl_mode if args.ctrl_mode != "manual" else "MPC", ctrl_bnds=ctrl_bnds,
+        dim_input, dim_state, args.ctrl_mode if args.ctrl_mode not in ("manual", "nominal") else "MPC", ctrl_bnds=ctrl_bnds,
         action_init=s["action_init"], t0=t0, sampling_time=args.dt, Nactor=args.Nactor, pred_step_size=pred_step_size,
         sys_rhs=my_sys._state_dyn, sys_out=my_sys.out, state_sys=state_init, prob_noise_pow=args.prob_noise_pow,
         is_est_model=0, model_est_stage=args.model_est_stage, model_est_period=args.dt * args.model_est_period_multiplier,
@@ -114,6 +114,14 @@ def run(name: str, argv=None):
         stage_obj_struct=args.stage_obj_struct, stage_obj_pars=[R1, R2] if args.stage_obj_struct == "biquadratic" else [R1],
         observation_target=np.array(s["target"], dtype=float) if len(s["target"]) else [],
         n_candidates=args.n_candidates, rounds=args.rounds, seed=args.seed, dtype=args.dtype, device=args.device)
+    # nominal controller: presets/main_3wrobot.py:239 (gain 5), main_3wrobot_NI.py:235 (gain 0.5); 2tank has none
+    my_ctrl_nominal = None
+    if name == "3wrobot":
+        my_ctrl_nominal = controllers.CtrlNominal3WRobot(s["pars"][0], s["pars"][1], ctrl_gain=5, ctrl_bnds=ctrl_bnds,
+                                                         t0=t0, sampling_time=args.dt, dtype=args.dtype, device=args.device)
+    elif name == "3wrobotNI":
+        my_ctrl_nominal = controllers.CtrlNominal3WRobotNI(ctrl_gain=0.5, ctrl_bnds=ctrl_bnds, t0=t0,
+                                                           sampling_time=args.dt, dtype=args.dtype, device=args.device)
     my_simulator = simulator.Simulator(
         sys_type="diff_eqn", closed_loop_rhs=my_sys.closed_loop_rhs, sys_out=my_sys.out, state_init=state_init,
         disturb_init=[], action_init=np.zeros(dim_input) if not len(s["action_init"]) else np.array(s["action_init"]),
@@ -139,7 +147,7 @@ def run(name: str, argv=None):
     while True:  # presets/main_3wrobot.py:417-468
         my_simulator.sim_step()
         t, state, observation, state_full = my_simulator.get_sim_step_data()
-        action = controllers.ctrl_selector(t, observation, action_manual, None, my_ctrl_benchm, args.ctrl_mode)
+        action = controllers.ctrl_selector(t, observation, action_manual, my_ctrl_nominal, my_ctrl_benchm, args.ctrl_mode)
         my_sys.receive_action(action)
         my_ctrl_benchm.receive_sys_state(my_sys._state)
         my_ctrl_benchm.upd_accum_obj(observation, action)
@@ -166,5 +174,8 @@ def run(name: str, argv=None):
             if args.is_log_data:
                 datafile = datafiles[run_curr - 1]
             my_simulator.reset()
-            my_ctrl_benchm.reset(t0)
+            if args.ctrl_mode != "nominal":  # presets/main_3wrobot.py:463-466
+                my_ctrl_benchm.reset(t0)
+            else:
+                my_ctrl_nominal.reset(t0)
     return dict(t=t, state=np.array(state_full), action=np.array(action), accum_obj=np.array(accum_obj), ticks=ticks)

@@ -208,6 +208,8 @@ def test_batched_dropin_matches_single_env_objects():
     ("3wrobotNI", ["--ctrl_mode", "MPC", "--t1", "0.2", "--batch", "5", "--n_candidates", "64", "--rounds", "2"]),
     ("2tank", ["--ctrl_mode", "RQL", "--t1", "2.0", "--critic_struct", "quadratic", "--n_candidates", "64", "--rounds", "2"]),
     ("2tank", ["--ctrl_mode", "manual", "--t1", "1.0", "--action_manual", "0.7"]),
+    ("3wrobotNI", ["--ctrl_mode", "nominal", "--t1", "0.5"]),
+    ("3wrobot", ["--ctrl_mode", "nominal", "--t1", "0.3", "--batch", "3"]),
 ])
 def test_preset_scripts_run(name, argv, tmp_path, monkeypatch):
     """presets/main_*.py with the reference's flags (shared implementation rcognita_amd.presets.run)."""
