@@ -70,6 +70,7 @@ typedef enum rcg_where { RCG_HOST = 0, RCG_DEVICE = 1 } rcg_where;
                                             (reference loop order, presets/main_3wrobot.py:425-428)    */
 #define RCG_FLAG_ACCUM_EVERY_SUBSTEP 0x8 /* upd_accum_obj every sim step (controllers.py:1093 quirk)    */
 #define RCG_FLAG_NO_CLIP 0x10            /* ctrl_bnds all zero <=> unconstrained (systems.py:241)       */
+#define RCG_FLAG_DISTURB 0x20            /* System(is_disturb=1): full state [state, disturb] (systems.py:140-145) */
 
 /* per-env tensors owned by the handle (rcg_set_field / rcg_get_field) */
 typedef enum rcg_field {
@@ -90,7 +91,9 @@ typedef enum rcg_field {
   RCG_FIELD_ACT_BUF = 14,    /* [buffer_size][du][B] real                                         */
   RCG_FIELD_RETURNS = 15,    /* [B]      real    accum_obj of the last finished episode           */
   RCG_FIELD_ACTION_SQN = 16, /* [B][N][du] real  last optimised action sequence, one row per env  */
-  RCG_FIELD_COUNT_ = 17
+  RCG_FIELD_DISTURB = 17,    /* [dd][B] real  disturbance part of the full state (RCG_FLAG_DISTURB); dd = 2, 2, 1 */
+  RCG_FIELD_SUBSTEP_IDX = 18, /* [B] int32  simulation substeps since the episode began: noise counter word 3  */
+  RCG_FIELD_COUNT_ = 19
 } rcg_field;
 
 /* Plain-old-data configuration.  All reals are double here and are converted to the handle's
@@ -124,6 +127,14 @@ typedef struct rcg_cfg {
   double w_init[40];        /* w_critic_init (controllers.py:1041-1042: ones)                     */
   double w_min[40];         /* Wmin / Wmax (controllers.py:1026-1039)                             */
   double w_max[40];
+  /* Disturbance model (RCG_FLAG_DISTURB), System.pars_disturb = [sigma, mu, tau] (systems.py:303-306, 337):
+   * dq_k/dt = -tau_k (q_k + sigma_k (xi_k + mu_k)) (systems.py:343), xi ~ N(0,1) drawn once per RK4 substep from
+   * Philox4x32-10 with counter (env id lo, env id hi, EPISODE_IDX, SUBSTEP_IDX) and key (seed lo, seed hi), env id =
+   * env_id_base + index in this handle, so a shard reproduces exactly its slice of the unsharded run. */
+  double pars_disturb[6];  /* sigma[2], mu[2], tau[2] */
+  double disturb_init[2];  /* Simulator(disturb_init=...) (simulator.py:131-134) */
+  uint64_t seed;
+  int64_t env_id_base;
 } rcg_cfg;
 
 /* Per-shard summary of episode returns: what ranks exchange. */
@@ -177,6 +188,16 @@ int rcg_field_ptr(rcg_handle* h, int field, void** dev_out);
  * RCG_FLAG_PER_ENV_PARS and n == B, the per-env parameters). */
 int rcg_rhs(rcg_handle* h, const void* state, const void* action, void* dstate, void* clipped_action,
             int32_t n, int32_t clip);
+/* System.closed_loop_rhs on the FULL state of a system with is_disturb = 1 (systems.py:213-253 with :308-345,
+ * :370-394, :412-426), for n points: state [ds][n], disturb [dd][n], action [du][n], xi [dd][n] = the value randn()
+ * returns for component k (the reference draws it inside the right-hand side; here it is an input) -> dstate [ds][n],
+ * ddisturb [dd][n]; clipped_action (may be NULL) [du][n].  Needs a handle created with RCG_FLAG_DISTURB. */
+int rcg_rhs_full(rcg_handle* h, const void* state, const void* disturb, const void* action, const void* xi,
+                 void* dstate, void* ddisturb, void* clipped_action, int32_t n, int32_t clip);
+/* The draw rcg_sim_step will use for each env of the handle at its current (EPISODE_IDX, SUBSTEP_IDX):
+ * bits_out (device, [4][B] uint32, may be NULL) the four Philox words, xi_out (device, [2][B] real, may be NULL) the
+ * two normals (Box-Muller on 24-bit uniforms of words 0 and 1).  Integer output is bit-exact by contract. */
+int rcg_disturb_noise(rcg_handle* h, void* bits_out, void* xi_out);
 /* CtrlOptPred.stage_obj (controllers.py:1063-1084): obs [dy][n], act [du][n] -> out [n]. */
 int rcg_stage_obj(rcg_handle* h, const void* obs, const void* act, void* out, int32_t n);
 /* CtrlOptPred._critic (controllers.py:1192-1214): w [dc][n] -> out [n]. */

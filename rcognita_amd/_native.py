@@ -23,10 +23,12 @@ CRITIC_QUAD_LIN, CRITIC_QUADRATIC, CRITIC_QUAD_NOMIX, CRITIC_QUAD_MIX = 0, 1, 2,
 F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 FLAG_HAS_TARGET, FLAG_PER_ENV_PARS, FLAG_REF_LAG, FLAG_ACCUM_EVERY_SUBSTEP, FLAG_NO_CLIP = 1, 2, 4, 8, 16
+FLAG_DISTURB = 32
+DIM_DISTURB = {0: 2, 1: 2, 2: 1}  # sys_id -> dim_disturb (presets/main_*.py)
 
 (FIELD_STATE, FIELD_ACTION, FIELD_ACCUM, FIELD_STEP_IDX, FIELD_EPISODE_IDX, FIELD_STATUS, FIELD_PARS,
  FIELD_STATE_INIT, FIELD_STATE_PREV, FIELD_BEST_J, FIELD_BEST_IDX, FIELD_W_CRITIC, FIELD_W_PREV, FIELD_OBS_BUF,
- FIELD_ACT_BUF, FIELD_RETURNS, FIELD_ACTION_SQN) = range(17)
+ FIELD_ACT_BUF, FIELD_RETURNS, FIELD_ACTION_SQN, FIELD_DISTURB, FIELD_SUBSTEP_IDX) = range(19)
 
 MODE_IDS = {"MPC": MODE_MPC, "RQL": MODE_RQL, "SQL": MODE_SQL}
 STAGE_IDS = {"quadratic": STAGE_QUADRATIC, "biquadratic": STAGE_BIQUADRATIC}
@@ -42,7 +44,7 @@ SYMBOLS = [
     "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
     "rcg_critic_update", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
-    "rcg_control_tick_nominal", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
+    "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 
@@ -59,6 +61,8 @@ class RcgCfg(C.Structure):
         ("pars", C.c_double * 8), ("ctrl_bnds", C.c_double * 4), ("R1", C.c_double * 49), ("R2", C.c_double * 49),
         ("target", C.c_double * 8), ("action_init", C.c_double * 4), ("w_init", C.c_double * 40),
         ("w_min", C.c_double * 40), ("w_max", C.c_double * 40),
+        ("pars_disturb", C.c_double * 6), ("disturb_init", C.c_double * 2), ("seed", C.c_uint64),
+        ("env_id_base", C.c_int64),
     ]
 
 
@@ -117,6 +121,8 @@ def lib():
         "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
         "rcg_nominal_action": (C.c_int, [vp, vp, vp, vp, i32, C.c_double, C.POINTER(C.c_double), i32]),
         "rcg_control_tick_nominal": (C.c_int, [vp, C.c_double, C.POINTER(C.c_double)]),
+        "rcg_rhs_full": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32]),
+        "rcg_disturb_noise": (C.c_int, [vp, vp, vp]),
         "rcg_episode_reset": (C.c_int, [vp]),
         "rcg_episode_stats": (C.c_int, [vp, i32, vp, C.POINTER(RcgSummary)]),
         "rcg_profile": (C.c_int, [vp, i32]),

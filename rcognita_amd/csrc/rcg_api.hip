@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "rcg_disturb.hpp"
 #include "rcg_handle.hpp"
 
 using namespace rcg;
@@ -224,6 +225,11 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->fbytes[RCG_FIELD_BEST_IDX] = B * 4;
   h->fbytes[RCG_FIELD_RETURNS] = B * e;
   h->fbytes[RCG_FIELD_ACTION_SQN] = (size_t)cfg->n_actor * du * B * e;
+  const int dd = cfg->sys_id == RCG_SYS_2TANK ? 1 : 2;  // dim_disturb of the presets (main_*.py dim_disturb)
+  if (cfg->flags & RCG_FLAG_DISTURB) {
+    h->fbytes[RCG_FIELD_DISTURB] = dd * B * e;
+    h->fbytes[RCG_FIELD_SUBSTEP_IDX] = B * 4;
+  }
   if (cfg->buffer_size > 0) {
     h->fbytes[RCG_FIELD_W_CRITIC] = h->dc * B * e;
     h->fbytes[RCG_FIELD_W_PREV] = h->dc * B * e;
@@ -257,6 +263,9 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
     if (rc == RCG_OK && crit) rc = fill_rows<float>(h, h->f[RCG_FIELD_W_CRITIC], h->dc, cfg->w_init);
     if (rc == RCG_OK && crit) rc = fill_rows<float>(h, h->f[RCG_FIELD_W_PREV], h->dc, cfg->w_init);
   }
+  if (rc == RCG_OK && (cfg->flags & RCG_FLAG_DISTURB))
+    rc = cfg->dtype == RCG_F64 ? fill_rows<double>(h, h->f[RCG_FIELD_DISTURB], dd, cfg->disturb_init)
+                               : fill_rows<float>(h, h->f[RCG_FIELD_DISTURB], dd, cfg->disturb_init);
   if (rc != RCG_OK) {
     g_err = h->err;
     rcg_destroy(h);
@@ -371,6 +380,32 @@ int rcg_rhs(rcg_handle* h, const void* state, const void* action, void* dstate, 
             int32_t clip) {
   if (!h || !state || !action || !dstate || n < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_rhs: bad argument");
   return h->sys->rhs(h, state, action, dstate, clipped_action, n, clip);
+}
+
+int rcg_rhs_full(rcg_handle* h, const void* state, const void* disturb, const void* action, const void* xi, void* dstate,
+                 void* ddisturb, void* clipped_action, int32_t n, int32_t clip) {
+  if (!h || !state || !disturb || !action || !xi || !dstate || !ddisturb || n < 1)
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_rhs_full: bad argument");
+  if (!(h->cfg.flags & RCG_FLAG_DISTURB))
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_rhs_full: the handle was created without RCG_FLAG_DISTURB");
+  return h->sys->rhs_full(h, state, disturb, action, xi, dstate, ddisturb, clipped_action, n, clip);
+}
+
+int rcg_disturb_noise(rcg_handle* h, void* bits_out, void* xi_out) {
+  if (!h || (!bits_out && !xi_out)) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_disturb_noise: no output given");
+  if (!(h->cfg.flags & RCG_FLAG_DISTURB))
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_disturb_noise: the handle was created without RCG_FLAG_DISTURB");
+  const long B = h->cfg.batch;
+  const int32_t* ep = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
+  const int32_t* sub = (const int32_t*)h->f[RCG_FIELD_SUBSTEP_IDX];
+  if (h->cfg.dtype == RCG_F64)
+    hipLaunchKernelGGL((k_noise<double>), dim3(blocks_for(B)), dim3(256), 0, h->stream, ep, sub, (uint32_t*)bits_out,
+                       (double*)xi_out, B, (uint64_t)h->cfg.seed, (int64_t)h->cfg.env_id_base);
+  else
+    hipLaunchKernelGGL((k_noise<float>), dim3(blocks_for(B)), dim3(256), 0, h->stream, ep, sub, (uint32_t*)bits_out,
+                       (float*)xi_out, B, (uint64_t)h->cfg.seed, (int64_t)h->cfg.env_id_base);
+  HIPCHK(h, hipGetLastError());
+  return RCG_OK;
 }
 
 int rcg_stage_obj(rcg_handle* h, const void* obs, const void* act, void* out, int32_t n) {
@@ -493,6 +528,13 @@ int rcg_episode_reset(rcg_handle* h) {
                        (uint32_t*)h->f[RCG_FIELD_STATUS], h->ds, h->du, (float)h->cfg.action_init[0],
                        (float)h->cfg.action_init[1], B);
   HIPCHK(h, hipGetLastError());
+  if (h->cfg.flags & RCG_FLAG_DISTURB) {  // disturbance back to disturb_init, noise counter word 3 back to 0
+    const int dd = h->cfg.sys_id == RCG_SYS_2TANK ? 1 : 2;
+    const int rc = h->cfg.dtype == RCG_F64 ? fill_rows<double>(h, h->f[RCG_FIELD_DISTURB], dd, h->cfg.disturb_init)
+                                           : fill_rows<float>(h, h->f[RCG_FIELD_DISTURB], dd, h->cfg.disturb_init);
+    if (rc) return rc;
+    HIPCHK(h, hipMemsetAsync(h->f[RCG_FIELD_SUBSTEP_IDX], 0, h->fbytes[RCG_FIELD_SUBSTEP_IDX], h->stream));
+  }
   return RCG_OK;
 }
 

@@ -9,6 +9,7 @@
 #include "rcg_actor_dma.hpp"
 #include "rcg_actor_opt.hpp"
 #include "rcg_critic_fit.hpp"
+#include "rcg_disturb.hpp"
 #include "rcg_handle.hpp"
 #include "rcg_nominal.hpp"
 
@@ -28,6 +29,33 @@ static int op_rhs(rcg_handle* h, const void* state, const void* action, void* ds
     const real* pe = (h->f[RCG_FIELD_PARS] && n == h->cfg.batch) ? (const real*)h->f[RCG_FIELD_PARS] : nullptr;
     hipLaunchKernelGGL((k_rhs<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const real*)state,
                        (const real*)action, (real*)dstate, (real*)clipped, pe, (long)n, (int)clip, params<real>(h));
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+static inline DisturbPars disturb_pars(const rcg_handle* h) {
+  DisturbPars D;
+  for (int k = 0; k < 2; ++k) {
+    D.sigma[k] = h->cfg.pars_disturb[k];
+    D.mu[k] = h->cfg.pars_disturb[2 + k];
+    D.tau[k] = h->cfg.pars_disturb[4 + k];
+  }
+  D.seed = h->cfg.seed;
+  D.env_id_base = h->cfg.env_id_base;
+  return D;
+}
+
+// closed_loop_rhs on the full state [state, disturb], noise given (rcg_rhs_full)
+template <typename Sys>
+static int op_rhs_full(rcg_handle* h, const void* state, const void* disturb, const void* action, const void* xi,
+                       void* dstate, void* ddisturb, void* clipped, int32_t n, int32_t clip) {
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    const real* pe = (h->f[RCG_FIELD_PARS] && n == h->cfg.batch) ? (const real*)h->f[RCG_FIELD_PARS] : nullptr;
+    hipLaunchKernelGGL((k_rhs_full<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const real*)state,
+                       (const real*)disturb, (const real*)action, (const real*)xi, (real*)dstate, (real*)ddisturb,
+                       (real*)clipped, pe, (long)n, (int)clip, disturb_pars(h), params<real>(h));
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
@@ -81,6 +109,22 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
     A.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
     A.n_sub = n_substeps;
     ProfScope prof_scope(h, RCG_KERNEL_SIM);
+    if (h->cfg.flags & RCG_FLAG_DISTURB) {  // full state [state, disturb] (rcg_disturb.hpp)
+      SimDistArgs<real> D;
+      D.S = A;
+      D.disturb = (real*)h->f[RCG_FIELD_DISTURB];
+      D.substep_idx = (int32_t*)h->f[RCG_FIELD_SUBSTEP_IDX];
+      D.episode_idx = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
+      D.D = disturb_pars(h);
+      if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
+        hipLaunchKernelGGL((k_sim_dist<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, D,
+                           params<real>(h));
+      else
+        hipLaunchKernelGGL((k_sim_dist<Sys, real, false>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, D,
+                           params<real>(h));
+      HIPCHK(h, hipGetLastError());
+      return (int)RCG_OK;
+    }
     if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
       hipLaunchKernelGGL((k_sim<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, A,
                          params<real>(h));
@@ -362,7 +406,8 @@ template <typename Sys>
 struct SysInstances {
   static SysVTable table() {
     return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,        &op_critic_cost<Sys>, &op_actor<Sys>,
-                     &op_sim_step<Sys>, &op_critic_update<Sys>, &op_optimize<Sys>, &op_nominal<Sys>};
+                     &op_sim_step<Sys>, &op_critic_update<Sys>, &op_optimize<Sys>, &op_nominal<Sys>,
+                     &op_rhs_full<Sys>};
   }
 };
 

@@ -47,6 +47,12 @@ class EngineConfig:
     per_env_pars: bool = False
     ref_lag: bool = False
     accum_every_substep: bool = False
+    # disturbance model, System(is_disturb=1, pars_disturb=[sigma, mu, tau]) (systems.py:303-306, 337)
+    is_disturb: bool = False
+    pars_disturb: Optional[Sequence] = None  # [sigma, mu, tau], each of length dim_disturb
+    disturb_init: Optional[Sequence[float]] = None
+    seed: int = 0            # key of the counter-based noise generator
+    env_id_base: int = 0     # global id of this handle's env 0 (shards of one job share `seed`)
 
     def to_native(self) -> N.RcgCfg:
         ds, du, npar = N.SYS_DIMS[self.sys_id]
@@ -104,6 +110,23 @@ class EngineConfig:
             flags |= N.FLAG_REF_LAG
         if self.accum_every_substep:
             flags |= N.FLAG_ACCUM_EVERY_SUBSTEP
+        if self.is_disturb:
+            dd = N.DIM_DISTURB[int(self.sys_id)]
+            flags |= N.FLAG_DISTURB
+            if self.pars_disturb is None or len(self.pars_disturb) != 3:
+                raise ValueError("is_disturb needs pars_disturb = [sigma, mu, tau]")
+            for row, v in enumerate(self.pars_disturb):
+                v = np.asarray(v, dtype=np.float64).reshape(-1)
+                if len(v) < dd:
+                    raise ValueError(f"pars_disturb[{row}] needs {dd} entries, got {len(v)}")
+                for k in range(dd):
+                    c.pars_disturb[2 * row + k] = v[k]
+            if self.disturb_init is not None and len(self.disturb_init):
+                q0 = np.asarray(self.disturb_init, dtype=np.float64).reshape(-1)
+                for k in range(dd):
+                    c.disturb_init[k] = q0[k]
+            c.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
+            c.env_id_base = int(self.env_id_base)
         c.flags = flags
         return c
 
@@ -169,6 +192,7 @@ class Engine:
         self._h = None
         L = N.lib()
         self.ds, self.du, self.npar = N.SYS_DIMS[cfg.sys_id]
+        self.dd = N.DIM_DISTURB[int(cfg.sys_id)]
         self.dy = self.ds
         self.B = int(cfg.batch)
         self.N = int(cfg.Nactor)
@@ -230,10 +254,10 @@ class Engine:
         N.FIELD_STATE: "ds", N.FIELD_ACTION: "du", N.FIELD_ACCUM: None, N.FIELD_STEP_IDX: None,
         N.FIELD_EPISODE_IDX: None, N.FIELD_STATUS: None, N.FIELD_PARS: "npar", N.FIELD_STATE_INIT: "ds",
         N.FIELD_STATE_PREV: "ds", N.FIELD_BEST_J: None, N.FIELD_BEST_IDX: None, N.FIELD_W_CRITIC: "dc",
-        N.FIELD_W_PREV: "dc", N.FIELD_RETURNS: None,
+        N.FIELD_W_PREV: "dc", N.FIELD_RETURNS: None, N.FIELD_DISTURB: "dd", N.FIELD_SUBSTEP_IDX: None,
     }
     _FIELD_INT = {N.FIELD_STEP_IDX: np.int32, N.FIELD_EPISODE_IDX: np.int32, N.FIELD_BEST_IDX: np.int32,
-                  N.FIELD_STATUS: np.uint32}
+                  N.FIELD_STATUS: np.uint32, N.FIELD_SUBSTEP_IDX: np.int32}
 
     def _field_meta(self, f):
         """(device shape, dtype, host->device transform, device->host transform)."""
@@ -294,6 +318,27 @@ class Engine:
         d, ca = self.empty((self.ds, n)), self.empty((self.du, n))
         N.check(N.lib().rcg_rhs(self._h, ps, pa, C.c_void_p(d.ptr), C.c_void_p(ca.ptr), n, 1 if clip else 0), self._h)
         return d.to_host().T.copy(), ca.to_host().T.copy()
+
+    def rhs_full(self, state, disturb, action, xi, clip=True):
+        """``closed_loop_rhs`` on the full state of a system with ``is_disturb=1`` for ``n`` points, the noise value
+        ``xi [n, dd]`` given (rcg_rhs_full).  Returns ``(dstate [n, ds], ddisturb [n, dd], clipped_action [n, du])``."""
+        state = np.asarray(state, dtype=self.real).reshape(-1, self.ds)
+        disturb = np.asarray(disturb, dtype=self.real).reshape(-1, self.dd)
+        action = np.asarray(action, dtype=self.real).reshape(-1, self.du)
+        xi = np.asarray(xi, dtype=self.real).reshape(-1, self.dd)
+        n = state.shape[0]
+        keep = []
+        ptrs = [self._in(a, keep, lambda v: v.T) for a in (state, disturb, action, xi)]
+        d, dq, ca = self.empty((self.ds, n)), self.empty((self.dd, n)), self.empty((self.du, n))
+        N.check(N.lib().rcg_rhs_full(self._h, *ptrs, C.c_void_p(d.ptr), C.c_void_p(dq.ptr), C.c_void_p(ca.ptr), n,
+                                     1 if clip else 0), self._h)
+        return d.to_host().T.copy(), dq.to_host().T.copy(), ca.to_host().T.copy()
+
+    def disturb_noise(self):
+        """What the next ``sim_step`` substep will draw: ``(bits [B, 4] uint32, xi [B, 2])`` (rcg_disturb_noise)."""
+        bits, xi = self.empty((4, self.B), np.uint32), self.empty((2, self.B))
+        N.check(N.lib().rcg_disturb_noise(self._h, C.c_void_p(bits.ptr), C.c_void_p(xi.ptr)), self._h)
+        return bits.to_host().T.copy(), xi.to_host().T.copy()
 
     def stage_obj(self, obs, act):
         obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)

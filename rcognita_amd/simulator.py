@@ -25,8 +25,8 @@ class Simulator:
                  n_substeps=1, dtype="f64", device=0):
         if sys_type != "diff_eqn":
             raise NotImplementedError("only sys_type='diff_eqn' is on the native path (SURVEY.md 8a row 2)")
-        if is_disturb or is_dyn_ctrl:
-            raise NotImplementedError("is_disturb / is_dyn_ctrl are out of scope (SURVEY.md 8a rows 1, 8)")
+        if is_dyn_ctrl:
+            raise NotImplementedError("is_dyn_ctrl is out of scope (SURVEY.md 8a row 1)")
         sys_obj = getattr(closed_loop_rhs, "__self__", None)
         if not isinstance(sys_obj, System):
             raise TypeError(
@@ -47,17 +47,27 @@ class Simulator:
         self.B = x0.shape[0]
         spec = sys_obj.native_spec()
         a0 = np.zeros(sys_obj.dim_input) if len(action_init) == 0 else np.asarray(action_init, dtype=float)
+        self.is_disturb = bool(is_disturb)
+        if self.is_disturb != bool(sys_obj.is_disturb):
+            raise ValueError("Simulator(is_disturb=...) must agree with the System it integrates")
+        dist = dict(spec["disturb"])
+        if self.is_disturb:  # state_full_init = [state_init, disturb_init] (simulator.py:131-134)
+            self._q0 = np.zeros(sys_obj.dim_disturb) if len(disturb_init) == 0 else np.asarray(disturb_init, dtype=float)
+            dist.update(disturb_init=self._q0, env_id_base=0)
         self._eng = Engine(EngineConfig(sys_id=spec["sys_id"], batch=self.B, dtype=dtype, device=device,
                                         pars=spec["pars"], ctrl_bnds=spec["ctrl_bnds"],
                                         dt_sim=float(dt) / self.n_substeps, sampling_time=float(dt),
-                                        action_init=a0.reshape(-1)[: sys_obj.dim_input]))
+                                        action_init=a0.reshape(-1)[: sys_obj.dim_input], **dist))
         self._eng.set_state(x0)
+        if self.is_disturb:
+            state_init = np.concatenate([state_init, np.broadcast_to(self._q0, state_init.shape[:-1] + self._q0.shape)],
+                                        axis=-1)
         self.state_full_init = state_init.copy()
         self.step_idx = 0  # int: sim steps done in the current episode
         self.episode_idx = 0
         self.t = t0
         self.state_full = state_init.copy()
-        self.state = self.state_full
+        self.state = self.state_full[..., 0:self.dim_state]
         self.observation = self.sys_out(self.state)
 
     def _shape(self, a):
@@ -72,8 +82,10 @@ class Simulator:
         self.step_idx += 1
         self.t = self.t0 + self.step_idx * self.dt
         st = self._eng.get_state().astype(float)
+        if self.is_disturb:
+            st = np.concatenate([st, self._eng.get_field(N.FIELD_DISTURB).astype(float)], axis=-1)
         self.state_full = self._shape(st)
-        self.state = self.state_full
+        self.state = self.state_full[..., 0:self.dim_state]  # simulator.py:166
         self.observation = self.sys_out(self.state)
         # what System.closed_loop_rhs leaves behind in the reference: the clipped action and the
         # state of the last RHS evaluation (rcognita/systems.py:241-251)
@@ -98,5 +110,5 @@ class Simulator:
         self.episode_idx += 1
         self.t = self.t0
         self.state_full = self.state_full_init.copy()
-        self.state = self.state_full
+        self.state = self.state_full[..., 0:self.dim_state]
         self.observation = self.sys_out(self.state)

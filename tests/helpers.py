@@ -68,11 +68,16 @@ def engine_cfg(name, batch, dtype="f64", **kw):
 
 
 def both(name, batch, dtype="f64", **kw):
-    """(Engine, OracleCfg) built from the same keyword set (oracle naming)."""
+    """(Engine, OracleCfg) built from the same keyword set (oracle naming); ``engine_only`` = a dict of EngineConfig
+    fields the OracleCfg has no counterpart for (e.g. the disturbance model, which has its own oracle config)."""
     from rcognita_amd import Engine
 
+    eonly = kw.pop("engine_only", {})
     okw = {k: v for k, v in kw.items() if k not in ("per_env_pars", "action_init")}
-    return Engine(engine_cfg(name, batch, dtype, **kw)), oracle_cfg(name, **okw)
+    ec = engine_cfg(name, batch, dtype, **kw)
+    for k, v in eonly.items():
+        setattr(ec, k, v)
+    return Engine(ec), oracle_cfg(name, **okw)
 
 
 def rand_states(rng, name, n):

@@ -1,0 +1,196 @@
+"""Disturbance model on the GPU: RCG_FLAG_DISTURB handles against oracle/disturb_oracle.py and
+the reference's disturbed right-hand side (tests/golden/F11_disturb_*.npz)."""
+import numpy as np
+import pytest
+
+from oracle import disturb_oracle as DO
+from oracle import rcg_oracle as O
+from tests.conftest import load_golden
+from tests.helpers import PRESETS, SYSTEMS, both, rand_states, rel_err_norm
+
+pytestmark = pytest.mark.gpu
+
+SIGMA, MU, TAU = [2.0, 1.0], [0.5, -0.25], [1.5, 0.7]
+
+
+def _pair(name, B, dtype, seed=11, env_id_base=0, disturb_init=None, **kw):
+    eng, cfg = both(name, B, dtype, engine_only=dict(is_disturb=True, pars_disturb=[SIGMA, MU, TAU], seed=seed,
+                                                    env_id_base=env_id_base, disturb_init=disturb_init), **kw)
+    return eng, cfg, DO.DisturbCfg(SIGMA, MU, TAU, seed=seed, env_id_base=env_id_base, disturb_init=disturb_init)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_noise_bits_are_bit_exact_and_normals_match(dtype):
+    from rcognita_amd import _native as N
+
+    B, base = 777, (1 << 33) + 12345  # env ids beyond 32 bits reach counter word 1
+    eng, cfg, dcfg = _pair("3wrobotNI", B, dtype, seed=0xDEADBEEFCAFE, env_id_base=base)
+    ids = base + np.arange(B, dtype=np.int64)
+    ep = np.arange(B, dtype=np.int32) % 5
+    sub = (np.arange(B, dtype=np.int32) * 7) % 1000
+    eng.set_field(N.FIELD_EPISODE_IDX, ep)
+    eng.set_field(N.FIELD_SUBSTEP_IDX, sub)
+    bits, xi = eng.disturb_noise()
+    ref_bits = DO.noise_bits(dcfg.seed, ids, ep, sub)
+    np.testing.assert_array_equal(bits, ref_bits)
+    ref_xi = DO.normals_from_bits(ref_bits)
+    np.testing.assert_allclose(xi, ref_xi, rtol=1e-12 if dtype == "f64" else 2e-7, atol=1e-14 if dtype == "f64" else 1e-7)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_F11_rhs_full_matches_reference(name, dtype):
+    """closed_loop_rhs on [state, disturb] with the reference's own noise values: HIP == reference."""
+    meta, z = load_golden(f"F11_disturb_{name}")
+    n = z["state"].shape[0]
+    eng, _ = both(name, n, dtype, engine_only=dict(is_disturb=True, pars_disturb=[z["sigma"], z["mu"], z["tau"]]))
+    dx, dq, a = eng.rhs_full(z["state"], z["disturb"], z["action"], z["xi"], clip=True)
+    ds = z["state"].shape[1]
+    tol = 1e-12 if dtype == "f64" else 1e-5
+    assert rel_err_norm(dx, z["rhs_full"][:, :ds]) < tol
+    assert rel_err_norm(dq, z["rhs_full"][:, ds:], floor=1.0) < tol
+    np.testing.assert_allclose(a, z["action_clipped"], rtol=1e-7 if dtype == "f32" else 0)
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_sim_step_with_disturbance_vs_oracle(name):
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(3)
+    B, T, S = 41, 9, 2
+    eng, cfg, dcfg = _pair(name, B, "f64", seed=5, env_id_base=1000, disturb_init=[0.3, -0.2])
+    x0 = rand_states(rng, name, B)
+    eng.set_state(x0)
+    env = O.new_batch(cfg, x0)
+    DO.attach(cfg, env, dcfg)
+    for t in range(T):
+        u = rng.uniform(-1, 1, (B, cfg.du)) * np.abs(cfg.ctrl_bnds[:, 1]) * 1.3  # some beyond the bounds: clipped
+        eng.set_field(N.FIELD_ACTION, u)
+        env.action = u
+        eng.sim_step(S)
+        DO.sim_substeps(cfg, env, dcfg, S)
+        assert rel_err_norm(eng.get_state(), env.state) < 1e-10, t
+        assert rel_err_norm(eng.get_field(N.FIELD_DISTURB), env.disturb, floor=1.0) < 1e-10, t
+        np.testing.assert_array_equal(eng.get_field(N.FIELD_SUBSTEP_IDX), env.substep_idx)
+    if name == "2tank":  # inert in the reference: q never moves, the state is the undisturbed one
+        np.testing.assert_array_equal(eng.get_field(N.FIELD_DISTURB), np.full((B, 1), 0.3))
+    else:
+        assert np.std(eng.get_field(N.FIELD_DISTURB)) > 0.05
+
+
+def test_shards_reproduce_their_slice_of_the_unsharded_run():
+    """Counter-based noise: two handles of 32 envs with env_id_base 0 / 32 == one handle of 64, bit for bit (f32)."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(8)
+    x0 = rand_states(rng, "3wrobot", 64)
+    full, _, _ = _pair("3wrobot", 64, "f32", seed=99)
+    lo, _, _ = _pair("3wrobot", 32, "f32", seed=99, env_id_base=0)
+    hi, _, _ = _pair("3wrobot", 32, "f32", seed=99, env_id_base=32)
+    for e, xs in ((full, x0), (lo, x0[:32]), (hi, x0[32:])):
+        e.set_state(xs)
+        for _ in range(20):
+            e.control_tick(None, K=64)
+    np.testing.assert_array_equal(full.get_state(), np.concatenate([lo.get_state(), hi.get_state()]))
+    np.testing.assert_array_equal(full.get_field(N.FIELD_DISTURB),
+                                  np.concatenate([lo.get_field(N.FIELD_DISTURB), hi.get_field(N.FIELD_DISTURB)]))
+    other, _, _ = _pair("3wrobot", 32, "f32", seed=100)
+    other.set_state(x0[:32])
+    for _ in range(20):
+        other.control_tick(None, K=64)
+    assert not np.array_equal(other.get_field(N.FIELD_DISTURB), lo.get_field(N.FIELD_DISTURB))
+
+
+def test_episode_reset_restores_disturbance_and_advances_the_stream():
+    from rcognita_amd import _native as N
+
+    B = 50
+    eng, cfg, dcfg = _pair("3wrobotNI", B, "f64", seed=2, disturb_init=[0.1, 0.2])
+    x0 = rand_states(np.random.default_rng(1), "3wrobotNI", B)
+    eng.set_state(x0)
+    for _ in range(5):
+        eng.sim_step(1)
+    q_ep0 = eng.get_field(N.FIELD_DISTURB).copy()
+    eng.episode_reset()
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_DISTURB), np.tile([0.1, 0.2], (B, 1)))
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_SUBSTEP_IDX), np.zeros(B, np.int32))
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_EPISODE_IDX), np.ones(B, np.int32))
+    for _ in range(5):
+        eng.sim_step(1)
+    q_ep1 = eng.get_field(N.FIELD_DISTURB)
+    assert not np.array_equal(q_ep0, q_ep1)  # episode index is part of the counter
+    # and it is exactly the oracle's episode-1 stream
+    env = O.new_batch(cfg, x0)
+    DO.attach(cfg, env, dcfg)
+    env.episode_idx = np.ones(B, np.int32)
+    DO.sim_substeps(cfg, env, dcfg, 5)
+    assert rel_err_norm(q_ep1, env.disturb, floor=1.0) < 1e-10
+
+
+def test_disturbed_closed_loop_at_bench_size():
+    """BASELINE configs[1] batch with actuator disturbance under MPC (generated candidates): nothing fails, the
+    disturbance settles at its stationary mean -sigma*mu (systems.py:343), counters exact."""
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import preset_engine_config
+
+    B, T = 65536, 400
+    ec = preset_engine_config("3wrobot", B, Nactor=10)
+    ec.is_disturb, ec.pars_disturb, ec.seed = True, [SIGMA, MU, TAU], 4
+    ec.dt_sim, ec.sampling_time = 0.05, 0.05  # tau*dt = 0.075 / 0.035 per step: 400 steps are >> the time constant
+    eng = Engine(ec)
+    eng.set_state(rand_states(np.random.default_rng(0), "3wrobot", B))
+    for _ in range(T):
+        eng.control_tick(None, K=64)
+    q = eng.get_field(N.FIELD_DISTURB).astype(np.float64)
+    summ, _ = eng.episode_stats(from_accum=True)
+    assert summ["n_failed"] == 0
+    np.testing.assert_allclose(q.mean(axis=0), -np.array(SIGMA) * np.array(MU), atol=0.03)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_SUBSTEP_IDX), np.full(B, T, np.int32))
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
+
+
+def test_mirror_system_and_simulator_with_is_disturb():
+    """System(is_disturb=1, pars_disturb=[sigma, mu, tau]) / Simulator(is_disturb=1, disturb_init=...) with the
+    reference's constructor calls: full state [state, disturb] (systems.py:140-145, simulator.py:131-134)."""
+    from rcognita_amd import simulator, systems
+
+    meta, z = load_golden("F11_disturb_3wrobot")
+    p = PRESETS["3wrobot"]
+    bnds = np.array(p["bnds"], dtype=float)
+    my_sys = systems.Sys3WRobot(sys_type="diff_eqn", dim_state=5, dim_input=2, dim_output=5, dim_disturb=2,
+                                pars=[10, 1], ctrl_bnds=bnds, is_dyn_ctrl=0, is_disturb=1,
+                                pars_disturb=[z["sigma"], z["mu"], z["tau"]], seed=3)
+    assert my_sys._dim_full_state == 7
+    i = 17
+    # _state_dyn with the disturbance given == the reference's state rows; _disturb_dyn with xi given == its noise rows
+    my_sys.receive_action(z["action_clipped"][i])
+    np.testing.assert_allclose(my_sys._state_dyn(0, z["state"][i], z["action_clipped"][i], z["disturb"][i]),
+                               z["rhs_full"][i, :5], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(my_sys._disturb_dyn(0, z["disturb"][i], xi=z["xi"][i]), z["rhs_full"][i, 5:], rtol=1e-12)
+    full = np.concatenate([z["state"][i], z["disturb"][i]])
+    my_sys.receive_action(z["action"][i].copy())
+    r1 = my_sys.closed_loop_rhs(0.0, full)
+    assert r1.shape == (7,)
+    np.testing.assert_allclose(r1[:5], z["rhs_full"][i, :5], rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(my_sys.action, z["action_clipped"][i])
+    r2 = my_sys.closed_loop_rhs(0.0, full)
+    assert not np.array_equal(r1[5:], r2[5:])  # a fresh draw per call, as randn() in the reference
+    with pytest.raises(ValueError):
+        systems.Sys3WRobot(sys_type="diff_eqn", dim_state=5, dim_input=2, dim_output=5, dim_disturb=3, pars=[10, 1],
+                           ctrl_bnds=bnds, is_disturb=1, pars_disturb=[z["sigma"], z["mu"], z["tau"]])
+
+    x0 = np.array(p["x0"], dtype=float)
+    sim = simulator.Simulator(sys_type="diff_eqn", closed_loop_rhs=my_sys.closed_loop_rhs, sys_out=my_sys.out,
+                              state_init=x0, disturb_init=np.array([0.5, -0.5]), action_init=np.zeros(2), t0=0, t1=1.0,
+                              dt=0.01, max_step=0.005, first_step=1e-6, atol=1e-5, rtol=1e-3, is_disturb=1, is_dyn_ctrl=0)
+    np.testing.assert_array_equal(sim.state_full_init, np.concatenate([x0, [0.5, -0.5]]))
+    my_sys.receive_action(np.array([50.0, -20.0]))
+    for _ in range(3):
+        sim.sim_step()
+    t, state, obs, full = sim.get_sim_step_data()
+    assert abs(t - 0.03) < 1e-12 and state.shape == (5,) and full.shape == (7,) and obs.shape == (5,)
+    np.testing.assert_array_equal(full[:5], state)
+    assert not np.array_equal(full[5:], [0.5, -0.5])
+    with pytest.raises(ValueError):
+        simulator.Simulator(sys_type="diff_eqn", closed_loop_rhs=my_sys.closed_loop_rhs, sys_out=my_sys.out,
+                            state_init=x0, is_disturb=0)
