@@ -32,8 +32,8 @@ HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6.29e12 mea
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=500)
+    p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--batch", type=int, default=65536, help="envs per GPU (weak scaling)")
     p.add_argument("--candidates", type=int, default=256, help="K candidate sequences per env")
     p.add_argument("--nactor", type=int, default=10)

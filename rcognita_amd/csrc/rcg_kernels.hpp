@@ -18,6 +18,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/rcg.h"
 #include "rcg_systems.hpp"
 
@@ -62,12 +64,13 @@ __device__ __forceinline__ real stage_diag(const KParams<real>& P, const real* c
 
 // stage_obj, every structure (controllers.py:1076-1082):
 //   quadratic   chi @ R1 @ chi            biquadratic   chi**2 @ R2 @ chi**2 + chi @ R1 @ chi
+// `sk` = P.stage_kind, or a compile-time constant when the caller has already dispatched on it
 template <int NCHI, typename real>
-__device__ __forceinline__ real stage_any(const KParams<real>& P, const real* chi) {
+__device__ __forceinline__ real stage_with(const KParams<real>& P, const real* chi, const int sk) {
   real q;
-  if (!(P.stage_kind & STAGE_FULL)) {
+  if (!(sk & STAGE_FULL)) {
     q = stage_diag<NCHI, real>(P, chi);
-    if (P.stage_kind & STAGE_BIQUAD) {
+    if (sk & STAGE_BIQUAD) {
       real q4 = 0;
 #pragma unroll
       for (int i = 0; i < NCHI; ++i) {
@@ -85,7 +88,7 @@ __device__ __forceinline__ real stage_any(const KParams<real>& P, const real* ch
       for (int i = 0; i < NCHI; ++i) v = fma_r(chi[i], P.Rfull[i * NCHI + j], v);
       q = fma_r(v, chi[j], q);
     }
-    if (P.stage_kind & STAGE_BIQUAD) {
+    if (sk & STAGE_BIQUAD) {
       real c2[NCHI];
 #pragma unroll
       for (int i = 0; i < NCHI; ++i) c2[i] = chi[i] * chi[i];
@@ -102,15 +105,18 @@ __device__ __forceinline__ real stage_any(const KParams<real>& P, const real* ch
   }
   return q;
 }
+template <int NCHI, typename real>
+__device__ __forceinline__ real stage_any(const KParams<real>& P, const real* chi) {
+  return stage_with<NCHI, real>(P, chi, P.stage_kind);
+}
 
 // _critic = w @ regressor (controllers.py:1192-1214).  `w(i)` returns weight i of this lane's env.
 // chi already holds [obs - target, act]; quad-mix uses the RAW observation y (controllers.py:1212).
+// `cs` = P.critic_struct, or a compile-time constant when the caller has already dispatched on it.
 template <int DS, int DU, typename real, typename WGet>
-__device__ __forceinline__ real critic_value(const KParams<real>& P, const real* chi, const real* y,
-                                             const real* u, WGet w) {
+__device__ __forceinline__ real critic_with(const real* chi, const real* y, const real* u, WGet w, const int cs) {
   constexpr int NCHI = DS + DU;
   real acc = 0;
-  const int cs = P.critic_struct;
   if (cs == RCG_CRITIC_QUAD_LIN || cs == RCG_CRITIC_QUADRATIC) {
     int idx = 0;  // uptria2vec: row-major upper triangle incl. diagonal (utilities.py:81-96)
 #pragma unroll
@@ -135,6 +141,11 @@ __device__ __forceinline__ real critic_value(const KParams<real>& P, const real*
     for (int c = 0; c < DU; ++c) acc = fma_r(w(DS + DS * DU + c), u[c] * u[c], acc);
   }
   return acc;
+}
+template <int DS, int DU, typename real, typename WGet>
+__device__ __forceinline__ real critic_value(const KParams<real>& P, const real* chi, const real* y,
+                                             const real* u, WGet w) {
+  return critic_with<DS, DU, real>(chi, y, u, w, P.critic_struct);
 }
 
 template <typename Sys, typename real>
@@ -258,7 +269,16 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
   }
   const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
   const real h = P.h_pred;
-  auto wget = [&](int i) -> real { return A.w[(long)i * B + b]; };
+  // critic weights of this lane's env, once, into registers (they were re-read from memory at every use inside the
+  // horizon loop: the J store below may alias them, so the compiler cannot hoist the loads itself)
+  constexpr int DCMAX = GENERIC ? NCHI * (NCHI + 1) / 2 + NCHI : 1;
+  real wreg[DCMAX];
+  if (GENERIC) {
+    const bool has_w = P.mode != RCG_MODE_MPC && A.w != nullptr;
+#pragma unroll
+    for (int i = 0; i < DCMAX; ++i) wreg[i] = (has_w && i < P.dc) ? A.w[(long)i * B + b] : (real)0;
+  }
+  auto wget = [&](int i) -> real { return wreg[GENERIC ? i : 0]; };
 
   real bestJ = inf_r<real>();
   int bestI = 0x7fffffff;
@@ -299,48 +319,81 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
     const real* const urow = lds + (size_t)r * R;
 
     // ---- _actor_cost: explicit-Euler rollout + running cost (controllers.py:1284-1326) --------
-    real x[DS], y[DS];
+    // One body, several compile-time specialisations: `mode_c / sk_c / cs_c` are integral constants (-1 = read the
+    // runtime value).  The dispatch below runs once per tile, so the step loop carries no mode / stage-structure /
+    // critic-structure branches (they cost more than the ~14 VALU ops of a 2tank step).
+    real u0[DU];
+    auto rollout = [&](auto mode_c, auto sk_c, auto cs_c) -> real {
+      constexpr int MODE_C = decltype(mode_c)::value, SK_C = decltype(sk_c)::value, CS_C = decltype(cs_c)::value;
+      const int mode = MODE_C >= 0 ? MODE_C : P.mode;
+      const int sk = SK_C >= 0 ? SK_C : P.stage_kind;
+      const int cs = CS_C >= 0 ? CS_C : P.critic_struct;
+      real x[DS], y[DS];
 #pragma unroll
-    for (int c = 0; c < DS; ++c) {
-      x[c] = xs[c];
-      y[c] = y0[c];
-    }
-    real J = 0, gk = 1;
-    real u[DU], up[DU], u0[DU];
+      for (int c = 0; c < DS; ++c) {
+        x[c] = xs[c];
+        y[c] = y0[c];
+      }
+      real J = 0, gk = 1;
+      real u[DU], up[DU];
 #pragma unroll
-    for (int c = 0; c < DU; ++c) up[c] = 0;
-    for (int kk = 0; kk < N; ++kk) {
+      for (int c = 0; c < DU; ++c) up[c] = 0;
+      for (int kk = 0; kk < N; ++kk) {
 #pragma unroll
-      for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];
-      if (kk == 0) {
+        for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];
+        if (kk == 0) {
 #pragma unroll
-        for (int c = 0; c < DU; ++c) u0[c] = u[c];
-      } else {
-        real d[DS];
-        Sys::template rhs<real>(pre, x, up, d);  // unclipped, as sys_rhs([], state, u[k-1])
+          for (int c = 0; c < DU; ++c) u0[c] = u[c];
+        } else {
+          real d[DS];
+          Sys::template rhs<real>(pre, x, up, d);  // unclipped, as sys_rhs([], state, u[k-1])
 #pragma unroll
-        for (int c = 0; c < DS; ++c) {
-          x[c] = fma_r(h, d[c], x[c]);
-          y[c] = x[c];  // sys_out is the identity
+          for (int c = 0; c < DS; ++c) {
+            x[c] = fma_r(h, d[c], x[c]);
+            y[c] = x[c];  // sys_out is the identity
+          }
         }
-      }
-      real chi[NCHI];
-      make_chi<DS, DU, TGT, real>(P, y, u, chi);
-      if (!GENERIC) {  // MPC, quadratic, diagonal R1
-        J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
-      } else if (P.mode == RCG_MODE_MPC) {
-        J = fma_r(gk, stage_any<NCHI, real>(P, chi), J);
-      } else if (P.mode == RCG_MODE_RQL) {
-        if (kk < N - 1)
-          J = fma_r(gk, stage_any<NCHI, real>(P, chi), J);
-        else
-          J += critic_value<DS, DU, real>(P, chi, y, u, wget);
-      } else {  // SQL
-        J += critic_value<DS, DU, real>(P, chi, y, u, wget);
-      }
-      gk *= P.gamma;
+        real chi[NCHI];
+        make_chi<DS, DU, TGT, real>(P, y, u, chi);
+        if (mode == RCG_MODE_MPC) {
+          J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
+        } else if (mode == RCG_MODE_RQL) {
+          if (kk < N - 1)
+            J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
+          else
+            J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
+        } else {  // SQL
+          J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
+        }
+        gk *= P.gamma;
 #pragma unroll
-      for (int c = 0; c < DU; ++c) up[c] = u[c];
+        for (int c = 0; c < DU; ++c) up[c] = u[c];
+      }
+      return J;
+    };
+    using std::integral_constant;
+    typedef integral_constant<int, -1> rt;
+    real J;
+    if (!GENERIC) {  // MPC, quadratic, diagonal R1
+      J = rollout(integral_constant<int, RCG_MODE_MPC>{}, integral_constant<int, 0>{}, rt{});
+    } else if (P.mode == RCG_MODE_MPC) {
+      J = rollout(integral_constant<int, RCG_MODE_MPC>{}, rt{}, rt{});
+    } else if (P.mode == RCG_MODE_RQL && P.stage_kind == 0) {
+      switch (P.critic_struct) {
+        case RCG_CRITIC_QUAD_LIN: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUAD_LIN>{}); break;
+        case RCG_CRITIC_QUADRATIC: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUADRATIC>{}); break;
+        case RCG_CRITIC_QUAD_NOMIX: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUAD_NOMIX>{}); break;
+        default: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUAD_MIX>{}); break;
+      }
+    } else if (P.mode == RCG_MODE_SQL) {  // no stage cost inside the SQL sum
+      switch (P.critic_struct) {
+        case RCG_CRITIC_QUAD_LIN: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUAD_LIN>{}); break;
+        case RCG_CRITIC_QUADRATIC: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUADRATIC>{}); break;
+        case RCG_CRITIC_QUAD_NOMIX: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUAD_NOMIX>{}); break;
+        default: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUAD_MIX>{}); break;
+      }
+    } else {  // RQL with a full-matrix / biquadratic stage cost
+      J = rollout(rt{}, rt{}, rt{});
     }
 
     if (A.J && valid) A.J[b * K + k] = J;
