@@ -27,7 +27,11 @@
 
 namespace rcg {
 
-template <typename Sys, int R, bool TGT>
+// G1: gamma == 1 (the reference's default and every preset, main_3wrobot.py:147): the discounted sum of weighted
+// squares is accumulated per component, S_i += chi_i^2 (one fma per term and step instead of mul + fma + the
+// discount bookkeeping) and weighted once at the end, J = sum_i R1_ii S_i.  The rollout is VALU-issue-limited almost
+// as much as it is HBM-limited (about 30 VALU ops per step before, 14 of them the stage cost), so this matters.
+template <typename Sys, int R, bool TGT, bool G1>
 __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, const KParams<float> P) {
   typedef float real;
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
@@ -121,6 +125,9 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
 #pragma unroll
     for (int c = 0; c < DS; ++c) x[c] = y[c] = y0[c];  // state_sys == observation (see the launcher)
     real J = 0, gk = 1;
+    real S[NCHI];
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) S[i] = 0;
     if (A.dbg & 1) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
 #pragma unroll
       for (int i = 0; i < R; ++i) J += cur[i];
@@ -141,8 +148,17 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
         for (int c = 0; c < DS; ++c) chi[c] = TGT ? y[c] - P.target[c] : y[c];
 #pragma unroll
         for (int c = 0; c < DU; ++c) chi[DS + c] = cur[kk * DU + c];
-        J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
-        gk *= P.gamma;
+        if (G1) {
+#pragma unroll
+          for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
+        } else {
+          J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
+          gk *= P.gamma;
+        }
+      }
+      if (G1) {
+#pragma unroll
+        for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[i], J);
       }
     }
 

@@ -176,23 +176,27 @@ static int op_critic_update(rcg_handle* h, int32_t do_fit) {
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
 // Pick the k_actor_dma<Sys, R> instance for a runtime row length (R = N*du floats, 1..32, multiple of du).
 template <typename Sys, int R>
-static bool launch_dma_r(int r, bool tgt, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<float>& A,
-                         const KParams<float>& P) {
+static bool launch_dma_r(int r, bool tgt, bool g1, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                         const ActorArgs<float>& A, const KParams<float>& P) {
   if constexpr (R > 32) {
     return false;
   } else {
     if (r == R) {
       if constexpr (R % Sys::DU == 0) {
-        if (tgt)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, true>), grid, block, lds, s, A, P);
+        if (tgt && g1)
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, true>), grid, block, lds, s, A, P);
+        else if (tgt)
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, false>), grid, block, lds, s, A, P);
+        else if (g1)
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, true>), grid, block, lds, s, A, P);
         else
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, false>), grid, block, lds, s, A, P);
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, false>), grid, block, lds, s, A, P);
         return true;
       } else {
         return false;
       }
     }
-    return launch_dma_r<Sys, R + 1>(r, tgt, grid, block, lds, s, A, P);
+    return launch_dma_r<Sys, R + 1>(r, tgt, g1, grid, block, lds, s, A, P);
   }
 }
 
@@ -287,7 +291,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       A.gpw = (int)gpw;
       const long pw = (B + gpw - 1) / gpw;
       const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
-      if (!launch_dma_r<Sys, 1>(R, tgt, grid, block, (size_t)4 * 256 * R, h->stream, A, P))
+      const bool g1 = c.gamma == 1.0 && !getenv("RCG_NO_G1");  // per-component accumulation (rcg_actor_dma.hpp)
+      if (!launch_dma_r<Sys, 1>(R, tgt, g1, grid, block, (size_t)4 * 256 * R, h->stream, A, P))
         return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d floats", who, R);
       HIPCHK(h, hipGetLastError());
       return RCG_OK;
