@@ -26,6 +26,16 @@ def shard_range(n_envs: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_config(cfg, n_envs: int, rank: int, world: int):
+    """Copy of an ``EngineConfig`` for this rank's block of a job of ``n_envs`` envs: ``batch`` = the block size and
+    ``env_id_base`` = its first GLOBAL env id, so that counter-based per-env streams (the disturbance noise,
+    rcg_disturb.hpp) are the same whatever the number of ranks.  Returns ``(config, (lo, hi))``."""
+    import dataclasses
+
+    lo, hi = shard_range(n_envs, rank, world)
+    return dataclasses.replace(cfg, batch=hi - lo, env_id_base=int(getattr(cfg, "env_id_base", 0)) + lo), (lo, hi)
+
+
 def shard_by_type(type_counts, rank: int, world: int):
     """Mixed preset pool (BASELINE configs[4]): shard WITHIN each system type so that every rank gets
     the same type mix and load.  ``type_counts``: {type: n_envs} -> {type: (lo, hi)} for this rank."""

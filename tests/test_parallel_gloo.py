@@ -22,6 +22,27 @@ def test_shard_range_tiles_exactly():
         P.shard_range(10, 2, 2)
 
 
+def test_shard_config_carries_global_env_ids():
+    """A rank's EngineConfig = its block size + the global id of its first env; the noise of an env is a function of
+    (seed, global id, episode, substep) only, so the union of the shards' streams is the unsharded stream."""
+    from oracle import disturb_oracle as DO
+    from rcognita_amd import EngineConfig
+
+    base = EngineConfig(sys_id=0, batch=1, pars=[10, 1], is_disturb=True, pars_disturb=[[1, 1], [0, 0], [1, 1]], seed=77)
+    n, world = 1003, 4
+    ids = []
+    for r in range(world):
+        cfg, (lo, hi) = P.shard_config(base, n, r, world)
+        assert cfg.batch == hi - lo and cfg.env_id_base == lo and cfg.seed == 77 and base.batch == 1
+        c = cfg.to_native()
+        assert c.env_id_base == lo and c.seed == 77 and c.batch == hi - lo
+        ids.append(cfg.env_id_base + np.arange(cfg.batch, dtype=np.int64))
+    z = np.zeros(n, np.int32)
+    whole = DO.disturb_noise(77, np.arange(n, dtype=np.int64), z, z + 5)
+    parts = np.concatenate([DO.disturb_noise(77, i, z[: len(i)], z[: len(i)] + 5) for i in ids])
+    np.testing.assert_array_equal(whole, parts)
+
+
 def test_shard_by_type_keeps_the_mix():
     counts = {"3wrobot": 21846, "3wrobotNI": 21845, "2tank": 21845}
     tot = {t: 0 for t in counts}

@@ -75,6 +75,37 @@ def main():
             "note": "adjoint gradient + 64-way line search per iteration (about 65 _actor_cost evaluations each)"}
         eng.close()
 
+    # ---- SURVEY 8f rows f3 / f4 on the C2 batch ---------------------------------------------------------
+    def timed(eng, tick):
+        for _ in range(a.warmup):
+            tick()
+        eng.profile(True)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            tick()
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        am, an = eng.profile_read(N.KERNEL_ACTOR)
+        sm, sn = eng.profile_read(N.KERNEL_SIM)
+        summ, _ = eng.episode_stats(from_accum=True)
+        return {"env_control_steps_per_s": eng.B * a.steps / dt, "ms_per_tick": dt / a.steps * 1e3,
+                "decision_kernel_ms": am / max(an, 1), "sim_ms": sm / max(sn, 1), "n_failed": summ["n_failed"]}
+
+    from tests.helpers import rand_states
+
+    for name, gain in (("3wrobotNI", 0.5), ("3wrobot", 5.0)):  # preset gains (main_3wrobot_NI.py:235, main_3wrobot.py:239)
+        eng = Engine(preset_engine_config(name, B2, Nactor=5))
+        eng.set_state(rand_states(rng, name, B2))
+        out[f"f3_nominal_tick_{name}_B{B2}"] = timed(eng, lambda: eng.control_tick_nominal(gain))
+        eng.close()
+    ec = preset_engine_config("3wrobot", B2, Nactor=10)
+    ec.is_disturb, ec.pars_disturb, ec.seed = True, [[2.0, 1.0], [0.5, -0.25], [1.5, 0.7]], 4
+    eng = Engine(ec)
+    eng.set_state(rand_states(rng, "3wrobot", B2))
+    out[f"f4_disturbed_MPC_tick_3wrobot_B{B2}_N10_K256_generated"] = timed(eng, lambda: eng.control_tick(None, K=256))
+    eng.close()
+
     # ---- configs[4], one GPU's shard -----------------------------------------------------------------
     total = 65536
     counts = {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
