@@ -363,11 +363,18 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
     for (int i = 0; i < Sys::DU; ++i) A.u0[i] = (real)c.action_init[i];
     A.iters = iters;
     A.shift = shift;
-    const int N = c.n_actor, R = N * Sys::DU;
-    const size_t lds = 4 * (size_t)(2 * R + N * Sys::DS + N) * sizeof(real);
-    const dim3 grid(blocks_for(c.batch, 4)), block(256);
+    const int N = c.n_actor;
+    const size_t lds = 4 * (size_t)opt_lds_reals(N, Sys::DS, Sys::DU, Sys::NP) * sizeof(real);  // 4 waves per block
+    if (lds > 160 * 1024)
+      return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_actor_optimize: horizon %d needs %zu B of LDS per block", N, lds);
+    const dim3 grid(blocks_for(c.batch, 4 * OPT_G)), block(256);  // a wave owns OPT_G envs
+    const bool tgt = c.flags & RCG_FLAG_HAS_TARGET;
+    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (the CU has 160 KB)
+      const void* fn = tgt ? (const void*)&k_actor_opt<Sys, real, true> : (const void*)&k_actor_opt<Sys, real, false>;
+      HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
-    if (c.flags & RCG_FLAG_HAS_TARGET)
+    if (tgt)
       hipLaunchKernelGGL((k_actor_opt<Sys, real, true>), grid, block, lds, h->stream, A, P);
     else
       hipLaunchKernelGGL((k_actor_opt<Sys, real, false>), grid, block, lds, h->stream, A, P);
