@@ -194,3 +194,31 @@ def test_mirror_system_and_simulator_with_is_disturb():
     with pytest.raises(ValueError):
         simulator.Simulator(sys_type="diff_eqn", closed_loop_rhs=my_sys.closed_loop_rhs, sys_out=my_sys.out,
                             state_init=x0, is_disturb=0)
+
+
+def test_new_entry_points_fail_loudly():
+    """Error convention of include/rcg.h for the f3/f4 entry points: negative status + message, nothing launched."""
+    import ctypes as C
+
+    from rcognita_amd import _native as N
+
+    plain, _ = both("3wrobot", 8, "f64")            # created WITHOUT RCG_FLAG_DISTURB
+    with pytest.raises(N.NativeError) as ei:
+        plain.rhs_full(np.zeros((8, 5)), np.zeros((8, 2)), np.zeros((8, 2)), np.zeros((8, 2)))
+    assert ei.value.code == N.ERR_UNSUPPORTED and "RCG_FLAG_DISTURB" in str(ei.value)
+    with pytest.raises(N.NativeError) as ei:
+        plain.disturb_noise()
+    assert ei.value.code == N.ERR_UNSUPPORTED
+    L = N.lib()
+    assert L.rcg_disturb_noise(plain._h, None, None) == N.ERR_BAD_ARG
+    assert L.rcg_rhs_full(plain._h, None, None, None, None, None, None, None, 8, 1) == N.ERR_BAD_ARG
+    assert L.rcg_nominal_action(plain._h, None, None, None, 8, 1.0, None, 1) == N.ERR_BAD_ARG
+    buf = plain.empty((5, 8))
+    assert L.rcg_nominal_action(plain._h, C.c_void_p(buf.ptr), None, None, 8, 1.0, None, 1) == N.ERR_BAD_ARG  # no output
+    assert L.rcg_nominal_action(plain._h, C.c_void_p(buf.ptr), C.c_void_p(buf.ptr), None, 0, 1.0, None, 1) == N.ERR_BAD_ARG
+    assert L.rcg_control_tick_nominal(None, 1.0, None) == N.ERR_BAD_ARG
+    assert b"rcg_nominal_action" in L.rcg_last_error(plain._h)
+    with pytest.raises(ValueError):  # pars_disturb must be [sigma, mu, tau]
+        both("3wrobot", 4, "f64", engine_only=dict(is_disturb=True, pars_disturb=[[1, 1]]))
+    with pytest.raises(ValueError):
+        both("3wrobot", 4, "f64", engine_only=dict(is_disturb=True, pars_disturb=[[1], [0], [1]]))
