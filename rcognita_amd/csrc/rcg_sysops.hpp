@@ -173,6 +173,27 @@ static int op_critic_update(rcg_handle* h, int32_t do_fit) {
   });
 }
 
+// Development knobs of the actor launcher, read from the environment ONCE per process (they select between variants
+// of the same computation for A/B measurements; none of them changes results beyond rounding):
+//   RCG_ACTOR_KERNEL=plain  force k_actor instead of k_actor_dma      RCG_GPW=<n>  envs per persistent wave
+//   RCG_DBG=1               timing-only variant (rollout skipped)      RCG_NO_G1=1  no gamma == 1 specialisation
+struct DevKnobs {
+  int dbg = 0;
+  bool force_plain = false, no_g1 = false;
+  long gpw = 0;
+};
+static inline const DevKnobs& dev_knobs() {
+  static const DevKnobs k = [] {
+    DevKnobs v;
+    if (const char* e = getenv("RCG_DBG")) v.dbg = atoi(e);
+    if (const char* e = getenv("RCG_ACTOR_KERNEL")) v.force_plain = !strcmp(e, "plain");
+    if (const char* e = getenv("RCG_GPW")) v.gpw = atol(e);
+    v.no_g1 = getenv("RCG_NO_G1") != nullptr;
+    return v;
+  }();
+  return k;
+}
+
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
 // Pick the k_actor_dma<Sys, R> instance for a runtime row length (R = N*du floats, 1..32, multiple of du).
 template <typename Sys, int R>
@@ -266,11 +287,9 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
 
   // Production shape (f32, MPC + diagonal R1, K a multiple of 64, rows of R <= 32 floats) -> k_actor_dma.
-  // Development knobs, read per launch: RCG_ACTOR_KERNEL=plain forces k_actor, RCG_GPW=<n> sets the envs per
-  // persistent wave, RCG_DBG=1 selects the timing-only variant.
-  if (const char* e = getenv("RCG_DBG")) A.dbg = atoi(e);
-  const char* ksel = getenv("RCG_ACTOR_KERNEL");
-  const bool force_plain = ksel && !strcmp(ksel, "plain");
+  const DevKnobs& knobs = dev_knobs();
+  A.dbg = knobs.dbg;
+  const bool force_plain = knobs.force_plain;
   bool dma_ok = false;
   if constexpr (std::is_same<real, float>::value)
     dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= 32 && !generic &&
@@ -286,12 +305,12 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       // 8 is ~3 % slower (fewer, longer waves leave a longer tail), so persistence is only used to keep the
       // wave count bounded for very large batches
       long gpw = B > (1L << 20) ? (B >> 20) : 1;
-      if (const char* e = getenv("RCG_GPW")) gpw = atol(e);
+      if (knobs.gpw > 0) gpw = knobs.gpw;
       gpw = gpw < 1 ? 1 : (gpw > 8 ? 8 : gpw);
       A.gpw = (int)gpw;
       const long pw = (B + gpw - 1) / gpw;
       const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
-      const bool g1 = c.gamma == 1.0 && !getenv("RCG_NO_G1");  // per-component accumulation (rcg_actor_dma.hpp)
+      const bool g1 = c.gamma == 1.0 && !knobs.no_g1;  // per-component accumulation (rcg_actor_dma.hpp)
       if (!launch_dma_r<Sys, 1>(R, tgt, g1, grid, block, (size_t)4 * 256 * R, h->stream, A, P))
         return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d floats", who, R);
       HIPCHK(h, hipGetLastError());

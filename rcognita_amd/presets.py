@@ -86,7 +86,10 @@ def run(name: str, argv=None):
                          "(SURVEY.md 2, component 5); use manual, nominal, MPC, RQL or SQL")
     if args.is_est_model:
         raise SystemExit("--is_est_model: model estimation needs the absent `sippy` package (out of scope)")
-    state_init_as_given = np.array([eval(v.replace("pi", str(np.pi))) for v in args.state_init])  # header cell
+    # arithmetic expressions with `pi`, as the reference accepts (presets/main_3wrobot.py:166-170), but evaluated
+    # without builtins; the int/float type of each entry is kept because it shows in the log header cell
+    state_init_as_given = np.array([eval(v.replace("pi", str(np.pi)), {"__builtins__": {}}, {})
+                                    for v in args.state_init])
     state_init = state_init_as_given.astype(float)
     dim_state, dim_input = s["dim_state"], s["dim_input"]
     assert args.t1 > args.dt > 0.0
