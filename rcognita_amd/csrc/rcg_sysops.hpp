@@ -181,6 +181,8 @@ struct DevKnobs {
   int dbg = 0;
   bool force_plain = false, no_g1 = false;
   long gpw = 0;
+  long lds_pad = 0;  // RCG_LDS_PAD=<bytes>: extra dynamic LDS per block, caps the resident blocks per CU (-1: no cap)
+  int per_cu = 0;    // RCG_PER_CU=2|4|8: resident blocks per CU for k_actor_dma (0: by row length)
 };
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
@@ -188,6 +190,8 @@ static inline const DevKnobs& dev_knobs() {
     if (const char* e = getenv("RCG_DBG")) v.dbg = atoi(e);
     if (const char* e = getenv("RCG_ACTOR_KERNEL")) v.force_plain = !strcmp(e, "plain");
     if (const char* e = getenv("RCG_GPW")) v.gpw = atol(e);
+    if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
+    if (const char* e = getenv("RCG_PER_CU")) v.per_cu = atoi(e);
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
     return v;
   }();
@@ -301,17 +305,34 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
   if constexpr (std::is_same<real, float>::value) {
     if (dma_ok) {
-      // envs per persistent wave: measured on C2 (B = 65536, K = 256), 1 and 2 are equal within noise and
-      // 8 is ~3 % slower (fewer, longer waves leave a longer tail), so persistence is only used to keep the
-      // wave count bounded for very large batches
-      long gpw = B > (1L << 20) ? (B >> 20) : 1;
+      // Launch geometry, measured on MI355X at C2 (B = 65536, K = 256, N = 10):
+      //  * residency: 2 blocks (8 waves) per CU stream faster than 8 blocks per CU - 0.204 ms against 0.213-0.218 ms.
+      //    The dynamic-LDS request is raised to 56 KB so that at most two blocks fit into the CU's 160 KB;
+      //  * envs per wave (gpw): each wave writes the results of its gpw envs once, coalesced, so gpw >= 4 turns 6
+      //    scattered 4-byte writes per env into 16-64-byte segments; powers of two only (3, 6 measured 2-3 % slower);
+      //  * rounds: the grid must be several times the 512 resident blocks so that the CUs stay balanced (single-round
+      //    grids that do not divide evenly over 256 CUs lost 10 %: gpw = 20, 28, 48) - gpw is the largest power of
+      //    two <= 16 that still leaves >= 8192 waves.
+      long gpw = 1;
+      while (gpw < 16 && B / (gpw * 2) >= 8192) gpw *= 2;
       if (knobs.gpw > 0) gpw = knobs.gpw;
-      gpw = gpw < 1 ? 1 : (gpw > 8 ? 8 : gpw);
+      gpw = gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
       A.gpw = (int)gpw;
       const long pw = (B + gpw - 1) / gpw;
       const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
       const bool g1 = c.gamma == 1.0 && !knobs.no_g1;  // per-component accumulation (rcg_actor_dma.hpp)
-      if (!launch_dma_r<Sys, 1>(R, tgt, g1, grid, block, (size_t)4 * 256 * R, h->stream, A, P))
+      // blocks per CU: 2 for rows of >= 20 floats (a block keeps R KiB in flight), 4 for shorter rows, which need more
+      // waves to keep enough bytes on the wire (measured R = 6 ... 32: 2 vs 4 differ by 1-3 % either side of R = 20,
+      // R = 10 with 2 blocks/CU is 9 % slower than with 4; 8 blocks/CU is 5-15 % slower than the better of the two)
+      const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : (R >= 20 ? 2 : 4);
+      size_t lds_req = (size_t)4 * 256 * R;
+      if (knobs.lds_pad > 0) {
+        lds_req += (size_t)knobs.lds_pad;
+      } else if (knobs.lds_pad == 0) {  // RCG_LDS_PAD=-1: no residency cap
+        const size_t want = per_cu <= 2 ? (size_t)56 * 1024 : (per_cu <= 4 ? (size_t)36 * 1024 : 0);
+        if (lds_req < want) lds_req = want;
+      }
+      if (!launch_dma_r<Sys, 1>(R, tgt, g1, grid, block, lds_req, h->stream, A, P))
         return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d floats", who, R);
       HIPCHK(h, hipGetLastError());
       return RCG_OK;

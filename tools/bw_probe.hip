@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -111,6 +112,59 @@ __global__ __launch_bounds__(256) void k_rows(const v4f* __restrict__ p, long n_
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
 }
 
+
+// D: the production kernel's data path without its arithmetic: each wave owns `tiles_per_wave` consecutive tiles; a
+// tile goes HBM -> LDS with NROW direct-to-LDS loads (global_load_lds_dwordx4 nt), every lane then pulls ITS row
+// (NROW x 16 B) LDS -> registers, the next tile's loads are issued, the row is consumed.  REG: same, but the tile is
+// loaded into registers and parked in LDS with ds_write_b128 (no direct-to-LDS path).
+template <int NROW, bool REG>
+__global__ __launch_bounds__(256) void k_tiles_lds(const v4f* __restrict__ p, long n_tiles_total, int tiles_per_wave,
+                                                   float* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wave = (long)blockIdx.x * 4 + wv;
+  const long t0 = wave * tiles_per_wave;
+  if (t0 >= n_tiles_total) return;
+  unsigned char* tile = smem + (size_t)wv * NROW * 1024;
+  const unsigned char* g = reinterpret_cast<const unsigned char*>(p) + (size_t)t0 * NROW * 1024;
+  const v4f* myrow = reinterpret_cast<const v4f*>(tile) + lane * NROW;
+  v4f acc = {0, 0, 0, 0};
+  v4f r[NROW];
+  auto issue = [&](const unsigned char* gg) {
+    if (REG) {
+#pragma unroll
+      for (int j = 0; j < NROW; ++j) r[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(gg) + j * 64 + lane);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NROW; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)(gg + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0, 2);
+    }
+  };
+  issue(g);
+  for (int t = 0; t < tiles_per_wave; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (REG) {
+#pragma unroll
+      for (int j = 0; j < NROW; ++j) reinterpret_cast<v4f*>(tile)[j * 64 + lane] = r[j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    v4f c[NROW];
+#pragma unroll
+    for (int j = 0; j < NROW; ++j) c[j] = myrow[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    g += NROW * 1024;
+    if (t + 1 < tiles_per_wave) issue(g);
+#pragma unroll
+    for (int j = 0; j < NROW; ++j) acc += c[j];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+
 template <typename F>
 static double time_it(F launch, int reps = 20) {
   hipEvent_t a, b;
@@ -126,7 +180,7 @@ static double time_it(F launch, int reps = 20) {
   return ms / reps * 1e-3;
 }
 
-int main() {
+int main(int argc, char** argv) {
   const long B = 65536, K = 256, R = 20;
   const size_t bytes = (size_t)B * K * R * 4;
   const size_t n4 = bytes / 16;
@@ -136,6 +190,30 @@ int main() {
   CHK(hipMalloc(&out, 64));
   CHK(hipMemset(d, 0, bytes));
   printf("buffer %.3f GB\n", bytes / 1e9);
+  if (argc > 1 && !strcmp(argv[1], "steady")) {
+    // steady state: windows of 50 launches, 12 windows per variant (the first launches after the GPU wakes up run
+    // in a clock transient; the bench's number is the long-run average)
+    const long n_tiles = (long)B * K / 64;
+    const unsigned tb = (unsigned)((n_tiles / 4 + 3) / 4);
+    for (int v = 0; v < 5; ++v) {
+      for (int win = 0; win < 6; ++win) {
+        double t;
+        if (v == 3)
+          t = time_it([&] { hipLaunchKernelGGL((k_tiles_lds<5, false>), dim3(tb), dim3(256), 4 * 5 * 1024, 0, d, n_tiles, 4, out); }, 50);
+        else if (v == 4)
+          t = time_it([&] { hipLaunchKernelGGL((k_tiles_lds<5, true>), dim3(tb), dim3(256), 4 * 5 * 1024, 0, d, n_tiles, 4, out); }, 50);
+        else if (v == 0)
+          t = time_it([&] { hipLaunchKernelGGL((k_stream<true, 8>), dim3(8192), dim3(256), 0, 0, d, n4, out); }, 50);
+        else if (v == 1)
+          t = time_it([&] { hipLaunchKernelGGL((k_tiles<true, 5, true>), dim3(tb), dim3(256), 0, 0, d, n_tiles, 4, out); }, 50);
+        else
+          t = time_it([&] { hipLaunchKernelGGL((k_rows<true, 5, true>), dim3(tb), dim3(256), 0, 0, d, n_tiles, 4, out); }, 50);
+        printf("%s window %2d : %7.1f us  %6.0f GB/s\n", v == 0 ? "stream nt unroll8" : v == 1 ? "tiles nt pipe tpw4 " : v == 2 ? "rows nt pipe tpw4  " : v == 3 ? "tiles LDS-DMA tpw4 " : "tiles reg->LDS tpw4",
+               win, t * 1e6, bytes / t / 1e9);
+      }
+    }
+    return 0;
+  }
   for (int blocks : {2048, 4096, 8192, 16384}) {
     double t = time_it([&] { hipLaunchKernelGGL((k_stream<false, 4>), dim3(blocks), dim3(256), 0, 0, d, n4, out); });
     printf("stream   plain unroll4 blocks=%5d : %7.1f us  %6.0f GB/s\n", blocks, t * 1e6, bytes / t / 1e9);
