@@ -27,6 +27,20 @@
 
 namespace rcg {
 
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the immediate must be a constant): n <= 16 here (a tile is at most
+// 8 loads, an env-state request at most 7); anything else waits for everything.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define RCG_VMCNT_CASE(k) \
+  case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    RCG_VMCNT_CASE(1) RCG_VMCNT_CASE(2) RCG_VMCNT_CASE(3) RCG_VMCNT_CASE(4) RCG_VMCNT_CASE(5) RCG_VMCNT_CASE(6)
+    RCG_VMCNT_CASE(7) RCG_VMCNT_CASE(8) RCG_VMCNT_CASE(9) RCG_VMCNT_CASE(10) RCG_VMCNT_CASE(11) RCG_VMCNT_CASE(12)
+    RCG_VMCNT_CASE(13) RCG_VMCNT_CASE(14) RCG_VMCNT_CASE(15) RCG_VMCNT_CASE(16)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef RCG_VMCNT_CASE
+}
+
 // G1: gamma == 1 (the reference's default and every preset, main_3wrobot.py:147): the discounted sum of weighted
 // squares is accumulated per component, S_i += chi_i^2 (one fma per term and step instead of mul + fma + the
 // discount bookkeeping) and weighted once at the end, J = sum_i R1_ii S_i.  The rollout is VALU-issue-limited almost
@@ -52,13 +66,17 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
   const long env0 = wave * A.gpw;
   if (env0 >= B) return;
   const long env1 = env0 + A.gpw < B ? env0 + A.gpw : B;
-  const long n_tiles = (env1 - env0) * T;
+  // 32-bit on purpose: a 64-bit loop compare has no scalar form, and its VGPR temporary once landed in the registers
+  // of the in-flight env-state prefetch (a WAW hazard the compiler resolves with s_waitcnt vmcnt(0))
+  const int n_tiles = (int)(env1 - env0) * T;
 
-  unsigned char* const tile = smem_raw + (size_t)wave_in_wg * (256 * R);  // this wave's LDS tile
-  const real* const myrow = reinterpret_cast<const real*>(tile) + lane * R;
+  // this wave's LDS: one tile, or two (A.depth == 2: tile g lives in buffer g & 1 and tile g + 2 is requested into it
+  // as soon as tile g's rows are in registers, so two tiles are in flight while the rollout runs)
+  const int depth = A.depth == 2 ? 2 : 1;
+  unsigned char* const tile0 = smem_raw + (size_t)wave_in_wg * (256 * R) * depth;
   const unsigned char* gb = reinterpret_cast<const unsigned char*>(A.cand) + (size_t)env0 * K * (4 * R);
 
-  auto issue_tile = [&](const unsigned char* g) {
+  auto issue_tile = [&](const unsigned char* g, unsigned char* tile) {
 #pragma unroll
     for (int j = 0; j < NFULL; ++j)
       __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0,
@@ -88,8 +106,11 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
       for (int i = 0; i < NP; ++i) pn[i] = A.pars_env[(long)i * B + b];
     }
   };
+  // loads one env-state request issues (vmcnt bookkeeping of the depth-2 pipeline)
+  const int n_env_loads = (A.dbg & 4) ? 0 : DS + (A.pars_env ? NP : 0);
   fetch_env(env0);
-  issue_tile(gb);  // after the env request: retiring the env state must not drain the first tile
+  issue_tile(gb, tile0);  // after the env request: retiring the env state must not drain the first tile
+  if (depth == 2 && n_tiles > 1) issue_tile(gb + 256 * R, tile0 + 256 * R);  // T >= 2: same env
 
   const real h = P.h_pred;
   long b = env0;
@@ -107,7 +128,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
 #pragma unroll
   for (int c = 0; c < DU; ++c) resU[c] = 0;
 
-  for (long g = 0; g < n_tiles; ++g) {
+  for (int g = 0; g < n_tiles; ++g) {
     if (t == 0) {  // first tile of env b: adopt the state requested one tile ago
 #pragma unroll
       for (int c = 0; c < DS; ++c) y0[c] = yn[c];
@@ -117,18 +138,27 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
       bestJ = inf_r<real>();
       bestI = 0x7fffffff;
     }
-    // 2. tile g has landed (every older vector-memory operation has retired) -> my row into registers
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // 2. tile g has landed -> my row into registers.  vmcnt retires in issue order: depth 1 waits for everything;
+    //    depth 2 lets what was issued AFTER tile g stay in flight: tile g + 1, preceded by an env-state request iff
+    //    tile g + 1 opens the next env (t == T - 1)
+    if (depth == 2 && g + 1 < n_tiles)
+      wait_vmcnt(NFULL + NREM + (t == T - 1 ? n_env_loads : 0));
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned char* const tile = tile0 + ((depth == 2 && (g & 1)) ? 256 * R : 0);
+    const real* const myrow = reinterpret_cast<const real*>(tile) + lane * R;
     real cur[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) cur[i] = myrow[i];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane's row is out of LDS (in-order per wave)
     __builtin_amdgcn_wave_barrier();
-    // 3. the LDS tile is free: request what the next iteration needs, the tile loads last
+    // 3. this LDS buffer is free: request tile g + depth into it, an env-state request first if it opens an env
+    //    (one code path for both depths: two sites would be merged by the compiler with register copies of the
+    //    prefetched state, i.e. with a wait for it)
     gb += 256 * R;
-    if (g + 1 < n_tiles) {
-      if (t == T - 1) fetch_env(b + 1);
-      issue_tile(gb);
+    if (g + depth < n_tiles) {
+      if (t == T - depth) fetch_env(b + 1);  // tile g + depth is the first tile of env b + 1 (depth 2: T >= 2)
+      issue_tile(gb + (depth - 1) * (256 * R), tile);
     }
 
     // 4. _actor_cost of this lane's row (controllers.py:1284-1306), registers only

@@ -203,6 +203,7 @@ struct ActorArgs {
   int grid_g;             // generated grid: levels per input
   int vec_ok;             // rows are 16-B granular: stage with dwordx4
   int gpw;                // k_actor_dma: consecutive envs per (persistent) wave
+  int depth;              // k_actor_dma: tiles in flight per wave, 1 or 2 (2 needs K >= 128 and no J output)
   int dbg;                // development only (env RCG_DBG): bit0 = skip the rollout (timing-only build)
 };
 

@@ -183,6 +183,7 @@ struct DevKnobs {
   long gpw = 0;
   long lds_pad = 0;  // RCG_LDS_PAD=<bytes>: extra dynamic LDS per block, caps the resident blocks per CU (-1: no cap)
   int per_cu = 0;    // RCG_PER_CU=2|4|8: resident blocks per CU for k_actor_dma (0: by row length)
+  int depth = 0;     // RCG_DEPTH=2: two tiles in flight per wave (default: one)
 };
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
@@ -192,6 +193,7 @@ static inline const DevKnobs& dev_knobs() {
     if (const char* e = getenv("RCG_GPW")) v.gpw = atol(e);
     if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
     if (const char* e = getenv("RCG_PER_CU")) v.per_cu = atoi(e);
+    if (const char* e = getenv("RCG_DEPTH")) v.depth = atoi(e);
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
     return v;
   }();
@@ -325,7 +327,12 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       // waves to keep enough bytes on the wire (measured R = 6 ... 32: 2 vs 4 differ by 1-3 % either side of R = 20,
       // R = 10 with 2 blocks/CU is 9 % slower than with 4; 8 blocks/CU is 5-15 % slower than the better of the two)
       const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : (R >= 20 ? 2 : 4);
-      size_t lds_req = (size_t)4 * 256 * R;
+      // RCG_DEPTH=2: two tiles in flight per wave (double-buffered LDS tile, exact vmcnt bookkeeping; needs an env of
+      // at least two tiles and no per-candidate J store inside the loop, because stores and loads retire out of order
+      // with respect to each other).  Measured 1.5-3 % SLOWER than one tile in flight on C2 and on N = 5, K = 128,
+      // K = 512 (+0.7 % only at N = 16): the default stays 1.
+      A.depth = (knobs.depth == 2 && K >= 128 && !A.J) ? 2 : 1;
+      size_t lds_req = (size_t)4 * 256 * R * A.depth;
       if (knobs.lds_pad > 0) {
         lds_req += (size_t)knobs.lds_pad;
       } else if (knobs.lds_pad == 0) {  // RCG_LDS_PAD=-1: no residency cap

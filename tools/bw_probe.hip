@@ -190,6 +190,25 @@ int main(int argc, char** argv) {
   CHK(hipMalloc(&out, 64));
   CHK(hipMemset(d, 0, bytes));
   printf("buffer %.3f GB\n", bytes / 1e9);
+  if (argc > 1 && !strcmp(argv[1], "residency")) {
+    // the production data path (LDS-DMA tiles) at different residencies (LDS request caps the blocks per CU) and
+    // tiles per wave: is a low-residency launch limited by the bytes in flight?
+    const long n_tiles = (long)B * K / 64;
+    for (int lds_kb : {20, 36, 56}) {
+      for (int tpw : {4, 32, 64}) {
+        const unsigned tb = (unsigned)((n_tiles / tpw + 3) / 4);
+        double best = 1e9, sum = 0;
+        for (int win = 0; win < 5; ++win) {
+          const double t = time_it([&] { hipLaunchKernelGGL((k_tiles_lds<5, false>), dim3(tb), dim3(256), lds_kb * 1024, 0, d, n_tiles, tpw, out); }, 50);
+          best = t < best ? t : best;
+          sum += t;
+        }
+        printf("LDS-DMA tiles  lds=%2d KB (%d blocks/CU) tiles/wave=%2d : mean %7.1f us %6.0f GB/s  best %7.1f us\n", lds_kb,
+               160 / lds_kb, tpw, sum / 5 * 1e6, bytes / (sum / 5) / 1e9, best * 1e6);
+      }
+    }
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "steady")) {
     // steady state: windows of 50 launches, 12 windows per variant (the first launches after the GPU wakes up run
     // in a clock transient; the bench's number is the long-run average)
