@@ -347,7 +347,9 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
           for (int c = 0; c < DU; ++c) u0[c] = u[c];
         } else {
           real d[DS];
-          Sys::template rhs<real>(pre, x, up, d);  // unclipped, as sys_rhs([], state, u[k-1])
+          // unclipped, as sys_rhs([], state, u[k-1]); f32: hardware v_sin/v_cos behind the exact reduction, as in
+          // k_actor_dma (3.7e-7 max abs error, 7 VALU ops instead of ~25: the generated-candidate regime is VALU-bound)
+          Sys::template rhs<real, std::is_same<real, float>::value>(pre, x, up, d);
 #pragma unroll
           for (int c = 0; c < DS; ++c) {
             x[c] = fma_r(h, d[c], x[c]);
