@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
       for (int c = 0; c < DU; ++c) u[c] = clamp_r<real>(fma_r(-alpha, de[k * DU + c], ue[k * DU + c]), P.lo[c], P.hi[c]);
       if (k > 0) {
         real d[DS];
-        Sys::template rhs<real>(pre, x, up, d);
+        // f32: hardware v_sin/v_cos behind the exact reduction, as in every f32 rollout of the build (the 64 trial
+        // rollouts of the line search are where this kernel spends its instructions)
+        Sys::template rhs<real, std::is_same<real, float>::value>(pre, x, up, d);
 #pragma unroll
         for (int c = 0; c < DS; ++c) {
           x[c] = fma_r(h, d[c], x[c]);
