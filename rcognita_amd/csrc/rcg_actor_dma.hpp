@@ -17,11 +17,17 @@
 //        wait of any kind.  Trig: hardware v_sin/v_cos behind an exact reduction (rcg_math.hpp::sincos_hw).
 // The only vmcnt wait is the one in front of step 2 of the NEXT tile, which is exactly the data it needs.
 // vmcnt retires in issue order, so whatever else the next iteration needs from memory (the next env's state)
-// is requested BEFORE the tile loads and never drains them; the tick epilogue's read-modify-writes of ACCUM and
-// STEP_IDX are no-return atomics (one adder per address: still deterministic) and need no wait at all.
+// is requested BEFORE the tile loads and never drains them.
+//     5. per env: wave argmin on a packed (cost, index) key (DPP + v_readlane, rcg_math.hpp); the winner is parked in
+//        lane (env - env0).  When the wave's envs are done, lanes < n_envs store action / best_J / best_idx coalesced
+//        and issue ACCUM / STEP_IDX as no-return atomics (one adder per address: still deterministic).  Per-env
+//        4-byte writes from lane 0 cost 7 % (scattered partial-line writes interleaved with the read stream).
 // No s_barrier anywhere: a wave only reads LDS it filled itself.
-// Measured on C2 (B = 65536, K = 256, N = 10): 222-227 us per launch = 5.9-6.05 TB/s; with the rollout skipped
-// (A.dbg bit 0, timing-only build) 204-214 us; this access pattern alone reads at 7.0 TB/s (tools/bw_probe.hip).
+// Launch geometry (rcg_sysops.hpp::launch_actor): a wave owns a power-of-two number of consecutive envs, 2 blocks per
+// CU resident (4 for rows shorter than 20 floats), grid of several rounds.
+// Measured on C2 (B = 65536, K = 256, N = 10): 203 us per launch = 6.6 TB/s (83 % of the 8 TB/s peak); the bare data
+// path of this kernel (steps 1-3, no arithmetic) holds 7.0-7.2 TB/s (tools/bw_probe.hip residency).  A.dbg bits
+// (RCG_DBG) switch pieces off for such measurements: 1 rollout, 2 argmin + writes, 4 env-state loads.
 #pragma once
 #include "rcg_kernels.hpp"
 
@@ -43,8 +49,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 // G1: gamma == 1 (the reference's default and every preset, main_3wrobot.py:147): the discounted sum of weighted
 // squares is accumulated per component, S_i += chi_i^2 (one fma per term and step instead of mul + fma + the
-// discount bookkeeping) and weighted once at the end, J = sum_i R1_ii S_i.  The rollout is VALU-issue-limited almost
-// as much as it is HBM-limited (about 30 VALU ops per step before, 14 of them the stage cost), so this matters.
+// discount bookkeeping) and weighted once at the end, J = sum_i R1_ii S_i.  About 30 VALU ops per step before, 14 of
+// them the stage cost; measured +1.2 % on C2 (the kernel is HBM-bound, the VALU work only has to stay out of the way).
 template <typename Sys, int R, bool TGT, bool G1>
 __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, const KParams<float> P) {
   typedef float real;
