@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RCG_LIB lets a developer A/B another build of the same ABI; the default is the in-tree library
@@ -90,6 +91,13 @@ def lib():
             f"{LIB_PATH} not found: build the HIP library first (`make lib` at the repo root, or "
             "`python -c 'import __graft_entry__ as g; g.build()'`).  rcognita_amd has no CPU fallback."
         )
+    # PyTorch-ROCm ships its own HIP runtime.  If this library brings the system runtime up first, torch's later
+    # initialisation in the same process finds no GPU ("No HIP GPUs are available"); the other order works.  So when
+    # torch is already imported, let it initialise first.  (torch is plumbing for callers that hand over tensors;
+    # this module never imports it on its own.)
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and not torch.cuda.is_initialized():
+        torch.cuda.init()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     sig = {
