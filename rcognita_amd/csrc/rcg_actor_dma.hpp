@@ -81,6 +81,12 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
   const int depth = A.depth == 2 ? 2 : 1;
   unsigned char* const tile0 = smem_raw + (size_t)wave_in_wg * (256 * R) * depth;
   const unsigned char* gb = reinterpret_cast<const unsigned char*>(A.cand) + (size_t)env0 * K * (4 * R);
+  // operator mode (rcg_actor_cost): the J of one env is staged in LDS ([K] floats per wave, behind the tiles of all
+  // four waves) and written out at the env's end in 1-KiB bursts; a 256-B store after every tile, interleaved with
+  // the read stream, made the operator 35 % slower than the tick for 5 % more bytes
+  // (A.jwave: the staging area holds all envs of the wave and is written once, when the wave is done)
+  const int jspan = A.jwave ? A.gpw * K : K;  // floats of staging per wave
+  real* const jstage = reinterpret_cast<real*>(smem_raw + (size_t)4 * (256 * R) * depth) + (size_t)wave_in_wg * jspan;
 
   auto issue_tile = [&](const unsigned char* g, unsigned char* tile) {
 #pragma unroll
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
     }
 
     const int k = t * 64 + lane;
-    if (A.J) A.J[b * K + k] = J;
+    if (A.J) jstage[(A.jwave ? (int)(b - env0) * K : 0) + k] = J;
     const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
     if (Jc < bestJ || bestI == 0x7fffffff) {
       bestJ = Jc;
@@ -219,6 +225,21 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
       for (int c = 0; c < DU; ++c) bu[c] = cur[c];  // the sequence's first action
     }
 
+    // env b complete (per-env staging) or wave complete (A.jwave): the staged costs go out in one piece
+    if (A.J && (A.jwave ? g == n_tiles - 1 : t == T - 1)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      real* const Jout = A.J + (A.jwave ? env0 : b) * K;
+      const int n = A.jwave ? (int)(env1 - env0) * K : K;  // a multiple of 64
+      if ((n & 255) == 0) {
+        for (int i = lane * 4; i < n; i += 256) {
+          const v4f v = *reinterpret_cast<const v4f*>(jstage + i);
+          *reinterpret_cast<v4f*>(Jout + i) = v;
+        }
+      } else {
+        for (int i = lane; i < n; i += 64) Jout[i] = jstage[i];
+      }
+    }
     if (++t == T) {  // env b complete: wave argmin (lower J, then lower index) + tick epilogue
       if (A.dbg & 2) {  // development: no argmin / stores (one store keeps the work alive)
         if (bestJ == (real)-12345.678f) A.best_J[b] = bestJ;

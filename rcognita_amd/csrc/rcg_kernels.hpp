@@ -204,6 +204,7 @@ struct ActorArgs {
   int vec_ok;             // rows are 16-B granular: stage with dwordx4
   int gpw;                // k_actor_dma: consecutive envs per (persistent) wave
   int depth;              // k_actor_dma: tiles in flight per wave, 1 or 2 (2 needs K >= 128 and no J output)
+  int jwave;              // k_actor_dma, J output: stage the costs of all envs of the wave in LDS (else env by env)
   int dbg;                // development only (env RCG_DBG): bit0 = skip the rollout (timing-only build)
 };
 

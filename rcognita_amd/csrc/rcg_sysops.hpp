@@ -299,7 +299,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   bool dma_ok = false;
   if constexpr (std::is_same<real, float>::value)
     dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= 32 && !generic &&
-             A.obs == A.state_sys && !force_plain;
+             A.obs == A.state_sys && !force_plain &&
+             !(A.J && (size_t)4 * 256 * R + (size_t)16 * K > (size_t)64 * 1024);  // J staging must fit next to the tiles
   if (sim_first) {  // the env step of the tick (Simulator.sim_step) precedes the decision
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
     if (rc) return rc;
@@ -332,7 +333,9 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       // with respect to each other).  Measured 1.5-3 % SLOWER than one tile in flight on C2 and on N = 5, K = 128,
       // K = 512 (+0.7 % only at N = 16): the default stays 1.
       A.depth = (knobs.depth == 2 && K >= 128 && !A.J) ? 2 : 1;
-      size_t lds_req = (size_t)4 * 256 * R * A.depth;
+      // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
+      A.jwave = (A.J && (size_t)4 * 256 * R * A.depth + (size_t)16 * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
+      size_t lds_req = (size_t)4 * 256 * R * A.depth + (A.J ? (size_t)16 * K * (A.jwave ? gpw : 1) : 0);
       if (knobs.lds_pad > 0) {
         lds_req += (size_t)knobs.lds_pad;
       } else if (knobs.lds_pad == 0) {  // RCG_LDS_PAD=-1: no residency cap

@@ -121,6 +121,11 @@ def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B):
     cand1 = (lo + (hi - lo) * rng.random((K, Nh, 2))).astype(np.float32)          # one candidate set ...
     cand = eng.to_device(np.ascontiguousarray(np.broadcast_to(cand1, (B, K, Nh, 2))))  # ... streamed per env
     env = O.new_batch(cfg, x0.astype(np.float64))
+    # operator mode first (rcg_actor_cost: J of every candidate, staged per wave in LDS and written in one burst)
+    J = eng.actor_cost(cand)
+    J_or = O.actor_cost(cand1.astype(np.float64)[None], x0.astype(np.float64)[:, None, :], x0.astype(np.float64)[:, None, :],
+                        cfg, pars=env.pars)
+    assert J.shape == (B, K) and rel_err_norm(J, J_or) < 1e-5
     same = np.ones(B, dtype=bool)
     for _ in range(T):
         eng.control_tick(cand, K=K)

@@ -75,6 +75,36 @@ def main():
             "note": "adjoint gradient + 64-way line search per iteration (about 65 _actor_cost evaluations each)"}
         eng.close()
 
+    # ---- the operator boundary itself (unit U1 of SURVEY 8d): rcg_actor_cost, J for every candidate ------
+    import ctypes as C
+
+    Kc, Nc = 256, 10
+    eng = Engine(preset_engine_config("3wrobot", B2, Nactor=Nc))
+    eng.set_state(np.stack([rng.uniform(-10, 10, B2), rng.uniform(-10, 10, B2), rng.uniform(-np.pi, np.pi, B2),
+                            rng.uniform(-1, 1, B2), rng.uniform(-1, 1, B2)], axis=-1))
+    bn = np.array([[-300, 300], [-100, 100]], dtype=np.float32)
+    cand = eng.to_device(bn[:, 0] + (bn[:, 1] - bn[:, 0]) * rng.random((B2, Kc, Nc, 2), dtype=np.float32))
+    Jd = eng.empty((B2, Kc))
+    call = lambda: N.check(N.lib().rcg_actor_cost(eng._h, C.c_void_p(cand.ptr), Kc, None, None, None, C.c_void_p(Jd.ptr)),
+                           eng._h)
+    for _ in range(a.warmup + 20):
+        call()
+    eng.profile(True)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps * 4):
+        call()
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    am, an = eng.profile_read(N.KERNEL_ACTOR)
+    per_eval = 4 * (Nc * 2 + 5 + 5 + 1)  # 4 (N du + ds + dy + 1) = 124 B; obs == state_sys here: read once
+    out[f"U1_actor_cost_operator_3wrobot_B{B2}_K{Kc}_N{Nc}_streamed"] = {
+        "actor_cost_evals_per_s": B2 * Kc * a.steps * 4 / dt, "kernel_ms": am / max(an, 1),
+        "kernel_GBps_moved": (B2 * Kc * (Nc * 2 * 4 + 4) + B2 * 20) / (am / max(an, 1) * 1e-3) / 1e9,
+        "survey_bytes_per_eval": per_eval}
+    eng.close()
+    del cand, Jd
+
     # ---- SURVEY 8f rows f3 / f4 on the C2 batch ---------------------------------------------------------
     def timed(eng, tick):
         for _ in range(a.warmup):
