@@ -142,3 +142,40 @@ def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B):
     assert rel_err_norm(eng.get_field(N.FIELD_ACCUM)[same], env.accum[same], floor=float(np.max(np.abs(env.accum)))) < 1e-4
     summ, _ = eng.episode_stats(from_accum=True)
     assert summ["count"] == B and summ["n_failed"] == 0
+
+
+def test_one_million_envs():
+    """Size edge: B = 2^20 envs (16x the bench batch) through the tick with generated candidates, an episode reset in
+    the middle.  Integer fields exact for every env, the summary consistent with the per-env returns, and a random
+    sample of envs against the oracle."""
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import preset_engine_config
+
+    rng = np.random.default_rng(2026)
+    B, K, Nh, T = 1 << 20, 64, 5, 3
+    eng = Engine(preset_engine_config("3wrobotNI", B, Nactor=Nh))
+    x0 = rand_states(rng, "3wrobotNI", B).astype(np.float32)
+    eng.set_state(x0)
+    for _ in range(T):
+        eng.control_tick(None, K=K)
+    summ, returns = eng.episode_stats(from_accum=True, want_returns=True)
+    assert summ["count"] == B and summ["n_failed"] == 0
+    np.testing.assert_allclose(summ["sum"], returns.astype(np.float64).sum(), rtol=1e-9)
+    assert summ["min"] == returns.min() and summ["max"] == returns.max()
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
+    sel = np.sort(rng.choice(B, 64, replace=False))
+    cfg = oracle_cfg("3wrobotNI", n_actor=Nh)
+    env = O.new_batch(cfg, x0[sel].astype(np.float64))
+    grid = O.grid_candidates(cfg, K)
+    for _ in range(T):
+        O.control_tick(cfg, env, grid)
+    ok = eng.get_field(N.FIELD_BEST_IDX)[sel] == env.best_idx
+    assert ok.mean() > 0.9
+    assert rel_err_norm(eng.get_state()[sel][ok], env.state[ok]) < 1e-4
+    eng.episode_reset()
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_EPISODE_IDX), np.ones(B, np.int32))
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.zeros(B, np.int32))
+    np.testing.assert_array_equal(eng.get_state(), x0)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_RETURNS), returns)
+    eng.control_tick(None, K=K)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.ones(B, np.int32))
