@@ -51,10 +51,17 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // squares is accumulated per component, S_i += chi_i^2 (one fma per term and step instead of mul + fma + the
 // discount bookkeeping) and weighted once at the end, J = sum_i R1_ii S_i.  About 30 VALU ops per step before, 14 of
 // them the stage cost; measured +1.2 % on C2 (the kernel is HBM-bound, the VALU work only has to stay out of the way).
-template <typename Sys, int R, bool TGT, bool G1>
+// CRIT: mode RQL (instantiated with G1 = false only): the last stage cost is replaced by Q_w(y_{N-1}, u_{N-1})
+// (controllers.py:1307-1310) - the horizon is unrolled, so that is a compile-time position.  The env's critic weights
+// travel with its state (requested one tile ahead, held in registers).  Measured on configs[2] with streamed
+// candidates: 0.474 ms against 0.506 ms on k_actor.  SQL (Q_w at every step, :1311-1326) was tried here as well and
+// is 18 % SLOWER than on k_actor, whose rollout is specialised on the critic structure at compile time: it stays there.
+template <typename Sys, int R, bool TGT, bool G1, bool CRIT>
 __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, const KParams<float> P) {
   typedef float real;
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
+  constexpr int DCMAX = CRIT ? NCHI * (NCHI + 1) / 2 + NCHI : 1;  // quad-lin, the largest critic structure
+  static_assert(!(CRIT && G1), "critic modes use the discounted accumulation");
   static_assert(R % DU == 0 && R >= DU && R <= 32, "row = N*du floats, at most 32");
   constexpr int N = R / DU;
   constexpr int NFULL = R / 4, NREM = R % 4;  // 1-KiB and 256-B direct-to-LDS loads per tile
@@ -102,9 +109,11 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
   // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
   // "pointer ? load : default" selects (a default written into a register with a load in flight would force a
   // vmcnt(0) on the spot).
-  real y0[DS], yn[DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1];
+  real y0[DS], yn[DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1], wc[DCMAX], wn[DCMAX];
 #pragma unroll
   for (int i = 0; i < NP; ++i) pn[i] = P.pars[i];
+#pragma unroll
+  for (int i = 0; i < DCMAX; ++i) wn[i] = wc[i] = 0;  // entries >= dc are never loaded and never read
   auto fetch_env = [&](long b) {
     if (A.dbg & 4) {  // development: no env-state loads
 #pragma unroll
@@ -117,9 +126,14 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
 #pragma unroll
       for (int i = 0; i < NP; ++i) pn[i] = A.pars_env[(long)i * B + b];
     }
+    if (CRIT) {
+#pragma unroll
+      for (int i = 0; i < DCMAX; ++i)
+        if (i < P.dc) wn[i] = A.w[(long)i * B + b];  // wave-uniform branch
+    }
   };
   // loads one env-state request issues (vmcnt bookkeeping of the depth-2 pipeline)
-  const int n_env_loads = (A.dbg & 4) ? 0 : DS + (A.pars_env ? NP : 0);
+  const int n_env_loads = (A.dbg & 4) ? 0 : DS + (A.pars_env ? NP : 0) + (CRIT ? P.dc : 0);
   fetch_env(env0);
   issue_tile(gb, tile0);  // after the env request: retiring the env state must not drain the first tile
   if (depth == 2 && n_tiles > 1) issue_tile(gb + 256 * R, tile0 + 256 * R);  // T >= 2: same env
@@ -147,6 +161,10 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
 #pragma unroll
       for (int i = 0; i < NP; ++i) pv[i] = pn[i];
       pre_env = Sys::template prepare<real>(pv);
+      if (CRIT) {
+#pragma unroll
+        for (int i = 0; i < DCMAX; ++i) wc[i] = wn[i];
+      }
       bestJ = inf_r<real>();
       bestI = 0x7fffffff;
     }
@@ -204,6 +222,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
         if (G1) {
 #pragma unroll
           for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
+        } else if (CRIT && kk == N - 1) {
+          J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], [&](int i) -> real { return wc[i]; }, P.critic_struct);
         } else {
           J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
           gk *= P.gamma;

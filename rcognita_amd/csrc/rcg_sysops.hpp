@@ -184,6 +184,9 @@ struct DevKnobs {
   long lds_pad = 0;  // RCG_LDS_PAD=<bytes>: extra dynamic LDS per block, caps the resident blocks per CU (-1: no cap)
   int per_cu = 0;    // RCG_PER_CU=2|4|8: resident blocks per CU for k_actor_dma (0: by row length)
   int depth = 0;     // RCG_DEPTH=2: two tiles in flight per wave (default: one)
+  bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL goes to k_actor too (the state before the CRIT instances existed)
+  // modes k_actor_dma serves: MPC, and RQL through its CRIT instances; SQL stays on k_actor (measured 18 % faster there)
+  bool dma_serves(int mode) const { return mode == RCG_MODE_MPC || (mode == RCG_MODE_RQL && !mpc_only); }
 };
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
@@ -194,6 +197,7 @@ static inline const DevKnobs& dev_knobs() {
     if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
     if (const char* e = getenv("RCG_PER_CU")) v.per_cu = atoi(e);
     if (const char* e = getenv("RCG_DEPTH")) v.depth = atoi(e);
+    v.mpc_only = getenv("RCG_DMA_MPC_ONLY") != nullptr;
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
     return v;
   }();
@@ -203,27 +207,31 @@ static inline const DevKnobs& dev_knobs() {
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
 // Pick the k_actor_dma<Sys, R> instance for a runtime row length (R = N*du floats, 1..32, multiple of du).
 template <typename Sys, int R>
-static bool launch_dma_r(int r, bool tgt, bool g1, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+static bool launch_dma_r(int r, bool tgt, bool g1, bool crit, dim3 grid, dim3 block, size_t lds, hipStream_t s,
                          const ActorArgs<float>& A, const KParams<float>& P) {
   if constexpr (R > 32) {
     return false;
   } else {
     if (r == R) {
       if constexpr (R % Sys::DU == 0) {
-        if (tgt && g1)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, true>), grid, block, lds, s, A, P);
+        if (crit && tgt)  // RQL / SQL (the gamma == 1 specialisation is an MPC one)
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, false, true>), grid, block, lds, s, A, P);
+        else if (crit)
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, false, true>), grid, block, lds, s, A, P);
+        else if (tgt && g1)
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, true, false>), grid, block, lds, s, A, P);
         else if (tgt)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, false>), grid, block, lds, s, A, P);
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, false, false>), grid, block, lds, s, A, P);
         else if (g1)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, true>), grid, block, lds, s, A, P);
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, true, false>), grid, block, lds, s, A, P);
         else
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, false>), grid, block, lds, s, A, P);
+          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, false, false>), grid, block, lds, s, A, P);
         return true;
       } else {
         return false;
       }
     }
-    return launch_dma_r<Sys, R + 1>(r, tgt, g1, grid, block, lds, s, A, P);
+    return launch_dma_r<Sys, R + 1>(r, tgt, g1, crit, grid, block, lds, s, A, P);
   }
 }
 
@@ -298,8 +306,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool force_plain = knobs.force_plain;
   bool dma_ok = false;
   if constexpr (std::is_same<real, float>::value)
-    dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= 32 && !generic &&
-             A.obs == A.state_sys && !force_plain &&
+    dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= 32 && P.stage_kind == 0 &&
+             knobs.dma_serves(c.mode) && A.obs == A.state_sys && !force_plain &&
              !(A.J && (size_t)4 * 256 * R + (size_t)16 * K > (size_t)64 * 1024);  // J staging must fit next to the tiles
   if (sim_first) {  // the env step of the tick (Simulator.sim_step) precedes the decision
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
@@ -342,7 +350,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
         const size_t want = per_cu <= 2 ? (size_t)56 * 1024 : (per_cu <= 4 ? (size_t)36 * 1024 : 0);
         if (lds_req < want) lds_req = want;
       }
-      if (!launch_dma_r<Sys, 1>(R, tgt, g1, grid, block, lds_req, h->stream, A, P))
+      const bool crit = c.mode == RCG_MODE_RQL;  // the CRIT instances (critic weights travel with the env state)
+      if (!launch_dma_r<Sys, 1>(R, tgt, g1 && !crit, crit, grid, block, lds_req, h->stream, A, P))
         return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d floats", who, R);
       HIPCHK(h, hipGetLastError());
       return RCG_OK;

@@ -128,3 +128,38 @@ def test_rql_sql_control_tick_vs_oracle(name, mode, cs, K, every, dtype):
         env.w_prev = eng.get_field(N.FIELD_W_PREV).astype(np.float64)
         checked += 1
     assert checked >= (T if dtype == "f64" else 1)
+
+
+@pytest.mark.parametrize("cs", [O.CRITIC_QUAD_LIN, O.CRITIC_QUADRATIC, O.CRITIC_QUAD_NOMIX, O.CRITIC_QUAD_MIX])
+@pytest.mark.parametrize("mode", [O.MODE_RQL, O.MODE_SQL])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_streamed_rql_sql_on_the_production_kernel(name, mode, cs):
+    """f32, streamed candidates, K a multiple of 64: RQL runs on k_actor_dma's critic instances (the env's critic
+    weights travel with its state), SQL on k_actor's compile-time-specialised rollout.  _actor_cost of every candidate
+    and the argmin against the float64 oracle, per-env weights, gamma != 1."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(1000 * mode + 10 * cs + len(name))
+    B, K, Nh = 9, 128, 6
+    eng, cfg = both(name, B, "f32", n_actor=Nh, mode=mode, critic_struct=cs, gamma=0.9, n_critic=4, buffer_size=6)
+    x0 = rand_states(rng, name, B).astype(np.float32)
+    eng.set_state(x0)
+    lo, hi = O.critic_bounds(cs, cfg.dc)
+    w = rng.uniform(np.maximum(lo, -2.0), np.minimum(hi, 2.0), (B, cfg.dc)).astype(np.float32)
+    eng.set_field(N.FIELD_W_CRITIC, w)
+    cand = rand_actions(rng, name, (B, K, Nh)).astype(np.float32)
+    x64, w64, c64 = x0.astype(np.float64), w.astype(np.float64), cand.astype(np.float64)
+    J_or = O.actor_cost(c64, x64[:, None, :], x64[:, None, :], cfg, pars=np.asarray(cfg.pars, dtype=np.float64),
+                        w_critic=w64[:, None, :])
+    J = eng.actor_cost(cand)  # W_CRITIC of the handle
+    assert J.shape == (B, K)
+    # signed critic weights make J a difference of large terms: the error is measured against the env's largest |J|
+    # (what an argmin over the row is sensitive to), 1e-5 as everywhere else in f32
+    scale = np.max(np.abs(J_or), axis=1, keepdims=True)
+    assert np.max(np.abs(J - J_or) / scale) < 1e-5
+    a, bj, bi = eng.actor_argmin(cand)
+    ref_i = np.argmin(J_or, axis=1)
+    flipped = bi != ref_i  # an f32 near-tie may pick the runner-up: then its cost must be within rounding of the best
+    for e in np.flatnonzero(flipped):
+        assert abs(J_or[e, bi[e]] - J_or[e, ref_i[e]]) <= 2e-5 * abs(J_or[e, ref_i[e]]) + 1e-6
+    np.testing.assert_array_equal(a[~flipped], cand[np.arange(B), ref_i, 0, :][~flipped])
