@@ -54,6 +54,30 @@ def main():
             "sim_ms": sm / max(sn, 1), "n_failed": summ["n_failed"], "candidates": "generated 256-level grid"}
         eng.close()
 
+    # ---- configs[2] with STREAMED candidates (2.7 GB per tick): MPC / RQL on k_actor_dma, SQL on k_actor --
+    cand_host = rng.random((B, K, Nh, 1), dtype=np.float32)
+    for mode in ("MPC", "RQL", "SQL"):
+        kw = dict(Nactor=Nh, mode=mode, critic_struct="quadratic", Ncritic=4, buffer_size=10 if mode != "MPC" else 0)
+        eng = Engine(preset_engine_config("2tank", B, **kw))
+        eng.set_state(np.stack([rng.uniform(0, 2, B), rng.uniform(-2, 2, B)], axis=-1))
+        cand = eng.to_device(cand_host)
+        for _ in range(a.warmup + 5):
+            eng.control_tick(cand, K=K)
+        eng.profile(True)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.control_tick(cand, K=K)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        am, an = eng.profile_read(N.KERNEL_ACTOR)
+        out[f"C3_2tank_B{B}_N{Nh}_K{K}_{mode}_streamed"] = {
+            "env_control_steps_per_s": B * a.steps / dt, "ms_per_tick": dt / a.steps * 1e3, "actor_ms": am / max(an, 1),
+            "actor_GBps": B * K * Nh * 4 / (am / max(an, 1) * 1e-3) / 1e9}
+        eng.close()
+        del cand
+    del cand_host
+
     # ---- on-device optimiser tick on the C2 shape ------------------------------------
     B2 = 65536
     for iters in (5, 10):
