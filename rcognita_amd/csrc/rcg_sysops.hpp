@@ -184,6 +184,10 @@ struct DevKnobs {
   long lds_pad = 0;  // RCG_LDS_PAD=<bytes>: extra dynamic LDS per block, caps the resident blocks per CU (-1: no cap)
   int per_cu = 0;    // RCG_PER_CU=2|4|8: resident blocks per CU for k_actor_dma (0: by row length)
   int depth = 0;     // RCG_DEPTH=2: two tiles in flight per wave (default: one)
+  // RCG_PLAIN_LDS=<bytes>: minimum dynamic-LDS request of the streamed k_actor, i.e. a residency cap.  Unlike
+  // k_actor_dma, k_actor has no direct-to-LDS prefetch and hides latency with occupancy: 4 blocks/CU measured 7 %
+  // slower than 8, 2 blocks/CU 68 % slower (configs[2], SQL, streamed) - the default is no cap.
+  long plain_lds = 0;
   bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL goes to k_actor too (the state before the CRIT instances existed)
   // modes k_actor_dma serves: MPC, and RQL through its CRIT instances; SQL stays on k_actor (measured 18 % faster there)
   bool dma_serves(int mode) const { return mode == RCG_MODE_MPC || (mode == RCG_MODE_RQL && !mpc_only); }
@@ -197,6 +201,7 @@ static inline const DevKnobs& dev_knobs() {
     if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
     if (const char* e = getenv("RCG_PER_CU")) v.per_cu = atoi(e);
     if (const char* e = getenv("RCG_DEPTH")) v.depth = atoi(e);
+    if (const char* e = getenv("RCG_PLAIN_LDS")) v.plain_lds = atol(e);
     v.mpc_only = getenv("RCG_DMA_MPC_ONLY") != nullptr;
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
     return v;
@@ -294,7 +299,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   int wpb = 4;  // waves per workgroup
   size_t lds_per_wave = cand ? 64 * row_bytes : 0;
   while (wpb > 1 && lds_per_wave * wpb > 64 * 1024) wpb >>= 1;
-  const size_t lds = lds_per_wave * wpb;
+  size_t lds = lds_per_wave * wpb;
+  if (cand && (size_t)dev_knobs().plain_lds > lds) lds = (size_t)dev_knobs().plain_lds;  // residency experiments
   const unsigned blocks = (unsigned)((n_waves + wpb - 1) / wpb);
   const KParams<real>& P = params<real>(h);
   const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
