@@ -121,6 +121,26 @@ def main():
     eng.synchronize()
     dt = time.perf_counter() - t0
     am, an = eng.profile_read(N.KERNEL_ACTOR)
+    # the tick with heterogeneous parameters (m ~ U(5, 20), I ~ U(0.5, 2) per env, [np][B] loads)
+    ech = preset_engine_config("3wrobot", B2, Nactor=Nc)
+    ech.per_env_pars = True
+    engh = Engine(ech)
+    engh.set_field(N.FIELD_PARS, np.stack([rng.uniform(5, 20, B2), rng.uniform(0.5, 2, B2)], axis=-1))
+    engh.set_state(eng.get_state())
+    for _ in range(a.warmup + 20):
+        engh.control_tick(cand, K=Kc)
+    engh.profile(True)
+    engh.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps * 4):
+        engh.control_tick(cand, K=Kc)
+    engh.synchronize()
+    dth = time.perf_counter() - t0
+    amh, anh = engh.profile_read(N.KERNEL_ACTOR)
+    out[f"C2_3wrobot_B{B2}_N{Nc}_K{Kc}_streamed_per_env_pars"] = {
+        "env_control_steps_per_s": B2 * a.steps * 4 / dth, "ms_per_tick": dth / (a.steps * 4) * 1e3,
+        "actor_ms": amh / max(anh, 1)}
+    engh.close()
     per_eval = 4 * (Nc * 2 + 5 + 5 + 1)  # 4 (N du + ds + dy + 1) = 124 B; obs == state_sys here: read once
     out[f"U1_actor_cost_operator_3wrobot_B{B2}_K{Kc}_N{Nc}_streamed"] = {
         "actor_cost_evals_per_s": B2 * Kc * a.steps * 4 / dt, "kernel_ms": am / max(an, 1),
