@@ -133,9 +133,63 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
     }
   };
   // loads one env-state request issues (vmcnt bookkeeping of the depth-2 pipeline)
-  const int n_env_loads = (A.dbg & 4) ? 0 : DS + (A.pars_env ? NP : 0) + (CRIT ? P.dc : 0);
-  fetch_env(env0);
-  issue_tile(gb, tile0);  // after the env request: retiring the env state must not drain the first tile
+  const int n_env_loads =
+      ((A.dbg & 4) || A.sim_state != nullptr) ? 0 : DS + (A.pars_env ? NP : 0) + (CRIT ? P.dc : 0);
+
+  // Fused env step (the tick's Simulator.sim_step in this launch, A.sim_state != nullptr): lane e < ne integrates env
+  // env0 + e - exactly k_sim's arithmetic (rk4_step, clip, freeze on a non-finite state) - while the first tile is in
+  // flight, writes STATE / STATE_PREV / STATUS, and keeps the new state; each env's rollout then starts from
+  // v_readlane of that lane instead of a global load.  Saves the k_sim launch and the state's HBM round trip.
+  const bool fused = A.sim_state != nullptr;
+  real xs[DS], ps[NP > 0 ? NP : 1];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) xs[c] = 0;
+#pragma unroll
+  for (int i = 0; i < (NP > 0 ? NP : 1); ++i) ps[i] = NP > 0 ? P.pars[i] : (real)0;
+  if (fused) {
+    const int ne = (int)(env1 - env0);
+    const bool mine = lane < ne;
+    const long be = env0 + (mine ? lane : 0);
+    real x[DS], xp[DS], u[DU];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) x[c] = A.sim_state[(long)c * B + be];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) u[c] = A.sim_action[(long)c * B + be];
+    const uint32_t st = A.sim_status[be];
+    if (A.pars_env) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) ps[i] = A.pars_env[(long)i * B + be];
+    }
+    issue_tile(gb, tile0);  // after the requests above: using them must not wait for the tile
+#pragma unroll
+    for (int c = 0; c < DU; ++c) u[c] = P.clip ? clamp_r<real>(u[c], P.lo[c], P.hi[c]) : u[c];  // systems.py:241-243
+#pragma unroll
+    for (int c = 0; c < DS; ++c) xs[c] = xp[c] = x[c];
+    if (mine && !(st & 1u)) {  // frozen envs keep their state
+      const auto pre = Sys::template prepare<real>(ps);
+      for (int s = 0; s < A.sim_nsub; ++s) {
+#pragma unroll
+        for (int c = 0; c < DS; ++c) xp[c] = x[c];
+        rk4_step<Sys, real>(pre, x, u, P.dt_sim);
+      }
+      bool ok = true;
+#pragma unroll
+      for (int c = 0; c < DS; ++c) ok = ok && finite_r<real>(x[c]);
+      if (!ok) {  // freeze the env at its last finite state and flag it (as k_sim)
+        A.sim_status[be] = st | 1u;
+      } else {
+#pragma unroll
+        for (int c = 0; c < DS; ++c) {
+          A.sim_state[(long)c * B + be] = x[c];
+          A.sim_state_prev[(long)c * B + be] = xp[c];
+          xs[c] = x[c];
+        }
+      }
+    }
+  } else {
+    fetch_env(env0);
+    issue_tile(gb, tile0);  // after the env request: retiring the env state must not drain the first tile
+  }
   if (depth == 2 && n_tiles > 1) issue_tile(gb + 256 * R, tile0 + 256 * R);  // T >= 2: same env
 
   const real h = P.h_pred;
@@ -155,11 +209,21 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
   for (int c = 0; c < DU; ++c) resU[c] = 0;
 
   for (int g = 0; g < n_tiles; ++g) {
-    if (t == 0) {  // first tile of env b: adopt the state requested one tile ago
+    if (t == 0) {  // first tile of env b: adopt the state requested one tile ago / integrated in the prologue
+      if (fused) {
+        const int e = __builtin_amdgcn_readfirstlane((int)(b - env0));
 #pragma unroll
-      for (int c = 0; c < DS; ++c) y0[c] = yn[c];
+        for (int c = 0; c < DS; ++c)
+          y0[c] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xs[c]), e));
 #pragma unroll
-      for (int i = 0; i < NP; ++i) pv[i] = pn[i];
+        for (int i = 0; i < NP; ++i)
+          pv[i] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(ps[i]), e));
+      } else {
+#pragma unroll
+        for (int c = 0; c < DS; ++c) y0[c] = yn[c];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pv[i] = pn[i];
+      }
       pre_env = Sys::template prepare<real>(pv);
       if (CRIT) {
 #pragma unroll
@@ -187,7 +251,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
     //    prefetched state, i.e. with a wait for it)
     gb += 256 * R;
     if (g + depth < n_tiles) {
-      if (t == T - depth) fetch_env(b + 1);  // tile g + depth is the first tile of env b + 1 (depth 2: T >= 2)
+      if (t == T - depth && !fused) fetch_env(b + 1);  // tile g + depth opens env b + 1 (depth 2: T >= 2)
       issue_tile(gb + (depth - 1) * (256 * R), tile);
     }
 

@@ -184,6 +184,7 @@ struct DevKnobs {
   long lds_pad = 0;  // RCG_LDS_PAD=<bytes>: extra dynamic LDS per block, caps the resident blocks per CU (-1: no cap)
   int per_cu = 0;    // RCG_PER_CU=2|4|8: resident blocks per CU for k_actor_dma (0: by row length)
   int depth = 0;     // RCG_DEPTH=2: two tiles in flight per wave (default: one)
+  bool fuse_sim = false;  // RCG_FUSE_SIM=1: the tick's env step runs in k_actor_dma's prologue (see launch_actor)
   // RCG_PLAIN_LDS=<bytes>: minimum dynamic-LDS request of the streamed k_actor, i.e. a residency cap.  Unlike
   // k_actor_dma, k_actor has no direct-to-LDS prefetch and hides latency with occupancy: 4 blocks/CU measured 7 %
   // slower than 8, 2 blocks/CU 68 % slower (configs[2], SQL, streamed) - the default is no cap.
@@ -201,6 +202,7 @@ static inline const DevKnobs& dev_knobs() {
     if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
     if (const char* e = getenv("RCG_PER_CU")) v.per_cu = atoi(e);
     if (const char* e = getenv("RCG_DEPTH")) v.depth = atoi(e);
+    v.fuse_sim = getenv("RCG_FUSE_SIM") != nullptr;
     if (const char* e = getenv("RCG_PLAIN_LDS")) v.plain_lds = atol(e);
     v.mpc_only = getenv("RCG_DMA_MPC_ONLY") != nullptr;
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
@@ -315,7 +317,13 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= 32 && P.stage_kind == 0 &&
              knobs.dma_serves(c.mode) && A.obs == A.state_sys && !force_plain &&
              !(A.J && (size_t)4 * 256 * R + (size_t)16 * K > (size_t)64 * 1024);  // J staging must fit next to the tiles
-  if (sim_first) {  // the env step of the tick (Simulator.sim_step) precedes the decision
+  // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
+  // RCG_FUSE_SIM=1 fuses it into k_actor_dma's prologue instead (same rk4_step code: every field bit-identical over a
+  // 7-tick ragged run) - measured a wash: the kernel gets 3-4 % slower (each wave integrates its envs in front of its
+  // first tile, not hidden at 2 waves per SIMD), the tick 0.206-0.210 ms against 0.2055-0.208 ms.  Off by default.
+  const bool fuse_sim = sim_first && dma_ok && knobs.fuse_sim &&
+                        !(c.flags & (RCG_FLAG_DISTURB | RCG_FLAG_ACCUM_EVERY_SUBSTEP));
+  if (sim_first && !fuse_sim) {
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
     if (rc) return rc;
   }
@@ -346,7 +354,14 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       // at least two tiles and no per-candidate J store inside the loop, because stores and loads retire out of order
       // with respect to each other).  Measured 1.5-3 % SLOWER than one tile in flight on C2 and on N = 5, K = 128,
       // K = 512 (+0.7 % only at N = 16): the default stays 1.
-      A.depth = (knobs.depth == 2 && K >= 128 && !A.J) ? 2 : 1;
+      A.depth = (knobs.depth == 2 && K >= 128 && !A.J && !fuse_sim) ? 2 : 1;  // (the fused step's stores: as J)
+      if (fuse_sim) {
+        A.sim_state = (float*)h->f[RCG_FIELD_STATE];
+        A.sim_state_prev = (float*)h->f[RCG_FIELD_STATE_PREV];
+        A.sim_action = (const float*)h->f[RCG_FIELD_ACTION];
+        A.sim_status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+        A.sim_nsub = c.substeps_per_tick;
+      }
       // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
       A.jwave = (A.J && (size_t)4 * 256 * R * A.depth + (size_t)16 * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
       size_t lds_req = (size_t)4 * 256 * R * A.depth + (A.J ? (size_t)16 * K * (A.jwave ? gpw : 1) : 0);

@@ -1,0 +1,34 @@
+"""Helper of tests/test_hip_knobs.py (not a test module): a short streamed closed loop on a ragged batch, printed as
+one hash over every per-env field.  The development knobs of the launcher (RCG_*) are read once per process, so each
+variant runs in its own interpreter."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import preset_engine_config
+
+    rng = np.random.default_rng(5)
+    B, K, Nh = 32773, 128, 5  # several envs per wave, a ragged last wave, two tiles per env
+    eng = Engine(preset_engine_config("3wrobot", B, Nactor=Nh))
+    x0 = np.stack([rng.uniform(-10, 10, B), rng.uniform(-10, 10, B), rng.uniform(-3, 3, B), rng.uniform(-1, 1, B),
+                   rng.uniform(-1, 1, B)], -1).astype(np.float32)
+    eng.set_state(x0)
+    cand = eng.to_device((rng.random((B, K, Nh, 2), dtype=np.float32) - 0.5) * np.array([600, 200], dtype=np.float32))
+    for _ in range(5):
+        eng.control_tick(cand, K=K)
+    h = hashlib.sha256()
+    for f in (N.FIELD_STATE, N.FIELD_STATE_PREV, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_STEP_IDX, N.FIELD_BEST_IDX,
+              N.FIELD_BEST_J, N.FIELD_STATUS):
+        h.update(np.ascontiguousarray(eng.get_field(f)).tobytes())
+    print("HASH", h.hexdigest())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,35 @@
+"""The launcher's opt-in kernel variants (development knobs, rcg_sysops.hpp::DevKnobs) must reproduce the default
+launch BIT FOR BIT: same arithmetic, different scheduling.  Each variant is a separate process (the knobs are read once
+per process).  ``gpu`` marked."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(env_extra):
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("RCG_") and k != "RCG_LIB":
+            del env[k]
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "knob_probe.py")], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("HASH ")]
+    assert line, out.stdout
+    return line[-1]
+
+
+def test_scheduling_variants_are_bit_identical():
+    base = _run({})
+    for knobs in ({"RCG_FUSE_SIM": "1"},                     # env step fused into the actor kernel's prologue
+                  {"RCG_DEPTH": "2"},                        # two tiles in flight per wave
+                  {"RCG_GPW": "1", "RCG_LDS_PAD": "-1"},     # one env per wave, no residency cap (the first geometry)
+                  {"RCG_GPW": "16", "RCG_PER_CU": "4"}):
+        assert _run(knobs) == base, knobs
