@@ -176,7 +176,12 @@ static int op_critic_update(rcg_handle* h, int32_t do_fit) {
 // Development knobs of the actor launcher, read from the environment ONCE per process (they select between variants
 // of the same computation for A/B measurements; none of them changes results beyond rounding):
 //   RCG_ACTOR_KERNEL=plain  force k_actor instead of k_actor_dma      RCG_GPW=<n>  envs per persistent wave
-//   RCG_DBG=1               timing-only variant (rollout skipped)      RCG_NO_G1=1  no gamma == 1 specialisation
+//   RCG_DBG=<bits>          1 skip the rollout, 2 skip argmin + writes, 4 skip env-state loads (timing only: wrong results)
+//   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL on k_actor
+//   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
+//   RCG_DEPTH=2             two tiles in flight per wave               RCG_FUSE_SIM=1  env step in the actor's prologue
+//   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor
+// tests/test_hip_knobs.py checks that the scheduling variants reproduce the default launch bit for bit.
 struct DevKnobs {
   int dbg = 0;
   bool force_plain = false, no_g1 = false;
