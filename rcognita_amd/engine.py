@@ -9,7 +9,7 @@ Host-side arrays use the reference's natural shapes with a leading batch axis (`
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import numpy as np

@@ -9,7 +9,7 @@ so nothing here imports torch on its own.
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 
