@@ -300,6 +300,37 @@ def test_control_tick_closed_loop_vs_oracle(name, K, streamed, ref_lag, dtype):
     assert checked >= (T if dtype == "f64" else 1)
 
 
+@pytest.mark.parametrize("name,K", [("3wrobot", 64), ("2tank", 32)])
+def test_long_closed_loop_f64_vs_oracle(name, K):
+    """400 consecutive ticks (with two episode resets on the way) of the float64 build against the oracle: the argmin
+    sequence identical, state / accum / returns to 1e-9, int32 counters exact - no drift, no bookkeeping slip."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(77)
+    B, Nh, T = 24, 10, 400
+    eng, cfg = both(name, B, "f64", n_actor=Nh)
+    x0 = rand_states(rng, name, B)
+    eng.set_state(x0)
+    env = O.new_batch(cfg, x0)
+    grid = O.grid_candidates(cfg, K)
+    for t in range(T):
+        eng.control_tick(None, K=K)
+        O.control_tick(cfg, env, grid)
+        if t % 50 == 49:
+            np.testing.assert_array_equal(eng.get_field(N.FIELD_BEST_IDX), env.best_idx)
+            assert rel_err_norm(eng.get_state(), env.state) < 1e-9, t
+        if t in (149, 299):  # episode boundary: returns := accum, state := state_init, counters
+            ret = env.accum.copy()
+            eng.episode_reset()
+            env = O.new_batch(cfg, x0)
+            env.episode_idx = np.full(B, 1 if t == 149 else 2, dtype=np.int32)
+            np.testing.assert_allclose(eng.get_field(N.FIELD_RETURNS), ret, rtol=1e-9)
+            np.testing.assert_array_equal(eng.get_field(N.FIELD_EPISODE_IDX), env.episode_idx)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, 100, np.int32))
+    assert rel_err_norm(eng.get_state(), env.state) < 1e-9
+    assert rel_err_norm(eng.get_field(N.FIELD_ACCUM), env.accum, floor=float(np.max(np.abs(env.accum)))) < 1e-9
+
+
 def test_accum_every_substep_flag():
     from rcognita_amd import _native as N
 
