@@ -180,6 +180,28 @@ def main():
     out[f"f4_disturbed_MPC_tick_3wrobot_B{B2}_N10_K256_generated"] = timed(eng, lambda: eng.control_tick(None, K=256))
     eng.close()
 
+    # ---- the pure env step (Simulator.sim_step = k_sim) where it is bandwidth-bound: 2^24 envs ----------------
+    for name, ds, du in (("3wrobot", 5, 2), ("2tank", 2, 1)):
+        Bs = 1 << 24
+        eng = Engine(preset_engine_config(name, Bs, Nactor=3))
+        x = rng.uniform(-1, 1, (Bs, ds)).astype(np.float32)
+        eng.set_state(np.abs(x) + 0.1 if name == "2tank" else x)
+        eng.set_field(N.FIELD_ACTION, np.full((Bs, du), 0.3, np.float32))
+        del x
+        for _ in range(20):
+            eng.sim_step(1)
+        eng.profile((N.KERNEL_SIM,), stride=1)
+        eng.synchronize()
+        for _ in range(50):
+            eng.sim_step(1)
+        eng.synchronize()
+        ms, n = eng.profile_read(N.KERNEL_SIM)
+        bytes_env = (3 * ds + du) * 4 + 4  # read state, action, status; write state, state_prev
+        out[f"sim_step_only_{name}_B{Bs}"] = {"env_steps_per_s": Bs / (ms / n * 1e-3), "kernel_ms": ms / n,
+                                              "kernel_GBps": Bs * bytes_env / (ms / n * 1e-3) / 1e9,
+                                              "bytes_per_env_step": bytes_env}
+        eng.close()
+
     # ---- configs[4], one GPU's shard -----------------------------------------------------------------
     total = 65536
     counts = {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
