@@ -196,6 +196,8 @@ def main():
     # HIP events around the kernels of the tick on the engine's own stream, inside the timed region; sampled
     # (every n-th launch) because each event is a marker packet on the stream.
     if args.profile_stride > 0:
+        if args.steps // args.profile_stride < 8:  # short runs: time (almost) every launch rather than none
+            args.profile_stride = max(1, args.steps // 8)
         eng.profile((N.KERNEL_ACTOR, N.KERNEL_SIM), stride=args.profile_stride)
     barrier()
     t0 = time.perf_counter()
