@@ -41,6 +41,25 @@ def test_optimizer_vs_oracle_and_reference_slsqp(name, dtype):
         assert rel_err_norm(J, J_or) < 2e-4
 
 
+@pytest.mark.parametrize("dtype,N", [("f64", 16), ("f64", 24), ("f32", 30)])
+def test_optimizer_long_horizons_large_lds(dtype, N):
+    """Horizons whose per-block LDS (u, d, states of 16 envs x 4 waves) exceeds the 64 KB default limit: the launcher
+    raises the kernel's dynamic-LDS attribute (f64: N = 16 needs 80 KB, N = 24 119 KB; f32: N = 30 74 KB).  Result
+    against the oracle twin; a ragged batch (B = 37: a wave with 5 of its 16 envs)."""
+    rng = np.random.default_rng(N)
+    B = 37
+    eng, cfg = both("3wrobot", B, dtype, n_actor=N)
+    x = rand_states(rng, "3wrobot", B)
+    eng.set_state(x)
+    act, U, J, its = eng.actor_optimize(iters=4)
+    xin = x.astype(eng.real).astype(np.float64)
+    J_chk = O.actor_cost(U.astype(np.float64), xin, xin, cfg)
+    assert rel_err_norm(J, J_chk) < (1e-10 if dtype == "f64" else 1e-5)
+    U_or, J_or, its_or = O.actor_optimize(cfg, xin, xin, O.action_sqn_init(cfg, None), iters=4)
+    assert rel_err_norm(J, J_or) < (1e-9 if dtype == "f64" else 5e-4)
+    assert np.all(J <= O.actor_cost(np.tile(O.action_sqn_init(cfg, None), (B, 1, 1)), xin, xin, cfg) * (1 + 1e-6))
+
+
 @pytest.mark.parametrize("warm", [False, True])
 @pytest.mark.parametrize("name,N,ref_lag", [("3wrobot", 6, False), ("3wrobotNI", 4, True), ("2tank", 9, False)])
 def test_control_tick_opt_closed_loop_vs_oracle(name, N, ref_lag, warm):
