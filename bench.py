@@ -1,46 +1,62 @@
 #!/usr/bin/env python3
 """bench.py - env.control-steps/sec of the rcognita hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4|C5] [--scaling weak|strong]
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): Sys3WRobot, B = 65536 envs per GPU, RK4
+Workload, default (BASELINE.json configs[1], SURVEY.md 8d "C2"): Sys3WRobot, B = 65536 envs per GPU, RK4
 dt = 0.01 (one substep per control tick), CtrlOptPred MPC, Nactor = 10, K = 256 candidate action
 sequences per env streamed from HBM as a [B][K][N][du] f32 tensor (the `_actor_cost(action_sqn, obs)`
 operator shape).  One "step" = one env.control-step (unit U2) for every env of the batch:
-rcg_control_tick = k_sim (closed_loop_rhs under RK4) + k_actor (K rollouts + argmin + accum update).
+rcg_control_tick = k_sim (closed_loop_rhs under RK4) + k_actor_dma (K rollouts + argmin + accum update).
 Inputs are synthetic and resident in HBM before the timed region.
+  --config C4   configs[3]: 524288 Sys3WRobot envs in total, sharded over the ranks (strong scaling unless
+                --scaling weak), ONE all_gather of the per-env episode returns over RCCL in the timed region.
+  --config C5   configs[4]: mixed pool 3wrobot + 3wrobot_NI + 2tank, 65536 envs per GPU sharded within each type,
+                Nactor = 15, 256 generated candidates per env (VALU-bound regime).
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel k_actor: algorithmic bytes
-per launch (DESIGN.md "Bytes") / its mean duration measured with HIP events on the engine's stream
-inside the timed region.  `cpu_baseline` is the C oracle (oracle/oracle.c, kind "port") timed on this
-box's host cores on a bounded sample of the same workload.
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` from a plain shell starts the N ranks itself (the parent
+never touches the GPU: it spawns N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits,
+relays rank 0's JSON line and fails if any rank fails); under torchrun (`WORLD_SIZE` already set) the process IS a rank.
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel: algorithmic bytes per launch
+/ its mean duration measured with HIP events on the engine's own stream inside the timed region.  `parity` compares
+outputs of the same run's kernels with the CPU oracle.  `cpu_baseline` is the C oracle (oracle/oracle.c, kind "port")
+timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6.29e12 measured copy)
+HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6.29e12 measured copy)
+VALU_PEAK = 7.9e13  # f32 lane-instructions/s: 256 CUs x 4 SIMDs x 32 lanes/clk... = 157.3 TFLOP/s FMA / 2
+PRESPIN_S = 0.35    # untimed clock pre-spin: the first launches after the GPU wakes run 10-25 % slower
+C4_TOTAL_ENVS = 524288
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=500)
     p.add_argument("--warmup", type=int, default=100)
-    p.add_argument("--batch", type=int, default=65536, help="envs per GPU (weak scaling)")
+    p.add_argument("--config", choices=["C2", "C4", "C5"], default="C2",
+                   help="BASELINE.json configs[1] (default, the metric's config), configs[3], configs[4]")
+    p.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                   help="weak: --batch envs per GPU; strong: --batch envs in total (default: weak, C4: strong)")
+    p.add_argument("--batch", type=int, default=None, help="envs per GPU (weak) or in total (strong)")
     p.add_argument("--candidates", type=int, default=256, help="K candidate sequences per env")
-    p.add_argument("--nactor", type=int, default=10)
-    p.add_argument("--regime", choices=["streamed", "generated"], default="streamed")
+    p.add_argument("--nactor", type=int, default=None, help="horizon (default 10; C5: 15)")
+    p.add_argument("--regime", choices=["streamed", "generated"], default=None)
     p.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true")
+    p.add_argument("--no-parity", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                    help="nccl = RCCL over xGMI (the real thing); gloo only to exercise the N>1 code path on one GPU")
@@ -48,54 +64,155 @@ def parse():
                    help="debug: every rank uses cuda:0 (with --dist-backend gloo), to test the N>1 path on a 1-GPU box")
     p.add_argument("--profile-stride", type=int, default=8,
                    help="bracket every n-th kernel launch of the timed region with HIP events (0 = none)")
-    return p.parse_args()
+    p.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds the parent waits for its ranks")
+    p.add_argument("--dry-launch", action="store_true",
+                   help="ranks only rendezvous (gloo, CPU) and report their environment: tests the launcher without a GPU")
+    a = p.parse_args(argv)
+    if a.scaling is None:
+        a.scaling = "strong" if a.config == "C4" else "weak"
+    if a.batch is None:
+        a.batch = C4_TOTAL_ENVS if (a.config == "C4" and a.scaling == "strong") else 65536
+    if a.nactor is None:
+        a.nactor = 15 if a.config == "C5" else 10
+    if a.regime is None:
+        a.regime = "generated" if a.config == "C5" else "streamed"
+    if a.config == "C5" and a.regime != "generated":
+        p.error("--config C5 is the generated-candidate workload (BASELINE configs[4]: 256-candidate grid search)")
+    return a
 
 
-def make_engine(args, device, batch=None):
-    from rcognita_amd import Engine, EngineConfig
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: the parent of `python bench.py --gpus N` (never imports torch / librcg, never touches the GPU)
+# ---------------------------------------------------------------------------------------------------------------
+def refuse_dev_knobs():
+    """Result- or schedule-changing developer knobs of librcg (rcg_sysops.hpp::DevKnobs, _native.RCG_LIB) must not be
+    set for a measurement: the bench line is quoted for the library as shipped."""
+    bad = sorted(k for k in os.environ if k.startswith("RCG_"))
+    if bad:
+        raise SystemExit(f"bench.py: refusing to measure with developer knobs set in the environment: {', '.join(bad)} "
+                         "(unset them; A/B experiments belong in tools/)")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args, argv):
+    """Start args.gpus ranks of this script (one process per GPU), wait, relay rank 0's stdout."""
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RCG_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    deadline = time.monotonic() + args.launch_timeout
+    outs = [None] * n
+    failed = None
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            try:
+                outs[r] = procs[r].communicate(timeout=0.2)
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    failed = r
+                    break
+            except subprocess.TimeoutExpired:
+                pass
+        if time.monotonic() > deadline:
+            failed = -1
+            break
+    if failed is not None:  # one rank died or the job timed out: stop exactly the processes started above
+        for r in pending:
+            procs[r].kill()
+        for r in pending:
+            outs[r] = procs[r].communicate()
+        who = "timeout" if failed < 0 else f"rank {failed} exited with {procs[failed].returncode}"
+        sys.stderr.write(f"bench.py launcher: {who}\n")
+        for r in range(n):
+            if outs[r] and outs[r][1]:
+                sys.stderr.write(f"--- rank {r} stderr (tail) ---\n{outs[r][1][-3000:]}\n")
+        return 1
+    for r in range(1, n):
+        if outs[r][1]:
+            sys.stderr.write(outs[r][1][-2000:])
+    sys.stderr.write(outs[0][1][-4000:] if outs[0][1] else "")
+    sys.stdout.write(outs[0][0])
+    sys.stdout.flush()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workload pieces
+# ---------------------------------------------------------------------------------------------------------------
+def c2_engine_config(args, device, batch, dtype=None, env_id_base=0):
+    import numpy as np
+
+    from rcognita_amd import EngineConfig
     from rcognita_amd import _native as N
 
     bnds = np.array([[-300.0, 300.0], [-100.0, 100.0]])  # presets/main_3wrobot.py:207-211
     R1 = np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0])  # presets/main_3wrobot.py R1_diag default
-    cfg = EngineConfig(sys_id=N.SYS_3WROBOT, batch=batch or args.batch, dtype=args.dtype, device=device,
-                       Nactor=args.nactor, mode="MPC", pars=[10.0, 1.0], ctrl_bnds=bnds, R1=R1, gamma=1.0,
-                       dt_sim=0.01, sampling_time=0.01, pred_step_size=0.02, substeps_per_tick=1)
-    return Engine(cfg), bnds, R1
+    return EngineConfig(sys_id=N.SYS_3WROBOT, batch=batch, dtype=dtype or args.dtype, device=device,
+                        Nactor=args.nactor, mode="MPC", pars=[10.0, 1.0], ctrl_bnds=bnds, R1=R1, gamma=1.0,
+                        dt_sim=0.01, sampling_time=0.01, pred_step_size=0.02, substeps_per_tick=1,
+                        env_id_base=env_id_base), bnds
 
 
-def synth_state(rank, B):
-    """seed 1234 + rank; x,y ~ U(-10,10), alpha ~ U(-pi,pi), v, omega ~ U(-1,1)."""
-    rng = np.random.default_rng(1234 + rank)
-    return np.stack([rng.uniform(-10, 10, B), rng.uniform(-10, 10, B), rng.uniform(-np.pi, np.pi, B),
-                     rng.uniform(-1, 1, B), rng.uniform(-1, 1, B)], axis=-1)
+def c2_oracle_cfg(args):
+    import numpy as np
+
+    from oracle import rcg_oracle as O
+
+    bnds = np.array([[-300.0, 300.0], [-100.0, 100.0]])
+    return O.OracleCfg(sys_id=O.SYS_3WROBOT, n_actor=args.nactor, pars=[10.0, 1.0], ctrl_bnds=bnds,
+                       R1=np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0]), gamma=1.0, dt_sim=0.01, sampling_time=0.01,
+                       pred_step_size=0.02)
 
 
-def actor_bytes_per_launch(B, K, N, du, ds, esz, streamed, fused_sim):
-    """Algorithmic HBM bytes of one actor launch in tick mode (DESIGN.md 'Bytes')."""
+def synth_state(seed, lo, hi):
+    """x,y ~ U(-10,10), alpha ~ U(-pi,pi), v, omega ~ U(-1,1); the job's env g always gets the same
+    state whatever the number of ranks (generated for the whole job, sliced to this rank's [lo, hi))."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    n = hi
+    x = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-np.pi, np.pi, n),
+                  rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], axis=-1)
+    return x[lo:hi]
+
+
+def actor_bytes_per_launch(B, K, N, du, ds, esz, streamed):
+    """Algorithmic HBM bytes of one actor launch in tick mode."""
     per_env = ds * esz  # state read (obs == state_sys)
     per_env += du * esz + esz + 4  # action, best_J, best_idx writes
     per_env += 2 * esz + 2 * 4  # accum and step_idx read-modify-write
     if streamed:
         per_env += K * N * du * esz  # the candidate rows
-    if fused_sim:  # env step inside the launch: held action + status read, state + state_prev written
-        per_env += du * esz + 4 + 2 * ds * esz
     return B * per_env
 
 
 def cpu_baseline(args, seconds):
     """C oracle (port of the same algorithm, f64) on the host cores, bounded sample of the workload."""
+    import numpy as np
+
     from oracle import c_oracle as CO
     from oracle import rcg_oracle as O
 
     threads = CO.max_threads()
-    bnds = np.array([[-300.0, 300.0], [-100.0, 100.0]])
-    cfg = O.OracleCfg(sys_id=O.SYS_3WROBOT, n_actor=args.nactor, pars=[10.0, 1.0], ctrl_bnds=bnds,
-                      R1=np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0]), gamma=1.0, dt_sim=0.01, sampling_time=0.01,
-                      pred_step_size=0.02)
+    cfg = c2_oracle_cfg(args)
+    bnds = cfg.ctrl_bnds
     K = args.candidates
     Bc = 256 * threads
     rng = np.random.default_rng(99)
-    cb = CO.CBatch(cfg, synth_state(0, Bc))
+    cb = CO.CBatch(cfg, synth_state(1234, 0, Bc))
     if args.regime == "streamed":
         cand = bnds[:, 0] + (bnds[:, 1] - bnds[:, 0]) * rng.random((Bc, K, args.nactor, 2))
     else:
@@ -112,16 +229,20 @@ def cpu_baseline(args, seconds):
             "sample": f"{Bc} envs x {ticks + 1} ticks, K={K}, Nactor={args.nactor}, C oracle f64 + OpenMP, {dt:.1f} s"}
 
 
+# the reference itself (imported from /root/reference in the build container, SciPy RK45 + SLSQP, one env, one core)
+# ran 3.4 control steps/s at this horizon there; oracle/ref_loop.py - the same algorithm over the
+# oracle's operators, pinned on the reference's F7 traces - ran 3.3 in the same container: calibration ratio 0.97
+REF_IN_BUILD_CONTAINER = {"reference_steps_per_s_per_core": 3.4, "ref_loop_steps_per_s_per_core": 3.3}
+
+
 def cpu_reference_algorithm(args, seconds):
     """The reference ALGORITHM on one host core: one env, SciPy RK45 + SLSQP over the oracle's operators
     (oracle/ref_loop.py, pinned on traces captured from the reference).  Bounded by wall time."""
-    from oracle import rcg_oracle as O
+    import numpy as np
+
     from oracle.ref_loop import RefLoop
 
-    bnds = np.array([[-300.0, 300.0], [-100.0, 100.0]])
-    cfg = O.OracleCfg(sys_id=O.SYS_3WROBOT, n_actor=args.nactor, pars=[10.0, 1.0], ctrl_bnds=bnds,
-                      R1=np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0]), gamma=1.0, dt_sim=0.01, sampling_time=0.01,
-                      pred_step_size=0.02)
+    cfg = c2_oracle_cfg(args)
     loop = RefLoop(cfg, np.array([5.0, 5.0, -3 * np.pi / 4, 0.0, 0.0]), t1=1e9)
     t0 = time.perf_counter()
     ticks, last = 0, None
@@ -132,25 +253,123 @@ def cpu_reference_algorithm(args, seconds):
             ticks += 1
         last = act
     dt = time.perf_counter() - t0
+    cal = REF_IN_BUILD_CONTAINER
     return {"value": ticks / dt, "unit": "env-control-steps/s", "cores": 1, "kind": "reference algorithm "
             "(SciPy RK45 + SLSQP over the oracle's operators, preset main_3wrobot)",
-            "sample": f"1 env, {ticks} control ticks, {loop.nfev_actor} _actor_cost evaluations, {dt:.1f} s"}
+            "sample": f"1 env, {ticks} control ticks, {loop.nfev_actor} _actor_cost evaluations, {dt:.1f} s",
+            "calibration": {**cal, "ref_loop_over_reference": cal["ref_loop_steps_per_s_per_core"] /
+                            cal["reference_steps_per_s_per_core"],
+                            "note": "measured in the build container, where the reference can be imported; it cannot "
+                                    "travel to this box"}}
 
 
-def main():
-    args = parse()
+def parity_check(args, device, stream_ptr, x0, cand, K, tol=1e-5, n_sample=64, ticks=2):
+    """A fresh run of the SAME kernels on the SAME inputs (this rank's states and candidate tensor), `ticks` control
+    ticks, compared tick by tick with the CPU oracle on a sample of envs (oracle/parity.py: tie-aware best_idx, state /
+    action / best_J / accum within `tol`, int32 step counters exact).  f32 tolerance: the north star's 1e-5."""
+    import numpy as np
+
+    from oracle import parity as PAR
+    from oracle import rcg_oracle as O
+    from rcognita_amd import Engine
+    from rcognita_amd import _native as N
+
+    B = x0.shape[0]
+    ecfg, _ = c2_engine_config(args, device, B)
+    eng = Engine(ecfg)
+    eng.set_stream(stream_ptr)
+    eng.set_state(x0)
+    ocfg = c2_oracle_cfg(args)
+    sel = np.sort(np.random.default_rng(7).choice(B, min(n_sample, B), replace=False))
+    real = np.float32 if args.dtype == "f32" else np.float64
+    env = O.new_batch(ocfg, x0[sel].astype(real).astype(np.float64))
+    if cand is not None:
+        import torch
+
+        cand_host = cand[torch.as_tensor(sel, device=cand.device)].cpu().numpy().astype(np.float64)
+    else:
+        cand_host = O.grid_candidates(ocfg, K)
+    rep = PAR.TickReport()
+    tol = tol if args.dtype == "f32" else 1e-11
+    try:
+        for t in range(ticks):
+            eng.control_tick(cand, K=K)
+            dev = {k: v[sel] for k, v in PAR.device_fields(eng, N).items()}
+            env = PAR.check_tick(ocfg, env, cand_host, dev, tol=tol, report=rep, what=f"bench parity tick {t}")
+        out = {"ok": True, "tol": tol, **rep.as_dict()}
+    except AssertionError as e:
+        out = {"ok": False, "tol": tol, "error": str(e)[:500], **rep.as_dict()}
+    eng.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def dry_rank(args, rank, local_rank, world):
+    """--dry-launch: rendezvous over gloo on the CPU and report what the launcher handed to each rank."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    mine = torch.tensor([rank, local_rank, os.getpid()], dtype=torch.int64)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    from rcognita_amd.parallel import shard_range
+
+    lo, hi = shard_range(args.batch if args.scaling == "strong" else args.batch * world, rank, world)
+    span = torch.tensor([lo, hi], dtype=torch.int64)
+    spans = [torch.empty_like(span) for _ in range(world)]
+    dist.all_gather(spans, span)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(),
+                          "launcher": os.environ.get("RCG_BENCH_LAUNCHER", "external"),
+                          "ranks": [{"rank": int(p[0]), "local_rank": int(p[1]), "pid": int(p[2]),
+                                     "envs": [int(s[0]), int(s[1])]} for p, s in zip(parts, spans)],
+                          "scaling": args.scaling, "config": args.config}))
+    dist.destroy_process_group()
+
+
+def pool_states(rng, name, n):
+    """Synthetic initial states of the mixed pool, per system type."""
+    import numpy as np
+
+    if name == "3wrobot":
+        return np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-np.pi, np.pi, n),
+                         rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], axis=-1)
+    if name == "3wrobotNI":
+        return np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-np.pi, np.pi, n)], axis=-1)
+    return np.stack([rng.uniform(0, 2, n), rng.uniform(-2, 2, n)], axis=-1)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    launcher = os.environ.pop("RCG_BENCH_LAUNCHER", None)  # set by launch() for its children only; not a library knob
+    refuse_dev_knobs()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher and must not initialise the GPU
+        sys.exit(launch(args, argv))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world > 1:
         args.gpus = world
+    launcher = ("bench.py self-spawn" if launcher else ("torchrun/external" if world > 1 else "single process"))
+    if args.dry_launch:
+        os.environ["RCG_BENCH_LAUNCHER"] = launcher
+        return dry_rank(args, rank, local_rank, world)
 
+    import numpy as np
     import torch  # device memory for the synthetic candidates, stream, torch.distributed (plumbing)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     if args.single_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} device(s) "
+                         "are visible (use --single-device --dist-backend gloo to exercise the N>1 path on one GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
     coll_dev = torch.device("cuda", local_rank)  # where collective payloads live
@@ -164,23 +383,16 @@ def main():
             coll_dev = torch.device("cpu")
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
+    from rcognita_amd import Engine
     from rcognita_amd import _native as N
-    from rcognita_amd.parallel import gather_summaries
+    from rcognita_amd.parallel import gather_summaries, merge_summaries, shard_range
 
-    B, K, Nh, du, ds = args.batch, args.candidates, args.nactor, 2, 5
-    eng, bnds, _ = make_engine(args, local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_state(synth_state(rank, B))
+    K, Nh = args.candidates, args.nactor
+    total_envs = args.batch if args.scaling == "strong" else args.batch * world
+    stream_ptr = torch.cuda.current_stream().cuda_stream
     tdtype = torch.float32 if args.dtype == "f32" else torch.float64
     esz = 4 if args.dtype == "f32" else 8
-    cand = None
-    if args.regime == "streamed":
-        g = torch.Generator(device="cuda")
-        g.manual_seed(1234 + rank)
-        lo = torch.tensor(bnds[:, 0], device="cuda", dtype=tdtype)
-        hi = torch.tensor(bnds[:, 1], device="cuda", dtype=tdtype)
-        cand = torch.rand((B, K, Nh, du), generator=g, device="cuda", dtype=tdtype) * (hi - lo) + lo
-        cand = cand.contiguous()
+    streamed = args.regime == "streamed"
 
     def barrier():
         torch.cuda.synchronize()
@@ -188,24 +400,73 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- this rank's shard of the job -----------------------------------------------------------------------------
+    cand, x0, pool = None, None, None
+    if args.config == "C5":
+        from rcognita_amd.pool import MixedPool
+
+        counts = {"3wrobot": total_envs // 3 + total_envs % 3, "3wrobotNI": total_envs // 3, "2tank": total_envs // 3}
+        pool = MixedPool(counts, rank=rank, world=world, device=local_rank, dtype=args.dtype, Nactor=Nh)
+        rng = np.random.default_rng(1234 + rank)
+        pool.set_states({s.name: pool_states(rng, s.name, s.hi - s.lo) for s in pool.segments})
+        pool.set_streams([stream_ptr] * len(pool.segments))
+        engines = [s.engine for s in pool.segments]
+        B = pool.n_envs
+        tick = lambda: pool.control_tick(K)
+    else:
+        lo, hi = shard_range(total_envs, rank, world)
+        B = hi - lo
+        ecfg, bnds = c2_engine_config(args, local_rank, B, env_id_base=lo)
+        eng = Engine(ecfg)
+        eng.set_stream(stream_ptr)
+        x0 = synth_state(1234, lo, hi)
+        eng.set_state(x0)
+        if streamed:
+            g = torch.Generator(device="cuda")
+            g.manual_seed(1234 + rank)
+            blo = torch.tensor(bnds[:, 0], device="cuda", dtype=tdtype)
+            bhi = torch.tensor(bnds[:, 1], device="cuda", dtype=tdtype)
+            cand = (torch.rand((B, K, Nh, 2), generator=g, device="cuda", dtype=tdtype) * (bhi - blo) + blo).contiguous()
+        engines = [eng]
+        tick = lambda: eng.control_tick(cand, K=K)
+    du, ds = 2, 5
+
+    # ---- untimed: clock pre-spin (>= PRESPIN_S of the same kernels), then the W warm-up steps ------------------------
+    prespin = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < PRESPIN_S:
+        for _ in range(16):
+            tick()
+        prespin += 16
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
-        eng.control_tick(cand, K=K)
-    returns_dev = torch.empty(B, device="cuda", dtype=tdtype)
-    gathered = [torch.empty(B, device=coll_dev, dtype=tdtype) for _ in range(world)] if dist is not None else None
+        tick()
+    Bmax = B
+    if dist is not None:  # ragged shards: the all_gather payload is padded to the largest shard
+        bm = torch.tensor([B], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(bm, op=dist.ReduceOp.MAX)
+        Bmax = int(bm.item())
+    returns_dev = torch.zeros(Bmax, device="cuda", dtype=tdtype)
+    gathered = [torch.empty(Bmax, device=coll_dev, dtype=tdtype) for _ in range(world)] if dist is not None else None
 
     # HIP events around the kernels of the tick on the engine's own stream, inside the timed region; sampled
     # (every n-th launch) because each event is a marker packet on the stream.
     if args.profile_stride > 0:
         if args.steps // args.profile_stride < 8:  # short runs: time (almost) every launch rather than none
             args.profile_stride = max(1, args.steps // 8)
-        eng.profile((N.KERNEL_ACTOR, N.KERNEL_SIM), stride=args.profile_stride)
+        for e in engines:
+            e.profile((N.KERNEL_ACTOR, N.KERNEL_SIM), stride=args.profile_stride)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.control_tick(cand, K=K)
+        tick()
     if dist is not None:
         # episode-end exchange: ONE all_gather of the per-env running returns over RCCL
-        N.check(N.lib().rcg_get_field(eng._h, N.FIELD_ACCUM, returns_dev.data_ptr(), N.DEVICE), eng._h)
+        off = 0
+        for e in engines:
+            n_e = e.B
+            N.check(N.lib().rcg_get_field(e._h, N.FIELD_ACCUM, returns_dev[off:].data_ptr(), N.DEVICE), e._h)
+            off += n_e
         dist.all_gather(gathered, returns_dev if coll_dev.type == "cuda" else returns_dev.cpu())
     barrier()
     dt = time.perf_counter() - t0
@@ -213,37 +474,69 @@ def main():
         tmax = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    actor_ms, actor_n = eng.profile_read(N.KERNEL_ACTOR)
-    sim_ms, sim_n = eng.profile_read(N.KERNEL_SIM)
-    eng.profile(False)
+    actor_ms = actor_n = sim_ms = sim_n = 0
+    for e in engines:
+        a_ms, a_n = e.profile_read(N.KERNEL_ACTOR)
+        s_ms, s_n = e.profile_read(N.KERNEL_SIM)
+        actor_ms, actor_n, sim_ms, sim_n = actor_ms + a_ms, actor_n + a_n, sim_ms + s_ms, sim_n + s_n
+        e.profile(False)
 
-    summ, _ = eng.episode_stats(from_accum=True)
+    summ = merge_summaries([e.episode_stats(from_accum=True)[0] for e in engines])
     total = gather_summaries(summ, dist, device=coll_dev)  # per-shard summaries -> whole-job summary
-    steps_idx = eng.get_field(N.FIELD_STEP_IDX)
-    assert int(steps_idx.min()) == int(steps_idx.max()) == args.warmup + args.steps, "step counter mismatch"
+    ticks_done = prespin + args.warmup + args.steps
+    for e in engines:
+        steps_idx = e.get_field(N.FIELD_STEP_IDX)
+        assert int(steps_idx.min()) == int(steps_idx.max()) == ticks_done, "step counter mismatch"
+    rank_info = None
+    if dist is not None:
+        mine = torch.tensor([rank, local_rank, B], dtype=torch.int64, device=coll_dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        rank_info = [{"rank": int(p[0]), "device": int(p[1]), "envs": int(p[2])} for p in parts]
+        if coll_dev.type == "cuda":  # the gathered returns really are everyone's: compare their sum with the summaries
+            allret = torch.stack(gathered).double()
+            got = float(sum(allret[r, :ri["envs"]].sum().item() for r, ri in enumerate(rank_info)))
+            assert abs(got - total["sum"]) <= 1e-6 * max(abs(total["sum"]), 1.0), (got, total["sum"])
 
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
-    units = world * B * args.steps
+    units = total_envs * args.steps
     value = units / dt
-    streamed = args.regime == "streamed"
-    fused_sim = False  # the env step is its own launch (k_sim); kept as a parameter of the byte model
-    bytes_launch = actor_bytes_per_launch(B, K, Nh, du, ds, esz, streamed, fused_sim)
+    if args.config == "C5":
+        bytes_launch = sum(actor_bytes_per_launch(e.B, K, Nh, e.du, e.ds, esz, False) for e in engines)
+    else:
+        bytes_launch = actor_bytes_per_launch(B, K, Nh, du, ds, esz, streamed)
     actor_avg_s = (actor_ms / max(actor_n, 1)) * 1e-3
+    if args.config == "C5":
+        actor_avg_s *= len(engines)  # one launch per segment: the per-tick figure is their sum
     achieved = bytes_launch / actor_avg_s if actor_avg_s > 0 else 0.0
-    traffic = None
+    traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.config != "C5":
         try:
             traffic = json.load(open(pmc)).get(f"k_actor_{args.regime}_B{B}_K{K}_N{Nh}_{args.dtype}", {}).get(
                 "hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "                           "stored; not re-measured in this run)"
         except Exception:
             traffic = None
+    dma = streamed and K % 64 == 0 and args.config != "C5" and (args.dtype == "f32" or Nh * 2 <= 16)
+    workload = {
+        "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
+              "candidates (BASELINE configs[1])",
+        "C4": f"Sys3WRobot {total_envs} envs sharded over {world} rank(s), RK4 dt=0.01, MPC Nactor={Nh}, K={K} "
+              f"{args.regime} candidates, all_gather of episode returns (BASELINE configs[3])",
+        "C5": f"mixed pool 3wrobot+3wrobot_NI+2tank, {total_envs} envs over {world} rank(s) sharded within each type, "
+              f"Nactor={Nh}, K={K} generated grid (BASELINE configs[4])",
+    }[args.config]
+    metric = "env-control-steps/sec (whole node), 3wrobot Nactor=10"
+    if args.config != "C2" or Nh != 10:
+        metric = f"env-control-steps/sec (whole node), {args.config} Nactor={Nh}"
     out = {
-        "metric": "env-control-steps/sec (whole node), 3wrobot Nactor=10",
+        "metric": metric,
         "value": value,
         "unit": "env-control-steps/s",
         "n_gpus": world,
@@ -251,61 +544,36 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": f"Sys3WRobot B={B}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, "
-                               f"K={K} {args.regime} candidates (BASELINE configs[1])",
-                   "envs_per_gpu": B, "candidates": K, "nactor": Nh, "regime": args.regime,
-                   "parallelism": f"env-shard x{world}", "actor_cost_evals_per_s": value * K},
-        "roofline": {"bound": "hbm", "kernel": "k_actor_dma" if (streamed and args.dtype == "f32" and K % 64 == 0) else "k_actor",
+        "config": {"workload": workload, "config": args.config, "envs_total": total_envs, "envs_rank0": B,
+                   "candidates": K, "nactor": Nh, "regime": args.regime, "parallelism": f"env-shard x{world}",
+                   "actor_cost_evals_per_s": value * K, "prespin_ticks_untimed": prespin},
+        "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+        "dist_backend": (args.dist_backend if dist is not None else None),
+        "launcher": launcher,
+        "ranks": rank_info,
+        "roofline": {"bound": "hbm", "kernel": "k_actor_dma" if dma else "k_actor",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": actor_avg_s * 1e3,
                      "launches_timed": actor_n, "event_stride": args.profile_stride,
                      "sim_kernel_avg_ms": (sim_ms / sim_n) if sim_n else None,
                      "note": ("streamed regime: HBM-bound" if streamed else
-                              "generated regime is VALU-bound; the HBM fraction is reported for completeness only")},
+                              "generated regime is VALU-bound (see secondary.generated_grid.roofline_valu); the HBM "
+                              "fraction is reported for completeness only")},
         "returns_summary": total,
     }
 
-    if not args.no_secondary and world == 1:
-        sec = {}
-        # (1) generated level-grid candidates (VALU-bound regime) at the same K
-        eng2, _, _ = make_engine(args, local_rank)
-        eng2.set_stream(torch.cuda.current_stream().cuda_stream)
-        eng2.set_state(synth_state(rank, B))
-        for _ in range(5):
-            eng2.control_tick(None, K=K)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n2 = max(10, args.steps // 4)
-        for _ in range(n2):
-            eng2.control_tick(None, K=K)
-        torch.cuda.synchronize()
-        d2 = time.perf_counter() - t1
-        sec["generated_grid"] = {"env_control_steps_per_s": B * n2 / d2, "actor_cost_evals_per_s": B * n2 * K / d2,
-                                 "bound": "valu"}
-        # (2) pure env step: RK4 of closed_loop_rhs only (Simulator.sim_step), 64 B/env algorithmic
-        for _ in range(5):
-            eng2.sim_step(1)
-        eng2.profile((N.KERNEL_SIM,))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n3 = 200
-        for _ in range(n3):
-            eng2.sim_step(1)
-        torch.cuda.synchronize()
-        d3 = time.perf_counter() - t1
-        ms3, c3 = eng2.profile_read(N.KERNEL_SIM)
-        eng2.profile(False)
-        sec["sim_step_only"] = {"env_steps_per_s_wall": B * n3 / d3, "kernel_avg_us": ms3 / max(c3, 1) * 1e3,
-                                "kernel_GBps": B * ((3 * ds + du) * esz + 4) / max(ms3 / max(c3, 1) * 1e-3, 1e-12) / 1e9}
-        eng2.close()
-        out["secondary"] = sec
+    if not args.no_parity and args.config != "C5":
+        out["parity"] = parity_check(args, local_rank, stream_ptr, x0, cand, K)
 
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_secondary and world == 1 and args.config == "C2":
+        out["secondary"] = secondary(args, local_rank, stream_ptr, x0, B, K, Nh, torch, Engine, N)
+
+    if not args.no_cpu_baseline and world == 1 and args.config == "C2":
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         try:
@@ -314,7 +582,106 @@ def main():
             out["cpu_baseline"]["reference_algorithm"] = {"error": str(e)}
     print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if "parity" in out and not out["parity"]["ok"]:
+        sys.exit("bench.py: the parity check of this run FAILED - the numbers above are not valid")
+
+
+def valu_instr_per_eval(key):
+    """VALU instructions per _actor_cost evaluation from the stored SQ_INSTS_VALU pass (profiles/valu_instr.json)."""
+    path = os.path.join(ROOT, "profiles", "valu_instr.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
+
+
+def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
+    """Other regimes of the same workload on this GPU (rank 0, N = 1 only; not part of `value`)."""
+    sec = {}
+    du, ds = 2, 5
+    # (1) generated level-grid candidates (VALU-bound regime, SURVEY.md 8d) at the same K
+    ecfg, bnds = c2_engine_config(args, device, B)
+    eng2 = Engine(ecfg)
+    eng2.set_stream(stream_ptr)
+    eng2.set_state(x0)
+    for _ in range(5):
+        eng2.control_tick(None, K=K)
+    eng2.profile((N.KERNEL_ACTOR,), stride=1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n2 = max(10, args.steps // 4)
+    for _ in range(n2):
+        eng2.control_tick(None, K=K)
+    torch.cuda.synchronize()
+    d2 = time.perf_counter() - t1
+    ms2, c2 = eng2.profile_read(N.KERNEL_ACTOR)
+    eng2.profile(False)
+    evals_kernel = B * K / max(ms2 / max(c2, 1) * 1e-3, 1e-12)
+    g = {"env_control_steps_per_s": B * n2 / d2, "actor_cost_evals_per_s": B * n2 * K / d2, "bound": "valu",
+         "kernel_avg_ms": ms2 / max(c2, 1), "kernel_evals_per_s": evals_kernel}
+    ipe = valu_instr_per_eval(f"k_actor_generated_3wrobot_N{Nh}_{args.dtype}")
+    if ipe:
+        g["roofline_valu"] = {"instr_per_eval": ipe["valu_instr_per_eval"], "lane_instr_per_s": evals_kernel * ipe["valu_instr_per_eval"],
+                              "peak": VALU_PEAK, "frac": evals_kernel * ipe["valu_instr_per_eval"] / VALU_PEAK,
+                              "source": "profiles/valu_instr.json (rocprofv3 --pmc SQ_INSTS_VALU pass, stored) x this "
+                                        "run's kernel time"}
+    sec["generated_grid"] = g
+    # (2) pure env step: RK4 of closed_loop_rhs only (Simulator.sim_step), 64 B/env algorithmic
+    for _ in range(5):
+        eng2.sim_step(1)
+    eng2.profile((N.KERNEL_SIM,))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n3 = 200
+    for _ in range(n3):
+        eng2.sim_step(1)
+    torch.cuda.synchronize()
+    d3 = time.perf_counter() - t1
+    ms3, c3 = eng2.profile_read(N.KERNEL_SIM)
+    eng2.profile(False)
+    sec["sim_step_only"] = {"env_steps_per_s_wall": B * n3 / d3, "kernel_avg_us": ms3 / max(c3, 1) * 1e3,
+                            "kernel_GBps": B * ((3 * ds + du) * 4 + 4) / max(ms3 / max(c3, 1) * 1e-3, 1e-12) / 1e9}
+    eng2.close()
+    # (3) the reference's own arithmetic width: the same tick in float64 (streamed candidates, 2 x the bytes)
+    if args.dtype == "f32" and args.regime == "streamed":
+        try:
+            ecfg64, _ = c2_engine_config(args, device, B, dtype="f64")
+            e64 = Engine(ecfg64)
+            e64.set_stream(stream_ptr)
+            e64.set_state(x0)
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(4321)
+            blo = torch.tensor(bnds[:, 0], device="cuda", dtype=torch.float64)
+            bhi = torch.tensor(bnds[:, 1], device="cuda", dtype=torch.float64)
+            c64 = (torch.rand((B, K, Nh, du), generator=gen, device="cuda", dtype=torch.float64) * (bhi - blo) + blo).contiguous()
+            for _ in range(10):
+                e64.control_tick(c64, K=K)
+            e64.profile((N.KERNEL_ACTOR,), stride=1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n4 = max(20, args.steps // 5)
+            for _ in range(n4):
+                e64.control_tick(c64, K=K)
+            torch.cuda.synchronize()
+            d4 = time.perf_counter() - t1
+            ms4, c4 = e64.profile_read(N.KERNEL_ACTOR)
+            e64.close()
+            b64 = actor_bytes_per_launch(B, K, Nh, du, ds, 8, True)
+            sec["f64"] = {"env_control_steps_per_s": B * n4 / d4, "ms_per_step": d4 / n4 * 1e3, "dtype": "f64",
+                          "kernel": "k_actor_dma<double>" if Nh * du <= 16 else "k_actor",
+                          "kernel_avg_ms": ms4 / max(c4, 1),
+                          "roofline": {"bound": "hbm", "achieved": b64 / (ms4 / max(c4, 1) * 1e-3) / 1e9,
+                                       "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                       "frac": b64 / (ms4 / max(c4, 1) * 1e-3) / HBM_PEAK,
+                                       "algorithmic_bytes_per_launch": b64}}
+            del c64
+        except Exception as e:  # never let a secondary figure take the bench line down
+            sec["f64"] = {"error": str(e)[:300]}
+    return sec
 
 
 if __name__ == "__main__":

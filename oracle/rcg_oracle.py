@@ -430,8 +430,11 @@ def sim_substeps(cfg: OracleCfg, env: EnvBatch, n_substeps: int):
             env.accum = env.accum + stage_obj(env.state, env.action, cfg) * cfg.sampling_time
 
 
-def control_tick(cfg: OracleCfg, env: EnvBatch, cand):
+def control_tick(cfg: OracleCfg, env: EnvBatch, cand, force_idx=None):
     """One env.control-step (unit U2 of SURVEY §8d) for every env of the batch.
+
+    ``force_idx [B]`` (int, entries < 0 = not forced): take this candidate instead of the argmin for those envs -
+    used by the parity checker to follow a float32 run through an exact near-tie (``oracle/parity.py``).
 
     Order follows the reference loop (presets/main_3wrobot.py:419-429):
       1. sim_step        : ``substeps_per_tick`` RK4 substeps with the held, clipped action
@@ -445,8 +448,10 @@ def control_tick(cfg: OracleCfg, env: EnvBatch, cand):
     sim_substeps(cfg, env, cfg.substeps_per_tick)
     if cfg.mode != MODE_MPC:
         # buffer push + critic refit every `critic_every_ticks` ticks (controllers.py:1458-1477)
+        # critic_clock starts at t0 and tick j happens at t0 + (j + 1) dt, so `t - critic_clock >= critic_period`
+        # (controllers.py:1466) first holds on tick every - 1, then every `every` ticks
         every = max(int(cfg.critic_every_ticks), 1)
-        critic_update(cfg, env, do_fit=(env.tick_count % every) == 0)
+        critic_update(cfg, env, do_fit=((env.tick_count + 1) % every) == 0)
     env.tick_count += 1
     obs = env.state
     state_sys = env.state_prev if cfg.ref_lag else env.state
@@ -462,6 +467,10 @@ def control_tick(cfg: OracleCfg, env: EnvBatch, cand):
         w_critic=None if env.w_critic is None else env.w_critic[:, None, :],
     )
     best_J, best_idx = argmin_first(J)
+    if force_idx is not None:
+        f = np.asarray(force_idx)
+        best_idx = np.where(f >= 0, f, best_idx).astype(np.int32)
+        best_J = np.take_along_axis(np.where(np.isnan(J), np.inf, J), best_idx[:, None].astype(np.int64), axis=1)[:, 0]
     env.best_J, env.best_idx = best_J, best_idx
     env.action = np.take_along_axis(cand[:, :, 0, :], best_idx[:, None, None].astype(np.int64), axis=1)[:, 0, :]
     if not cfg.accum_every_substep:
@@ -787,7 +796,13 @@ def critic_update(cfg: OracleCfg, env: EnvBatch, do_fit=True):
     """RQL/SQL bookkeeping of compute_action (controllers.py:1458-1477): push (action_curr, obs), refit."""
     env.act_buf = push_vec(env.act_buf, env.action)
     env.obs_buf = push_vec(env.obs_buf, env.state)
-    if do_fit:
+    if do_fit and cfg.n_critic - 1 < 1:
+        # empty TD stack (Ncritic = 1): _critic_cost is identically 0 (controllers.py:1227-1245), SLSQP returns its
+        # start point w_critic_init = ones, clipped into [Wmin, Wmax]
+        lo, hi = critic_bounds(cfg.critic_struct, cfg.dc)
+        env.w_critic = np.broadcast_to(np.clip(np.ones(cfg.dc), lo, hi), env.w_prev.shape).copy()
+        env.w_prev = env.w_critic
+    elif do_fit:
         env.w_critic = critic_fit(cfg, env.w_prev, env.obs_buf, env.act_buf)
         env.w_prev = env.w_critic
     else:

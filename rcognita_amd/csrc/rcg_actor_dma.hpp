@@ -26,8 +26,9 @@
 // Launch geometry (rcg_sysops.hpp::launch_actor): a wave owns a power-of-two number of consecutive envs, 2 blocks per
 // CU resident (4 for rows shorter than 20 floats), grid of several rounds.
 // Measured on C2 (B = 65536, K = 256, N = 10): 203 us per launch = 6.6 TB/s (83 % of the 8 TB/s peak); the bare data
-// path of this kernel (steps 1-3, no arithmetic) holds 7.0-7.2 TB/s (tools/bw_probe.hip residency).  A.dbg bits
-// (RCG_DBG) switch pieces off for such measurements: 1 rollout, 2 argmin + writes, 4 env-state loads.
+// path of this kernel (steps 1-3, no arithmetic) holds 7.0-7.2 TB/s (tools/bw_probe.hip residency).  In a development
+// build (`make dev`, -DRCG_DEV -> librcg_dev.so) the A.dbg bits (env RCG_DBG) switch pieces off for such measurements:
+// 1 rollout, 2 argmin + writes, 4 env-state loads.  The production library compiles them out (RCG_DBG(A, bit) == 0).
 #pragma once
 #include "rcg_kernels.hpp"
 
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
 #pragma unroll
   for (int i = 0; i < DCMAX; ++i) wn[i] = wc[i] = 0;  // entries >= dc are never loaded and never read
   auto fetch_env = [&](long b) {
-    if (A.dbg & 4) {  // development: no env-state loads
+    if (RCG_DBG(A, 4)) {  // development: no env-state loads
 #pragma unroll
       for (int c = 0; c < DS; ++c) yn[c] = (real)0.5;
       return;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
   };
   // loads one env-state request issues (vmcnt bookkeeping of the depth-2 pipeline)
   const int n_env_loads =
-      ((A.dbg & 4) || A.sim_state != nullptr) ? 0 : DS + (A.pars_env ? NP : 0) + (CRIT ? P.dc : 0);
+      (RCG_DBG(A, 4) || A.sim_state != nullptr) ? 0 : DS + (A.pars_env ? NP : 0) + (CRIT ? P.dc : 0);
 
   // Fused env step (the tick's Simulator.sim_step in this launch, A.sim_state != nullptr): lane e < ne integrates env
   // env0 + e - exactly k_sim's arithmetic (rk4_step, clip, freeze on a non-finite state) - while the first tile is in
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
     real S[NCHI];
 #pragma unroll
     for (int i = 0; i < NCHI; ++i) S[i] = 0;
-    if (A.dbg & 1) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
+    if (RCG_DBG(A, 1)) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
 #pragma unroll
       for (int i = 0; i < R; ++i) J += cur[i];
     } else {
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
       }
     }
     if (++t == T) {  // env b complete: wave argmin (lower J, then lower index) + tick epilogue
-      if (A.dbg & 2) {  // development: no argmin / stores (one store keeps the work alive)
+      if (RCG_DBG(A, 2)) {  // development: no argmin / stores (one store keeps the work alive)
         if (bestJ == (real)-12345.678f) A.best_J[b] = bestJ;
         if (lane == 0 && A.step_idx) atomicAdd(&A.step_idx[b], 1);
         t = 0;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<float> A, con
   }
 
   // one coalesced write per field for the envs of this wave; stores and no-return atomics only
-  if (lane < (int)(env1 - env0) && !(A.dbg & 2)) {
+  if (lane < (int)(env1 - env0) && !RCG_DBG(A, 2)) {
     const long bb = env0 + lane;
 #pragma unroll
     for (int c = 0; c < DU; ++c)

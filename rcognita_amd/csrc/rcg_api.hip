@@ -41,6 +41,26 @@ static void prof_drain(rcg_handle* h) {
   h->ev_pending.clear();
 }
 
+// Every entry point that touches HIP runs on the handle's device whatever the calling thread's current device is
+// (two handles on two GPUs in one process, or a handle driven from another thread), and puts the previous one back.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const rcg_handle* h) {
+    if (h) enter(h->cfg.device);
+  }
+  explicit DeviceGuard(int device) { enter(device); }
+  void enter(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 static const int kDims[3][3] = {{5, 2, 2}, {3, 2, 0}, {2, 1, 5}};  // ds, du, np
 
 static int dim_critic(int cs, int dy, int du) {
@@ -155,7 +175,12 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
     return rcg_fail(nullptr, RCG_ERR_NO_DEVICE, "rcg_create: no HIP device visible; librcg has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev)
     return rcg_fail(nullptr, RCG_ERR_BAD_ARG, "rcg_create: device %d out of range (%d visible)", cfg->device, ndev);
-  HIPCHK(nullptr, hipSetDevice(cfg->device));
+  DeviceGuard dev_guard(cfg->device);  // the caller's current device is put back on return
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device)
+      return rcg_fail(nullptr, RCG_ERR_HIP, "rcg_create: cannot make device %d current", cfg->device);
+  }
 
   rcg_handle* h = new rcg_handle();
   h->cfg = *cfg;
@@ -266,6 +291,10 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   if (rc == RCG_OK && (cfg->flags & RCG_FLAG_DISTURB))
     rc = cfg->dtype == RCG_F64 ? fill_rows<double>(h, h->f[RCG_FIELD_DISTURB], dd, cfg->disturb_init)
                                : fill_rows<float>(h, h->f[RCG_FIELD_DISTURB], dd, cfg->disturb_init);
+  // the memsets and fills above ran on the NULL stream: finish them here, so that a (non-blocking) stream installed
+  // with rcg_set_stream cannot race with them
+  if (rc == RCG_OK && hipStreamSynchronize(h->stream) != hipSuccess)
+    rc = rcg_fail(h, RCG_ERR_HIP, "rcg_create: synchronising the initial fills");
   if (rc != RCG_OK) {
     g_err = h->err;
     rcg_destroy(h);
@@ -276,8 +305,8 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
 }
 
 int rcg_destroy(rcg_handle* h) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_OK;
-  (void)hipSetDevice(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
   for (int i = 0; i < RCG_FIELD_COUNT_; ++i)
     if (h->f[i]) (void)hipFree(h->f[i]);
@@ -293,25 +322,33 @@ int rcg_destroy(rcg_handle* h) {
 }
 
 int rcg_set_stream(rcg_handle* h, void* hip_stream) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
+  if ((hipStream_t)hip_stream == h->stream) return RCG_OK;
+  // work already queued on the old stream is finished before the first launch on the new one: the two streams are
+  // not ordered with respect to each other (torch.cuda.Stream() is non-blocking)
+  prof_drain(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   h->stream = (hipStream_t)hip_stream;
   return RCG_OK;
 }
 
 int rcg_synchronize(rcg_handle* h) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return RCG_OK;
 }
 
 int rcg_dev_alloc(rcg_handle* h, uint64_t bytes, void** dev_out) {
+  DeviceGuard dev_guard(h);
   if (!h || !dev_out) return RCG_ERR_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipMalloc(dev_out, bytes ? bytes : 16));
   return RCG_OK;
 }
 
 int rcg_dev_free(rcg_handle* h, void* dev) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipFree(dev));
@@ -319,6 +356,7 @@ int rcg_dev_free(rcg_handle* h, void* dev) {
 }
 
 int rcg_memcpy_h2d(rcg_handle* h, void* dev_dst, const void* host_src, uint64_t bytes) {
+  DeviceGuard dev_guard(h);
   if (!h || !dev_dst || !host_src) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_memcpy_h2d: null argument");
   HIPCHK(h, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -326,6 +364,7 @@ int rcg_memcpy_h2d(rcg_handle* h, void* dev_dst, const void* host_src, uint64_t 
 }
 
 int rcg_memcpy_d2h(rcg_handle* h, void* host_dst, const void* dev_src, uint64_t bytes) {
+  DeviceGuard dev_guard(h);
   if (!h || !host_dst || !dev_src) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_memcpy_d2h: null argument");
   HIPCHK(h, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -341,6 +380,7 @@ static int check_field(rcg_handle* h, int field, const char* who) {
 }
 
 int rcg_set_field(rcg_handle* h, int field, const void* src, int where) {
+  DeviceGuard dev_guard(h);
   int rc = check_field(h, field, "rcg_set_field");
   if (rc) return rc;
   if (!src) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_field: null src");
@@ -353,6 +393,7 @@ int rcg_set_field(rcg_handle* h, int field, const void* src, int where) {
 }
 
 int rcg_get_field(rcg_handle* h, int field, void* dst, int where) {
+  DeviceGuard dev_guard(h);
   int rc = check_field(h, field, "rcg_get_field");
   if (rc) return rc;
   if (!dst) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_get_field: null dst");
@@ -378,12 +419,14 @@ int rcg_field_ptr(rcg_handle* h, int field, void** dev_out) {
 // ---- stateless operators --------------------------------------------------------------------
 int rcg_rhs(rcg_handle* h, const void* state, const void* action, void* dstate, void* clipped_action, int32_t n,
             int32_t clip) {
+  DeviceGuard dev_guard(h);
   if (!h || !state || !action || !dstate || n < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_rhs: bad argument");
   return h->sys->rhs(h, state, action, dstate, clipped_action, n, clip);
 }
 
 int rcg_rhs_full(rcg_handle* h, const void* state, const void* disturb, const void* action, const void* xi, void* dstate,
                  void* ddisturb, void* clipped_action, int32_t n, int32_t clip) {
+  DeviceGuard dev_guard(h);
   if (!h || !state || !disturb || !action || !xi || !dstate || !ddisturb || n < 1)
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_rhs_full: bad argument");
   if (!(h->cfg.flags & RCG_FLAG_DISTURB))
@@ -392,6 +435,7 @@ int rcg_rhs_full(rcg_handle* h, const void* state, const void* disturb, const vo
 }
 
 int rcg_disturb_noise(rcg_handle* h, void* bits_out, void* xi_out) {
+  DeviceGuard dev_guard(h);
   if (!h || (!bits_out && !xi_out)) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_disturb_noise: no output given");
   if (!(h->cfg.flags & RCG_FLAG_DISTURB))
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_disturb_noise: the handle was created without RCG_FLAG_DISTURB");
@@ -409,29 +453,34 @@ int rcg_disturb_noise(rcg_handle* h, void* bits_out, void* xi_out) {
 }
 
 int rcg_stage_obj(rcg_handle* h, const void* obs, const void* act, void* out, int32_t n) {
+  DeviceGuard dev_guard(h);
   if (!h || !obs || !act || !out || n < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_stage_obj: bad argument");
   return h->sys->stage_obj(h, obs, act, out, n);
 }
 
 int rcg_critic(rcg_handle* h, const void* obs, const void* act, const void* w, void* out, int32_t n) {
+  DeviceGuard dev_guard(h);
   if (!h || !obs || !act || !w || !out || n < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_critic: bad argument");
   return h->sys->critic(h, obs, act, w, out, n);
 }
 
 int rcg_actor_cost(rcg_handle* h, const void* cand, int32_t K, const void* obs, const void* state_sys, const void* w,
                    void* J) {
+  DeviceGuard dev_guard(h);
   if (!h || !cand || !J) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_actor_cost: cand and J are required");
   return h->sys->actor(h, "rcg_actor_cost", cand, K, obs, state_sys, w, J, nullptr, nullptr, nullptr, false, false);
 }
 
 int rcg_actor_argmin(rcg_handle* h, const void* cand, int32_t K, const void* obs, const void* state_sys, void* action,
                      void* best_J, int32_t* best_idx) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
   return h->sys->actor(h, "rcg_actor_argmin", cand, K, obs, state_sys, nullptr, nullptr, action, best_J, best_idx,
                        false, false);
 }
 
 int rcg_critic_cost(rcg_handle* h, const void* w, void* Jc) {
+  DeviceGuard dev_guard(h);
   if (!h || !Jc) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_critic_cost: Jc is required");
   if (!h->f[RCG_FIELD_OBS_BUF])
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_critic_cost: handle has no critic buffers (buffer_size = 0)");
@@ -440,30 +489,73 @@ int rcg_critic_cost(rcg_handle* h, const void* w, void* Jc) {
 
 // ---- stateful steps -------------------------------------------------------------------------
 int rcg_sim_step(rcg_handle* h, int32_t n_substeps) {
+  DeviceGuard dev_guard(h);
   if (!h || n_substeps < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_sim_step: n_substeps must be >= 1");
   return h->sys->sim_step(h, n_substeps);
 }
 
+// w_critic = w_prev = clip(w_init, Wmin, Wmax): what the reference's SLSQP returns when the TD stack is empty
+// (Ncritic = 1: _critic_cost is identically 0, controllers.py:1227-1245, so minimize() stops at its start point)
+static int critic_keep_init(rcg_handle* h) {
+  double w[40];
+  for (int i = 0; i < h->dc; ++i) {
+    const double lo = h->cfg.w_min[i], hi = h->cfg.w_max[i], v = h->cfg.w_init[i];
+    w[i] = v < lo ? lo : (v > hi ? hi : v);
+  }
+  for (int f : {RCG_FIELD_W_CRITIC, RCG_FIELD_W_PREV}) {
+    const int rc = h->cfg.dtype == RCG_F64 ? fill_rows<double>(h, h->f[f], h->dc, w) : fill_rows<float>(h, h->f[f], h->dc, w);
+    if (rc) return rc;
+  }
+  return RCG_OK;
+}
+
 int rcg_critic_update(rcg_handle* h, int32_t do_fit) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
   if (!h->f[RCG_FIELD_OBS_BUF])
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_critic_update: handle has no critic buffers (buffer_size = 0)");
   const int m = h->cfg.n_critic - 1;
-  if (do_fit && (m < 1 || m > kFitMaxRows))
-    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_critic_update: the native critic fit needs 1 <= Ncritic-1 <= %d (got %d)",
+  if (do_fit && m > kFitMaxRows)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_critic_update: the native critic fit needs Ncritic-1 <= %d (got %d)",
                     kFitMaxRows, m);
+  if (do_fit && m < 1) {  // empty TD stack: push only, the weights stay at the (clipped) initial guess
+    const int rc = h->sys->critic_update(h, 0);
+    return rc ? rc : critic_keep_init(h);
+  }
   return h->sys->critic_update(h, do_fit);
 }
 
+// Argument checks of the decision step, made BEFORE the tick mutates anything (env step, buffer push): a refused
+// call leaves the handle exactly as it was.
+static int check_candidates(rcg_handle* h, const char* who, const void* cand, int32_t K) {
+  if (K < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: K must be >= 1", who);
+  if (!cand && h->du == 2) {
+    int g = 1;
+    while ((long)(g + 1) * (g + 1) <= (long)K) ++g;
+    if (g * g != K) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: generated grid for du = 2 needs a square K (got %d)", who, K);
+  }
+  if (h->cfg.mode != RCG_MODE_MPC && !h->f[RCG_FIELD_W_CRITIC])
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: RQL/SQL need critic weights (buffer_size > 0)", who);
+  return RCG_OK;
+}
+
 int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
+  int rc = check_candidates(h, "rcg_control_tick", cand, K);
+  if (rc) return rc;
   bool sim_first = true;  // MPC: env step, then the decision, both issued by the actor launcher
   if (h->cfg.mode != RCG_MODE_MPC) {  // RQL/SQL: the critic bookkeeping sits between the two
-    int rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
+    if (h->cfg.n_critic - 1 > kFitMaxRows)
+      return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick: the native critic fit needs Ncritic-1 <= %d (got %d)",
+                      kFitMaxRows, h->cfg.n_critic - 1);
+    rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
     if (rc) return rc;
-    // critic_period = critic_every_ticks * sampling_time (controllers.py:1466-1477)
+    // critic_period = critic_every_ticks * sampling_time.  The reference starts critic_clock at t0 and refits when
+    // t - critic_clock >= critic_period (controllers.py:1458-1471); tick j of an episode happens at t0 + (j+1)*dt, so
+    // the fits fall on ticks every-1, 2*every-1, ...
     const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
-    rc = rcg_critic_update(h, (h->tick_count % every) == 0 ? 1 : 0);
+    rc = rcg_critic_update(h, ((h->tick_count + 1) % every) == 0 ? 1 : 0);
     if (rc) return rc;
     sim_first = false;
   }
@@ -474,31 +566,35 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
 
 int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
                        void* u_opt, void* action, void* best_J, int32_t* n_iter) {
+  DeviceGuard dev_guard(h);
   if (!h || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_actor_optimize: iters must be >= 0");
   return h->sys->optimize(h, iters, obs, state_sys, u_init, 0, u_opt, action, best_J, n_iter, false);
 }
 
 int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start) {
+  DeviceGuard dev_guard(h);
   if (!h || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_tick_opt: iters must be >= 0");
   if (h->cfg.mode != RCG_MODE_MPC)
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_opt: MPC only (RQL/SQL use rcg_control_tick)");
-  int rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
-  if (rc) return rc;
-  const bool warm = warm_start && h->tick_count > 0;  // nothing to shift before the first decision
-  h->tick_count += 1;
+  // (the env step of the tick is issued by the optimiser's launcher, after its argument checks)
+  const bool warm = warm_start && h->tick_count > 0;  // nothing to shift before the episode's first decision
   void* sqn = h->f[RCG_FIELD_ACTION_SQN];
-  return h->sys->optimize(h, iters, nullptr, nullptr, warm ? sqn : nullptr, warm ? 1 : 0, sqn, h->f[RCG_FIELD_ACTION],
-                          h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true);
+  const int rc = h->sys->optimize(h, iters, nullptr, nullptr, warm ? sqn : nullptr, warm ? 1 : 0, sqn,
+                                  h->f[RCG_FIELD_ACTION], h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true);
+  if (rc == RCG_OK) h->tick_count += 1;
+  return rc;
 }
 
 int rcg_nominal_action(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double ctrl_gain,
                        const double* ctrl_pars, int32_t clip) {
+  DeviceGuard dev_guard(h);
   if (!h || !obs || (!action && !lyap) || n < 1)
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_nominal_action: obs and one of action/lyap are required, n >= 1");
   return h->sys->nominal(h, obs, action, lyap, n, ctrl_gain, ctrl_pars, clip, false);
 }
 
 int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl_pars) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
   if (h->cfg.sys_id == RCG_SYS_2TANK)  // refuse before the env is stepped
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_nominal: the reference defines no nominal controller for 2tank");
@@ -510,8 +606,12 @@ int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl
 }
 
 int rcg_episode_reset(rcg_handle* h) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
   const long B = h->cfg.batch;
+  // the tick counter belongs to the episode: the first decision of the new episode has no previous optimum to shift
+  // (rcg_control_tick_opt warm start) and the critic period restarts with the controller clock
+  h->tick_count = 0;
   if (h->cfg.dtype == RCG_F64)
     hipLaunchKernelGGL((k_episode_reset<double>), dim3(blocks_for(B)), dim3(256), 0, h->stream,
                        (double*)h->f[RCG_FIELD_STATE], (double*)h->f[RCG_FIELD_STATE_PREV],
@@ -539,6 +639,7 @@ int rcg_episode_reset(rcg_handle* h) {
 }
 
 int rcg_episode_stats(rcg_handle* h, int32_t from_accum, void* returns_out, rcg_summary* out) {
+  DeviceGuard dev_guard(h);
   if (!h || !out) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_episode_stats: out is required");
   const int field = from_accum ? RCG_FIELD_ACCUM : RCG_FIELD_RETURNS;
   const long B = h->cfg.batch;
@@ -566,6 +667,7 @@ int rcg_episode_stats(rcg_handle* h, int32_t from_accum, void* returns_out, rcg_
 
 // ---- measurement ----------------------------------------------------------------------------
 int rcg_profile(rcg_handle* h, int32_t enable) {
+  DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
   prof_drain(h);
   h->prof_mask = (unsigned)enable & 0xffu;
@@ -579,6 +681,7 @@ int rcg_profile(rcg_handle* h, int32_t enable) {
 }
 
 int rcg_profile_read(rcg_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
+  DeviceGuard dev_guard(h);
   if (!h || kernel < 0 || kernel >= RCG_KERNEL_COUNT_)
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_profile_read: bad kernel id");
   prof_drain(h);

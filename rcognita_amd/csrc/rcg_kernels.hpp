@@ -27,6 +27,14 @@ namespace rcg {
 
 enum : int { STAGE_FULL = 1, STAGE_BIQUAD = 2 };
 
+// Timing-only switches of k_actor_dma (they skip work, so results are WRONG): compiled in only with -DRCG_DEV
+// (`make dev` -> librcg_dev.so, used by tools/), constant 0 in the production library.
+#ifdef RCG_DEV
+#define RCG_DBG(A, bit) ((A).dbg & (bit))
+#else
+#define RCG_DBG(A, bit) 0
+#endif
+
 // Wave-uniform parameters, passed by value in the kernarg segment (=> scalar loads / SGPRs).
 // Kept small on purpose: the two full n x n stage-cost matrices live in a device buffer (`Rfull`)
 // that only the non-diagonal path reads; with them inline the struct overflowed the SGPR file and
@@ -205,7 +213,7 @@ struct ActorArgs {
   int gpw;                // k_actor_dma: consecutive envs per (persistent) wave
   int depth;              // k_actor_dma: tiles in flight per wave, 1 or 2 (2 needs K >= 128 and no J output)
   int jwave;              // k_actor_dma, J output: stage the costs of all envs of the wave in LDS (else env by env)
-  int dbg;                // development only (env RCG_DBG): bit0 = skip the rollout (timing-only build)
+  int dbg;                // -DRCG_DEV builds only (env RCG_DBG): bits skip parts of k_actor_dma for timing
   // k_actor_dma, fused env step of the tick (Simulator.sim_step inside the same launch): all nullptr / 0 otherwise
   real* sim_state;          // [ds][B] in/out
   real* sim_state_prev;     // [ds][B] out

@@ -176,7 +176,8 @@ static int op_critic_update(rcg_handle* h, int32_t do_fit) {
 // Development knobs of the actor launcher, read from the environment ONCE per process (they select between variants
 // of the same computation for A/B measurements; none of them changes results beyond rounding):
 //   RCG_ACTOR_KERNEL=plain  force k_actor instead of k_actor_dma      RCG_GPW=<n>  envs per persistent wave
-//   RCG_DBG=<bits>          1 skip the rollout, 2 skip argmin + writes, 4 skip env-state loads (timing only: wrong results)
+//   RCG_DBG=<bits>          -DRCG_DEV builds only (librcg_dev.so): 1 skip the rollout, 2 skip argmin + writes, 4 skip
+//                           env-state loads - timing only, wrong results; the production library ignores it
 //   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL on k_actor
 //   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
 //   RCG_DEPTH=2             two tiles in flight per wave               RCG_FUSE_SIM=1  env step in the actor's prologue
@@ -201,7 +202,9 @@ struct DevKnobs {
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
     DevKnobs v;
+#ifdef RCG_DEV
     if (const char* e = getenv("RCG_DBG")) v.dbg = atoi(e);
+#endif
     if (const char* e = getenv("RCG_ACTOR_KERNEL")) v.force_plain = !strcmp(e, "plain");
     if (const char* e = getenv("RCG_GPW")) v.gpw = atol(e);
     if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
@@ -456,6 +459,10 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
       return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_actor_optimize: horizon %d needs %zu B of LDS per block", N, lds);
     const dim3 grid(blocks_for(c.batch, 4 * OPT_G)), block(256);  // a wave owns OPT_G envs
     const bool tgt = c.flags & RCG_FLAG_HAS_TARGET;
+    if (tick) {  // rcg_control_tick_opt: the env step of the tick, once every argument check above has passed
+      const int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
+      if (rc) return rc;
+    }
     if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (the CU has 160 KB)
       const void* fn = tgt ? (const void*)&k_actor_opt<Sys, real, true> : (const void*)&k_actor_opt<Sys, real, false>;
       HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -232,22 +232,55 @@ class Engine:
         a = np.ascontiguousarray(arr, dtype=self.real if dtype is None else dtype)
         return DeviceArray(self, a.shape, a.dtype).upload(a)
 
-    def _in(self, x, keep, soa_from=None):
-        """Device pointer of an input.  numpy -> (optionally AoS->SoA transposed) upload."""
+    def _check_device_input(self, x, shape, dtype, what):
+        """A device-resident input goes to the kernels as a bare pointer: refuse anything whose element type, shape,
+        size or device differs from what the kernel will read (a float64 tensor on an f32 handle computes garbage, a
+        short one makes the kernel read past the allocation and faults the GPU)."""
+        dtype = np.dtype(dtype)
+        shape = tuple(int(v) for v in shape)
+        need = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if isinstance(x, DeviceArray):
+            if x.engine.cfg.device != self.cfg.device:
+                raise ValueError(f"{what}: DeviceArray lives on device {x.engine.cfg.device}, the handle on {self.cfg.device}")
+            if x.dtype != dtype:
+                raise ValueError(f"{what}: dtype {x.dtype} != {dtype} of this handle")
+            if x.ptr is None:
+                raise ValueError(f"{what}: DeviceArray was freed")
+            have, xshape = x.nbytes, x.shape
+        else:
+            if not x.is_cuda or not x.is_contiguous():
+                raise ValueError(f"{what}: torch inputs must be contiguous CUDA tensors in the device layout")
+            if x.device.index != self.cfg.device:
+                raise ValueError(f"{what}: tensor is on cuda:{x.device.index}, the handle on device {self.cfg.device}")
+            tname = str(x.dtype).replace("torch.", "")
+            if tname != dtype.name:
+                raise ValueError(f"{what}: dtype {tname} != {dtype.name} of this handle")
+            have, xshape = x.numel() * x.element_size(), tuple(x.shape)
+        if tuple(xshape) != shape:
+            raise ValueError(f"{what}: shape {tuple(xshape)} != expected device layout {shape}")
+        if have < need:
+            raise ValueError(f"{what}: {have} bytes, the kernel reads {need}")
+        return C.c_void_p(x.ptr if isinstance(x, DeviceArray) else x.data_ptr())
+
+    def _in(self, x, keep, soa_from=None, dev_shape=None, what="input", dtype=None):
+        """Device pointer of an input.  numpy -> (optionally AoS->SoA transposed) upload; device-resident inputs
+        (DeviceArray, torch) must already have the device layout ``dev_shape`` and the handle's element type."""
         if x is None:
             return None
-        if isinstance(x, DeviceArray):
-            return C.c_void_p(x.ptr)
-        if _is_torch(x):
-            if not x.is_cuda or not x.is_contiguous():
-                raise ValueError("torch inputs must be contiguous CUDA tensors in the device layout")
-            return C.c_void_p(x.data_ptr())
+        if isinstance(x, DeviceArray) or _is_torch(x):
+            if dev_shape is None:
+                raise ValueError(f"{what}: device-resident inputs are not accepted here")
+            return self._check_device_input(x, dev_shape, self.real if dtype is None else dtype, what)
         a = np.asarray(x, dtype=self.real)
         if soa_from is not None:
             a = soa_from(a)
         d = self.to_device(a)
         keep.append(d)
         return C.c_void_p(d.ptr)
+
+    def _in_soa(self, x, keep, d, what):
+        """Per-env input ``[B, d]`` on the host, or ``[d, B]`` already on the device."""
+        return self._in(x, keep, lambda a: a.reshape(self.B, d).T, dev_shape=(d, self.B), what=what)
 
     # ------------------------------------------------------------------ per-env tensors
     _FIELD_DIMS = {
@@ -279,8 +312,8 @@ class Engine:
         """Host array in the reference's shape (``[B, d]``, ``[B]``, ``[B, buffer_size, d]``)."""
         shape, dt, h2d, _ = self._field_meta(f)
         if isinstance(value, DeviceArray) or _is_torch(value):
-            ptr = value.ptr if isinstance(value, DeviceArray) else value.data_ptr()
-            N.check(N.lib().rcg_set_field(self._h, f, C.c_void_p(ptr), N.DEVICE), self._h)
+            ptr = self._check_device_input(value, shape, dt, f"set_field({f})")  # rcg_set_field copies the whole field
+            N.check(N.lib().rcg_set_field(self._h, f, ptr, N.DEVICE), self._h)
             return
         a = np.ascontiguousarray(h2d(np.asarray(value, dtype=dt)), dtype=dt)
         assert a.shape == shape, (a.shape, shape)
@@ -361,36 +394,41 @@ class Engine:
                                    self._in(w, keep, lambda a: a.T), C.c_void_p(out.ptr), n), self._h)
         return out.to_host()
 
-    def _cand(self, cand, keep):
-        """Candidates ``[B, K, N, du]`` (numpy / device).  Returns (pointer, K)."""
+    def _cand(self, cand, keep, K=None):
+        """Candidates ``[B, K, N, du]`` (numpy / device).  Returns (pointer, K).  An explicit ``K`` must agree with the
+        tensor: the kernels index ``B*K*N*du`` elements behind the pointer."""
         if cand is None:
-            return None, None
+            return None, (None if K is None else int(K))
         if isinstance(cand, DeviceArray) or _is_torch(cand):
-            shape = tuple(cand.shape)
-            K = shape[1] if len(shape) >= 2 else None
-            return self._in(cand, keep), K
-        a = np.asarray(cand, dtype=self.real)
-        if a.ndim == 3:  # [K, N, du] shared by all envs
-            a = np.broadcast_to(a[None], (self.B,) + a.shape)
-        a = a.reshape(self.B, -1, self.N, self.du)
-        return self._in(a, keep), a.shape[1]
+            shape = tuple(int(v) for v in cand.shape)
+            if len(shape) != 4:
+                raise ValueError(f"candidates on the device must be [B, K, N, du], got shape {shape}")
+            Kc = shape[1]
+            ptr = self._check_device_input(cand, (self.B, Kc, self.N, self.du), self.real, "candidates")
+        else:
+            a = np.asarray(cand, dtype=self.real)
+            if a.ndim == 3:  # [K, N, du] shared by all envs
+                a = np.broadcast_to(a[None], (self.B,) + a.shape)
+            a = a.reshape(self.B, -1, self.N, self.du)
+            ptr, Kc = self._in(a, keep), a.shape[1]
+        if K is not None and int(K) != Kc:
+            raise ValueError(f"K = {K} given, but the candidate tensor holds {Kc} sequences per env")
+        return ptr, Kc
 
     def actor_cost(self, cand, obs=None, state_sys=None, w=None):
         """``_actor_cost`` of every candidate: ``cand [B, K, N, du]`` -> ``J [B, K]``."""
         keep = []
         pc, K = self._cand(cand, keep)
         J = self.empty((self.B, K))
-        N.check(N.lib().rcg_actor_cost(self._h, pc, K, self._in(obs, keep, lambda a: a.reshape(self.B, self.dy).T),
-                                       self._in(state_sys, keep, lambda a: a.reshape(self.B, self.ds).T),
-                                       self._in(w, keep, lambda a: a.reshape(self.B, self.dc).T), C.c_void_p(J.ptr)),
-                self._h)
+        N.check(N.lib().rcg_actor_cost(self._h, pc, K, self._in_soa(obs, keep, self.dy, "obs"),
+                                       self._in_soa(state_sys, keep, self.ds, "state_sys"),
+                                       self._in_soa(w, keep, self.dc, "w"), C.c_void_p(J.ptr)), self._h)
         return J.to_host()
 
     def critic_cost(self, w=None):
         keep = []
         Jc = self.empty((self.B,))
-        N.check(N.lib().rcg_critic_cost(self._h, self._in(w, keep, lambda a: a.reshape(self.B, self.dc).T),
-                                        C.c_void_p(Jc.ptr)), self._h)
+        N.check(N.lib().rcg_critic_cost(self._h, self._in_soa(w, keep, self.dc, "w"), C.c_void_p(Jc.ptr)), self._h)
         return Jc.to_host()
 
     # ------------------------------------------------------------------ stateful steps
@@ -400,19 +438,21 @@ class Engine:
     def actor_argmin(self, cand=None, K=None, obs=None, state_sys=None):
         """Returns ``(action [B, du], best_J [B], best_idx [B] int32)``."""
         keep = []
-        pc, Kc = self._cand(cand, keep)
-        K = Kc if K is None else int(K)
+        pc, K = self._cand(cand, keep, K)
+        if K is None:
+            raise ValueError("actor_argmin: K is required with generated candidates (cand=None)")
         act, bj, bi = self.empty((self.du, self.B)), self.empty((self.B,)), self.empty((self.B,), np.int32)
-        N.check(N.lib().rcg_actor_argmin(self._h, pc, K, self._in(obs, keep, lambda a: a.reshape(self.B, self.dy).T),
-                                         self._in(state_sys, keep, lambda a: a.reshape(self.B, self.ds).T),
+        N.check(N.lib().rcg_actor_argmin(self._h, pc, K, self._in_soa(obs, keep, self.dy, "obs"),
+                                         self._in_soa(state_sys, keep, self.ds, "state_sys"),
                                          C.c_void_p(act.ptr), C.c_void_p(bj.ptr), C.c_void_p(bi.ptr)), self._h)
         return act.to_host().T.copy(), bj.to_host(), bi.to_host()
 
     def control_tick(self, cand=None, K=None):
         """One env.control-step for all envs.  ``cand`` on device for the timed path."""
         keep = []
-        pc, Kc = self._cand(cand, keep)
-        K = Kc if K is None else int(K)
+        pc, K = self._cand(cand, keep, K)
+        if K is None:
+            raise ValueError("control_tick: K is required with generated candidates (cand=None)")
         N.check(N.lib().rcg_control_tick(self._h, pc, K), self._h)
         if keep:  # temporaries were uploaded for this call: finish before they are freed
             self.synchronize()
@@ -426,8 +466,8 @@ class Engine:
             np.asarray(u_init, dtype=self.real).reshape(-1, self.N, self.du), (self.B, self.N, self.du)), keep)
         uo, act = self.empty((self.B, self.N, self.du)), self.empty((self.du, self.B))
         bj, ni = self.empty((self.B,)), self.empty((self.B,), np.int32)
-        N.check(N.lib().rcg_actor_optimize(self._h, int(iters), self._in(obs, keep, lambda a: a.reshape(self.B, self.dy).T),
-                                           self._in(state_sys, keep, lambda a: a.reshape(self.B, self.ds).T), pu,
+        N.check(N.lib().rcg_actor_optimize(self._h, int(iters), self._in_soa(obs, keep, self.dy, "obs"),
+                                           self._in_soa(state_sys, keep, self.ds, "state_sys"), pu,
                                            C.c_void_p(uo.ptr), C.c_void_p(act.ptr), C.c_void_p(bj.ptr),
                                            C.c_void_p(ni.ptr)), self._h)
         return act.to_host().T.copy(), uo.to_host(), bj.to_host(), ni.to_host()

@@ -9,18 +9,22 @@ from tests.helpers import PRESETS, oracle_cfg, rand_states, rel_err_norm
 pytestmark = pytest.mark.gpu
 
 
-def test_full_size_C3_2tank_rql_critic():
-    """configs[2]: Sys2Tank, B = 131072, Nactor = 20, RQL with the quadratic critic refit every tick.
-    Properties: integer counters exact for every env; a fit never increases Jc over w_init; weights stay in
-    the box; every env is independent of its position (first 16 envs alone == inside the batch); a random
-    sample of envs follows the oracle tick by tick."""
+@pytest.mark.parametrize("streamed", [False, True])
+def test_full_size_C3_2tank_rql_critic(streamed):
+    """configs[2]: Sys2Tank, B = 131072, Nactor = 20, RQL with the quadratic critic refit every tick, K = 256
+    candidates per env - generated level grid, and streamed from a [B][K][N][du] tensor (2.7 GB, k_actor_dma's critic
+    instances).  Properties: integer counters exact for every env; a fit never increases Jc over w_init; weights stay
+    in the box; every env is independent of its position (first 16 envs alone == inside the batch); a random sample
+    of envs follows the oracle on EVERY tick at 1e-5 (state, action, best_J, accum, critic weights, buffers;
+    oracle/parity.py)."""
+    from oracle import parity as PAR
     from rcognita_amd import Engine
     from rcognita_amd import _native as N
     from rcognita_amd.pool import preset_engine_config
 
-    B, K, Nh, T = 131072, 64, 20, 5
+    B, K, Nh, T = 131072, 256, 20, 5
     rng = np.random.default_rng(1234)
-    x0 = np.stack([rng.uniform(0, 2, B), rng.uniform(-2, 2, B)], axis=-1)
+    x0 = np.stack([rng.uniform(0, 2, B), rng.uniform(-2, 2, B)], axis=-1).astype(np.float32)
     kw = dict(Nactor=Nh, mode="RQL", critic_struct="quadratic", Ncritic=4, buffer_size=10, gamma=1.0, dtype="f32")
     eng = Engine(preset_engine_config("2tank", B, **kw))
     eng.set_state(x0)
@@ -29,24 +33,26 @@ def test_full_size_C3_2tank_rql_critic():
     sel = np.sort(rng.choice(B, 24, replace=False))
     cfg = oracle_cfg("2tank", n_actor=Nh, mode=O.MODE_RQL, critic_struct=O.CRITIC_QUADRATIC, n_critic=4,
                      buffer_size=10, gamma=1.0)
-    env = O.new_batch(cfg, x0[sel].astype(np.float32).astype(np.float64))
-    grid = O.grid_candidates(cfg, K)
-    follows = True
+    env = O.new_batch(cfg, x0[sel].astype(np.float64))
+    if streamed:
+        cand1 = rng.random((K, Nh, 1), dtype=np.float32)  # one candidate set, streamed per env
+        cand = eng.to_device(np.ascontiguousarray(np.broadcast_to(cand1, (B, K, Nh, 1))))
+        cand_small = small.to_device(np.ascontiguousarray(np.broadcast_to(cand1, (16, K, Nh, 1))))
+        cand_or = cand1.astype(np.float64)
+    else:
+        cand = cand_small = None
+        cand_or = O.grid_candidates(cfg, K)
+    rep = PAR.TickReport()
     for t in range(T):
-        eng.control_tick(None, K=K)
-        small.control_tick(None, K=K)
-        O.control_tick(cfg, env, grid)
-        bi = eng.get_field(N.FIELD_BEST_IDX)
-        if follows and np.array_equal(bi[sel], env.best_idx):
-            assert rel_err_norm(eng.get_state()[sel], env.state) < 1e-4
-            assert rel_err_norm(eng.get_field(N.FIELD_W_CRITIC)[sel], env.w_critic) < 1e-3
-        else:
-            follows = False  # an f32 near-tie flipped for one sampled env: stop the tick-by-tick comparison
-        assert t > 0 or follows  # the very first tick must agree
+        eng.control_tick(cand, K=K)
+        small.control_tick(cand_small, K=K)
+        dev = {k: v[sel] for k, v in PAR.device_fields(eng, N, critic=True).items()}
+        env = PAR.check_tick(cfg, env, cand_or, dev, tol=1e-5, report=rep, what=f"C3 t={t}")
+    assert rep.ticks == T
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STATUS), np.zeros(B, np.uint32))
     w = eng.get_field(N.FIELD_W_CRITIC)
-    assert np.all(w >= -1e-4) and np.all(w <= 1e3 + 1e-2)
+    assert np.all(w >= 0.0) and np.all(w <= 1e3)  # Wmin / Wmax of the quadratic critic (controllers.py:1030-1031)
     # position independence, bit for bit
     np.testing.assert_array_equal(small.get_state(), eng.get_state()[:16])
     np.testing.assert_array_equal(small.get_field(N.FIELD_W_CRITIC), w[:16])
@@ -54,7 +60,7 @@ def test_full_size_C3_2tank_rql_critic():
     # the fitted critic explains its own TD stack at least as well as the start point
     Jc_fit = eng.critic_cost()
     Jc_init = eng.critic_cost(np.ones((B, 6)))
-    assert np.all(Jc_fit <= Jc_init * (1 + 1e-3) + 1e-6)
+    assert np.all(Jc_fit <= Jc_init * (1 + 1e-5) + 1e-6)
     summ, _ = eng.episode_stats(from_accum=True)
     assert summ["count"] == B and summ["n_failed"] == 0 and np.isfinite(summ["sum"])
 
@@ -77,28 +83,27 @@ def test_mixed_pool_C5_shard(world, rank):
     states = {s.name: rand_states(rng, s.name, s.hi - s.lo) for s in pool.segments}
     pool.set_states(states)
     K, T = 256, 3
-    for _ in range(T):
+    from oracle import parity as PAR
+
+    sels, envs, cfgs, grids = {}, {}, {}, {}
+    for s in pool.segments:  # a sample of every segment against the oracle of its own system type, every tick, 1e-5
+        n = s.hi - s.lo
+        sels[s.name] = np.sort(rng.choice(n, 16, replace=False))
+        cfgs[s.name] = oracle_cfg(s.name, n_actor=15)
+        envs[s.name] = O.new_batch(cfgs[s.name], states[s.name][sels[s.name]].astype(np.float32).astype(np.float64))
+        grids[s.name] = O.grid_candidates(cfgs[s.name], K)
+    for t in range(T):
         pool.control_tick(K)
+        for s in pool.segments:
+            dev = {k: v[sels[s.name]] for k, v in PAR.device_fields(s.engine, N).items()}
+            envs[s.name] = PAR.check_tick(cfgs[s.name], envs[s.name], grids[s.name], dev, tol=1e-5,
+                                          what=f"C5 {s.name} t={t}")
     pool.synchronize()
     total_summ, per = pool.episode_stats(from_accum=True)
     assert total_summ["count"] == pool.n_envs and total_summ["n_failed"] == 0
-    # a sample of every segment against the oracle of its own system type
     for s in pool.segments:
         n = s.hi - s.lo
         np.testing.assert_array_equal(s.engine.get_field(N.FIELD_STEP_IDX), np.full(n, T, np.int32))
-        sel = np.sort(rng.choice(n, 16, replace=False))
-        cfg = oracle_cfg(s.name, n_actor=15)
-        env = O.new_batch(cfg, states[s.name][sel].astype(np.float32).astype(np.float64))
-        grid = O.grid_candidates(cfg, K)
-        ok = True
-        eng2_states = None
-        for t in range(T):
-            O.control_tick(cfg, env, grid)
-        bi = s.engine.get_field(N.FIELD_BEST_IDX)[sel]
-        if np.array_equal(bi, env.best_idx):  # otherwise an f32 near-tie flipped: trajectories legitimately differ
-            assert rel_err_norm(s.engine.get_state()[sel], env.state) < 1e-4, s.name
-            assert rel_err_norm(s.engine.get_field(N.FIELD_ACCUM)[sel], env.accum,
-                                floor=float(np.max(np.abs(env.accum)))) < 1e-4, s.name
         assert abs(per[s.name]["count"] - n) == 0
     pool.close()
 
@@ -126,20 +131,15 @@ def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B):
     J_or = O.actor_cost(cand1.astype(np.float64)[None], x0.astype(np.float64)[:, None, :], x0.astype(np.float64)[:, None, :],
                         cfg, pars=env.pars)
     assert J.shape == (B, K) and rel_err_norm(J, J_or) < 1e-5
-    same = np.ones(B, dtype=bool)
-    for _ in range(T):
+    from oracle import parity as PAR
+
+    rep = PAR.TickReport()
+    for t in range(T):  # EVERY env of the batch, every tick, 1e-5; near-ties (a handful in 32k argmins) are followed
         eng.control_tick(cand, K=K)
-        O.control_tick(cfg, env, cand1.astype(np.float64))
-        bi = eng.get_field(N.FIELD_BEST_IDX)
-        same &= bi == env.best_idx  # an env whose argmin flipped once is on a different trajectory from then on
-    assert same.mean() > 0.998  # f32 near-ties may flip a handful of 32k argmins
+        env = PAR.check_tick(cfg, env, cand1.astype(np.float64), PAR.device_fields(eng, N), tol=1e-5, report=rep,
+                             what=f"B={B} t={t}")
+    assert rep.ties <= 0.002 * B * T
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
-    assert rel_err_norm(eng.get_field(N.FIELD_BEST_J)[same], env.best_J[same]) < 1e-5
-    a_or = cand1[env.best_idx, 0, :]
-    np.testing.assert_array_equal(eng.get_field(N.FIELD_ACTION)[same], a_or[same])
-    tail = slice(B - 11, B)  # the ragged last waves in particular
-    assert np.array_equal(bi[tail], env.best_idx[tail]) or same[tail].mean() > 0.8
-    assert rel_err_norm(eng.get_field(N.FIELD_ACCUM)[same], env.accum[same], floor=float(np.max(np.abs(env.accum)))) < 1e-4
     summ, _ = eng.episode_stats(from_accum=True)
     assert summ["count"] == B and summ["n_failed"] == 0
 
@@ -156,22 +156,21 @@ def test_one_million_envs():
     eng = Engine(preset_engine_config("3wrobotNI", B, Nactor=Nh))
     x0 = rand_states(rng, "3wrobotNI", B).astype(np.float32)
     eng.set_state(x0)
-    for _ in range(T):
+    from oracle import parity as PAR
+
+    sel = np.sort(rng.choice(B, 64, replace=False))
+    cfg = oracle_cfg("3wrobotNI", n_actor=Nh)
+    env = O.new_batch(cfg, x0[sel].astype(np.float64))
+    grid = O.grid_candidates(cfg, K)
+    for t in range(T):
         eng.control_tick(None, K=K)
+        dev = {k: v[sel] for k, v in PAR.device_fields(eng, N).items()}
+        env = PAR.check_tick(cfg, env, grid, dev, tol=1e-5, what=f"2^20 envs t={t}")
     summ, returns = eng.episode_stats(from_accum=True, want_returns=True)
     assert summ["count"] == B and summ["n_failed"] == 0
     np.testing.assert_allclose(summ["sum"], returns.astype(np.float64).sum(), rtol=1e-9)
     assert summ["min"] == returns.min() and summ["max"] == returns.max()
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
-    sel = np.sort(rng.choice(B, 64, replace=False))
-    cfg = oracle_cfg("3wrobotNI", n_actor=Nh)
-    env = O.new_batch(cfg, x0[sel].astype(np.float64))
-    grid = O.grid_candidates(cfg, K)
-    for _ in range(T):
-        O.control_tick(cfg, env, grid)
-    ok = eng.get_field(N.FIELD_BEST_IDX)[sel] == env.best_idx
-    assert ok.mean() > 0.9
-    assert rel_err_norm(eng.get_state()[sel][ok], env.state[ok]) < 1e-4
     eng.episode_reset()
     np.testing.assert_array_equal(eng.get_field(N.FIELD_EPISODE_IDX), np.ones(B, np.int32))
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.zeros(B, np.int32))
