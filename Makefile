@@ -2,6 +2,10 @@
 #   make -j4        -> rcognita_amd/lib/librcg.so  +  oracle/_build/liboracle.so
 #   make lib        -> HIP library only (hipcc cross-compiles without a GPU)
 #   make oracle     -> C oracle only (gcc)
+#   make dev        -> rcognita_amd/lib/librcg_dev.so: the same sources with -DRCG_DEV (timing-only switches RCG_DBG of
+#                      k_actor_dma compiled in; for tools/ only - select it with RCG_LIB=.../librcg_dev.so)
+#   make asan       -> build/asan/abi_asan: the C oracle and the HOST side of librcg (host-only compile of the .hip units,
+#                      no device code) under clang -fsanitize=address,undefined, with tests/asan_driver.c; CPU only
 HIPCC   ?= hipcc
 CC      := gcc
 ARCH    ?= gfx950
@@ -16,6 +20,13 @@ HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-functi
 UNITS   := rcg_api rcg_sys_3wrobot rcg_sys_3wrobotni rcg_sys_2tank
 OBJS    := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(UNITS)))
 HDRS    := $(wildcard $(CSRC)/*.hpp) $(ROOT)include/rcg.h
+
+DEVOBJDIR := $(ROOT)build/obj_dev
+DEVOBJS   := $(addprefix $(DEVOBJDIR)/,$(addsuffix .o,$(UNITS)))
+ASANDIR   := $(ROOT)build/asan
+ASANOBJS  := $(addprefix $(ASANDIR)/,$(addsuffix .o,$(UNITS)))
+SANFLAGS  := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
+HOSTCLANG ?= /opt/rocm/lib/llvm/bin/clang
 
 all: lib oracle
 
@@ -34,7 +45,40 @@ $(ORACLE)/_build/liboracle.so: $(ORACLE)/oracle.c
 	@mkdir -p $(ORACLE)/_build
 	$(CC) -O2 -std=c11 -fPIC -shared -fopenmp -ffp-contract=off -Wall $(ORACLE)/oracle.c -o $@ -lm
 
-clean:
-	rm -rf $(LIBDIR)/librcg.so $(OBJDIR) $(ORACLE)/_build
+dev: $(LIBDIR)/librcg_dev.so
 
-.PHONY: all lib oracle clean
+$(DEVOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(DEVOBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DRCG_DEV -c $< -o $@
+
+$(LIBDIR)/librcg_dev.so: $(DEVOBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(DEVOBJS) -o $@
+
+# Sanitizer build (CPU only: GPU AddressSanitizer is not available on this pool).  --offload-host-only compiles the
+# host side of every .hip unit - the C ABI, argument checks, launch-geometry arithmetic - and drops the device code.
+asan: $(ASANDIR)/abi_asan
+
+$(ASANDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(ASANDIR)
+	$(HIPCC) -std=c++17 --offload-arch=$(ARCH) --offload-host-only $(SANFLAGS) -fPIC -Wall -Wno-unused-function \
+	  -ffp-contract=fast -I$(ROOT)include -c $< -o $@
+
+$(ASANDIR)/asan_driver.o: $(ROOT)tests/asan_driver.c $(ORACLE)/oracle.c $(ROOT)include/rcg.h
+	@mkdir -p $(ASANDIR)
+	$(HOSTCLANG) -std=c11 $(SANFLAGS) -ffp-contract=off -Wall -I$(ROOT)include -c $< -o $@
+
+# a host-only object still refers to the device image of its unit (__hip_fatbin_<hash>, registered with the runtime at
+# load time, read only when a kernel is first launched): there is none in this build, so each gets an empty definition
+$(ASANDIR)/no_device_image.c: $(ASANOBJS)
+	nm -u $(ASANOBJS) | grep -o '__hip_fatbin_[0-9a-f]*' | sort -u | \
+	  sed 's/.*/const unsigned char &[64] = {0};/' > $@
+
+$(ASANDIR)/abi_asan: $(ASANOBJS) $(ASANDIR)/asan_driver.o $(ASANDIR)/no_device_image.c
+	$(HOSTCLANG) -c $(ASANDIR)/no_device_image.c -o $(ASANDIR)/no_device_image.o
+	$(HIPCC) $(SANFLAGS) $(ASANOBJS) $(ASANDIR)/asan_driver.o $(ASANDIR)/no_device_image.o -o $@ -lm
+
+clean:
+	rm -rf $(LIBDIR)/librcg.so $(LIBDIR)/librcg_dev.so $(OBJDIR) $(DEVOBJDIR) $(ASANDIR) $(ORACLE)/_build
+
+.PHONY: all lib oracle dev asan clean

@@ -432,13 +432,23 @@ def main(argv=None):
     du, ds = 2, 5
 
     # ---- untimed: clock pre-spin (>= PRESPIN_S of the same kernels), then the W warm-up steps ------------------------
+    # The GPU reaches its steady clock after ~100 ticks (20 ms) of CONTINUOUS work and falls back within 10 ms of idling
+    # (tools/clock_ramp.py), so the spin never lets the queue run dry: the host waits on the event recorded two chunks
+    # ago, and the warm-up and the timed region follow without a gap.
     prespin = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < PRESPIN_S:
-        for _ in range(16):
+    t_spin = time.perf_counter()
+    evs = []
+    while True:
+        for _ in range(32):
             tick()
-        prespin += 16
-        torch.cuda.synchronize()
+        prespin += 32
+        ev = torch.cuda.Event()
+        ev.record()
+        evs.append(ev)
+        if len(evs) >= 3:
+            evs[-3].synchronize()
+            if time.perf_counter() - t_spin >= PRESPIN_S:
+                break
     for _ in range(args.warmup):
         tick()
     Bmax = B

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 100 /* 0.1.0 */
+#define RCG_VERSION 110 /* 0.1.1 */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -228,6 +228,12 @@ int rcg_actor_argmin(rcg_handle* h, const void* cand, int32_t K, const void* obs
  * candidates -> ACTION := winner's first action -> ACCUM += stage_obj(obs, action)*sampling_time ->
  * STEP_IDX += 1.  cand as rcg_actor_argmin. */
 int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
+/* T consecutive rcg_control_tick(h, NULL, K) - the loop of presets/main_3wrobot.py:415-468 for T sampling periods with
+ * the generated candidate grid - in ONE kernel launch: each env's wave keeps state, held action, ACCUM and STEP_IDX in
+ * registers and loops over {sim_step, K x _actor_cost, argmin, upd_accum_obj}.  Every field ends bit-identical to T
+ * single ticks (same arithmetic); BEST_J / BEST_IDX are the last tick's.  MPC without the disturbance model; other
+ * handles get RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of small batches. */
+int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398), MPC with a
  * diagonal R1: `iters` iterations of {adjoint gradient of _actor_cost w.r.t. the whole sequence, box-scaled
  * projected line search over 64 step lengths}.  obs / state_sys as rcg_actor_cost; u_init [B][N][du] (NULL:

@@ -421,6 +421,25 @@ def new_batch(cfg: OracleCfg, state0, action0=None, pars=None) -> EnvBatch:
     )
 
 
+def episode_reset(cfg: OracleCfg, env: EnvBatch, state_init, action_init=None):
+    """Episode boundary, twin of rcg_episode_reset (``Simulator.reset`` simulator.py:197-204 as intended +
+    ``CtrlOptPred.reset`` controllers.py:1046-1054): returns := accum, accum := 0, state := state_init, action :=
+    action_init (``action_min / 10`` by default), step_idx := 0, episode_idx += 1; the critic weights and both buffers
+    are RETAINED (the reference's reset touches only the clock and ``action_curr``).  Build-defined: the controller's
+    tick counter - and with it the critic period - restarts with the episode.  Returns the episode's returns."""
+    returns = env.accum.copy()
+    B = env.state.shape[0]
+    env.accum = np.zeros(B)
+    env.state = np.array(state_init, dtype=np.float64).reshape(B, cfg.ds)
+    env.state_prev = env.state.copy()
+    a0 = cfg.ctrl_bnds[:, 0] / 10.0 if action_init is None else np.asarray(action_init, dtype=np.float64)
+    env.action = np.array(np.broadcast_to(a0, (B, cfg.du)), dtype=np.float64)
+    env.step_idx = np.zeros(B, dtype=np.int32)
+    env.episode_idx = env.episode_idx + np.int32(1)
+    env.tick_count = 0
+    return returns
+
+
 def sim_substeps(cfg: OracleCfg, env: EnvBatch, n_substeps: int):
     """``n_substeps`` RK4 steps of size ``dt_sim`` under the held action (row 10)."""
     for _ in range(n_substeps):

@@ -564,6 +564,22 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
                        h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, sim_first);
 }
 
+int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K) {
+  DeviceGuard dev_guard(h);
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (T < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_ticks: T must be >= 1");
+  int rc = check_candidates(h, "rcg_control_ticks", nullptr, K);
+  if (rc) return rc;
+  if (h->cfg.mode != RCG_MODE_MPC)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED,
+                    "rcg_control_ticks: MPC only (RQL/SQL refit the critic between ticks: loop rcg_control_tick)");
+  if (h->cfg.flags & RCG_FLAG_DISTURB)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: not with the disturbance model (loop rcg_control_tick)");
+  rc = h->sys->ticks(h, T, K);
+  if (rc == RCG_OK) h->tick_count += T;
+  return rc;
+}
+
 int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
                        void* u_opt, void* action, void* best_J, int32_t* n_iter) {
   DeviceGuard dev_guard(h);

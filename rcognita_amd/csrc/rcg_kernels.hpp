@@ -252,6 +252,137 @@ __device__ __forceinline__ void stage_tile(const real* __restrict__ g, real* __r
   }
 }
 
+// ---- pieces shared by k_actor and k_ticks (same source => the persistent multi-tick kernel reproduces a sequence of
+// single ticks bit for bit; everything that could be contracted differently is an explicit fma) -------------------------
+// generated candidates: constant-over-horizon level grid (du = 1: K levels; du = 2: k -> (k / g, k % g))
+template <int DU, typename real>
+__device__ __forceinline__ void gen_candidate(const KParams<real>& P, int g, int k, real* ugen) {
+  const real den = (real)(g > 1 ? g - 1 : 1);
+  if (DU == 1) {
+    ugen[0] = fma_r((real)k, (P.hi[0] - P.lo[0]) / den, P.lo[0]);
+  } else {
+    const int gi = k / g, gj = k - gi * g;
+    ugen[0] = fma_r((real)gi, (P.hi[0] - P.lo[0]) / den, P.lo[0]);
+    ugen[DU - 1] = fma_r((real)gj, (P.hi[DU - 1] - P.lo[DU - 1]) / den, P.lo[DU - 1]);
+  }
+}
+
+// _actor_cost: explicit-Euler rollout + running cost (controllers.py:1284-1326) of ONE candidate: the row `urow`
+// (STREAM, step-major in LDS) or the constant sequence `ugen`.  MODE_C / SK_C / CS_C are compile-time values of mode /
+// stage_kind / critic_struct, -1 = read the runtime value: the caller dispatches once per tile, so the step loop
+// carries no mode / stage-structure / critic-structure branches (they cost more than the ~14 VALU ops of a 2tank step).
+template <typename Sys, typename real, bool TGT, bool STREAM, int MODE_C, int SK_C, int CS_C, typename WGet>
+__device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
+                                             const real* xs, const real* y0, const real* urow, const real* ugen,
+                                             WGet wget, real* u0) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  const int mode = MODE_C >= 0 ? MODE_C : P.mode;
+  const int sk = SK_C >= 0 ? SK_C : P.stage_kind;
+  const int cs = CS_C >= 0 ? CS_C : P.critic_struct;
+  const real h = P.h_pred;
+  real x[DS], y[DS];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    x[c] = xs[c];
+    y[c] = y0[c];
+  }
+  real J = 0, gk = 1;
+  real u[DU], up[DU];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) up[c] = 0;
+  for (int kk = 0; kk < N; ++kk) {
+#pragma unroll
+    for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];
+    if (kk == 0) {
+#pragma unroll
+      for (int c = 0; c < DU; ++c) u0[c] = u[c];
+    } else {
+      real d[DS];
+      // unclipped, as sys_rhs([], state, u[k-1]); f32: hardware v_sin/v_cos behind the exact reduction, as in
+      // k_actor_dma (3.7e-7 max abs error, 7 VALU ops instead of ~25: the generated-candidate regime is VALU-bound)
+      Sys::template rhs<real, std::is_same<real, float>::value>(pre, x, up, d);
+#pragma unroll
+      for (int c = 0; c < DS; ++c) {
+        x[c] = fma_r(h, d[c], x[c]);
+        y[c] = x[c];  // sys_out is the identity
+      }
+    }
+    real chi[NCHI];
+    make_chi<DS, DU, TGT, real>(P, y, u, chi);
+    if (mode == RCG_MODE_MPC) {
+      J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
+    } else if (mode == RCG_MODE_RQL) {
+      if (kk < N - 1)
+        J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
+      else
+        J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
+    } else {  // SQL
+      J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
+    }
+    gk *= P.gamma;
+#pragma unroll
+    for (int c = 0; c < DU; ++c) up[c] = u[c];
+  }
+  return J;
+}
+
+// Once per tile: pick the specialisation of rollout_cost for this handle's (mode, stage structure, critic structure).
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, typename WGet>
+__device__ __forceinline__ real rollout_dispatch(const KParams<real>& P, const typename Sys::template Pre<real>& pre,
+                                                 int N, const real* xs, const real* y0, const real* urow,
+                                                 const real* ugen, WGet wget, real* u0) {
+#define RCG_ROLL(M, S, C) rollout_cost<Sys, real, TGT, STREAM, M, S, C>(P, pre, N, xs, y0, urow, ugen, wget, u0)
+  if (!GENERIC) return RCG_ROLL(RCG_MODE_MPC, 0, -1);  // MPC, quadratic, diagonal R1
+  if (P.mode == RCG_MODE_MPC) return RCG_ROLL(RCG_MODE_MPC, -1, -1);
+  if (P.mode == RCG_MODE_RQL && P.stage_kind == 0) {
+    switch (P.critic_struct) {
+      case RCG_CRITIC_QUAD_LIN: return RCG_ROLL(RCG_MODE_RQL, 0, RCG_CRITIC_QUAD_LIN);
+      case RCG_CRITIC_QUADRATIC: return RCG_ROLL(RCG_MODE_RQL, 0, RCG_CRITIC_QUADRATIC);
+      case RCG_CRITIC_QUAD_NOMIX: return RCG_ROLL(RCG_MODE_RQL, 0, RCG_CRITIC_QUAD_NOMIX);
+      default: return RCG_ROLL(RCG_MODE_RQL, 0, RCG_CRITIC_QUAD_MIX);
+    }
+  }
+  if (P.mode == RCG_MODE_SQL) {  // no stage cost inside the SQL sum
+    switch (P.critic_struct) {
+      case RCG_CRITIC_QUAD_LIN: return RCG_ROLL(RCG_MODE_SQL, -1, RCG_CRITIC_QUAD_LIN);
+      case RCG_CRITIC_QUADRATIC: return RCG_ROLL(RCG_MODE_SQL, -1, RCG_CRITIC_QUADRATIC);
+      case RCG_CRITIC_QUAD_NOMIX: return RCG_ROLL(RCG_MODE_SQL, -1, RCG_CRITIC_QUAD_NOMIX);
+      default: return RCG_ROLL(RCG_MODE_SQL, -1, RCG_CRITIC_QUAD_MIX);
+    }
+  }
+  return RCG_ROLL(-1, -1, -1);  // RQL with a full-matrix / biquadratic stage cost
+#undef RCG_ROLL
+}
+
+// argmin over a segment of `seg` lanes (a power of two): lower J wins, ties -> lower candidate index; every lane of
+// the segment ends up with the winner
+template <int DU, typename real>
+__device__ __forceinline__ void segment_argmin(int seg, real& bestJ, int& bestI, real* bestU) {
+  for (int m = 1; m < seg; m <<= 1) {
+    const real oJ = __shfl_xor(bestJ, m, 64);
+    const int oI = __shfl_xor(bestI, m, 64);
+    real oU[DU];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) oU[c] = __shfl_xor(bestU[c], m, 64);
+    const bool take = (oJ < bestJ) || (oJ == bestJ && oI < bestI);
+    if (take) {
+      bestJ = oJ;
+      bestI = oI;
+#pragma unroll
+      for (int c = 0; c < DU; ++c) bestU[c] = oU[c];
+    }
+  }
+}
+
+// upd_accum_obj (controllers.py:1086-1093): accum + rho(obs, action) * sampling_time, one rounding
+template <typename Sys, bool TGT, typename real>
+__device__ __forceinline__ real accum_update(const KParams<real>& P, const real* obs, const real* act, real accum) {
+  constexpr int NCHI = Sys::DS + Sys::DU;
+  real chi[NCHI];
+  make_chi<Sys::DS, Sys::DU, TGT, real>(P, obs, act, chi);
+  return fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, accum);
+}
+
 template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM>
 __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
@@ -284,7 +415,6 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
     xs[c] = A.state_sys[(long)c * B + b];
   }
   const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
-  const real h = P.h_pred;
   // critic weights of this lane's env, once, into registers (they were re-read from memory at every use inside the
   // horizon loop: the J store below may alias them, so the compiler cannot hoist the loads itself)
   constexpr int DCMAX = GENERIC ? NCHI * (NCHI + 1) / 2 + NCHI : 1;
@@ -321,98 +451,11 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
       __builtin_amdgcn_wave_barrier();
       r = valid ? (big ? kl : e * K + kl) : 0;
     } else {
-      // generated candidates: constant-over-horizon level grid (du = 2: k -> (k / g, k % g))
-      const int g = A.grid_g;
-      const real den = (real)(g > 1 ? g - 1 : 1);
-      if (DU == 1) {
-        ugen[0] = P.lo[0] + (real)k * ((P.hi[0] - P.lo[0]) / den);
-      } else {
-        const int gi = k / g, gj = k - gi * g;
-        ugen[0] = P.lo[0] + (real)gi * ((P.hi[0] - P.lo[0]) / den);
-        ugen[DU - 1] = P.lo[DU - 1] + (real)gj * ((P.hi[DU - 1] - P.lo[DU - 1]) / den);
-      }
+      gen_candidate<DU, real>(P, A.grid_g, k, ugen);
     }
     const real* const urow = lds + (size_t)r * R;
-
-    // ---- _actor_cost: explicit-Euler rollout + running cost (controllers.py:1284-1326) --------
-    // One body, several compile-time specialisations: `mode_c / sk_c / cs_c` are integral constants (-1 = read the
-    // runtime value).  The dispatch below runs once per tile, so the step loop carries no mode / stage-structure /
-    // critic-structure branches (they cost more than the ~14 VALU ops of a 2tank step).
     real u0[DU];
-    auto rollout = [&](auto mode_c, auto sk_c, auto cs_c) -> real {
-      constexpr int MODE_C = decltype(mode_c)::value, SK_C = decltype(sk_c)::value, CS_C = decltype(cs_c)::value;
-      const int mode = MODE_C >= 0 ? MODE_C : P.mode;
-      const int sk = SK_C >= 0 ? SK_C : P.stage_kind;
-      const int cs = CS_C >= 0 ? CS_C : P.critic_struct;
-      real x[DS], y[DS];
-#pragma unroll
-      for (int c = 0; c < DS; ++c) {
-        x[c] = xs[c];
-        y[c] = y0[c];
-      }
-      real J = 0, gk = 1;
-      real u[DU], up[DU];
-#pragma unroll
-      for (int c = 0; c < DU; ++c) up[c] = 0;
-      for (int kk = 0; kk < N; ++kk) {
-#pragma unroll
-        for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];
-        if (kk == 0) {
-#pragma unroll
-          for (int c = 0; c < DU; ++c) u0[c] = u[c];
-        } else {
-          real d[DS];
-          // unclipped, as sys_rhs([], state, u[k-1]); f32: hardware v_sin/v_cos behind the exact reduction, as in
-          // k_actor_dma (3.7e-7 max abs error, 7 VALU ops instead of ~25: the generated-candidate regime is VALU-bound)
-          Sys::template rhs<real, std::is_same<real, float>::value>(pre, x, up, d);
-#pragma unroll
-          for (int c = 0; c < DS; ++c) {
-            x[c] = fma_r(h, d[c], x[c]);
-            y[c] = x[c];  // sys_out is the identity
-          }
-        }
-        real chi[NCHI];
-        make_chi<DS, DU, TGT, real>(P, y, u, chi);
-        if (mode == RCG_MODE_MPC) {
-          J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
-        } else if (mode == RCG_MODE_RQL) {
-          if (kk < N - 1)
-            J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
-          else
-            J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
-        } else {  // SQL
-          J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
-        }
-        gk *= P.gamma;
-#pragma unroll
-        for (int c = 0; c < DU; ++c) up[c] = u[c];
-      }
-      return J;
-    };
-    using std::integral_constant;
-    typedef integral_constant<int, -1> rt;
-    real J;
-    if (!GENERIC) {  // MPC, quadratic, diagonal R1
-      J = rollout(integral_constant<int, RCG_MODE_MPC>{}, integral_constant<int, 0>{}, rt{});
-    } else if (P.mode == RCG_MODE_MPC) {
-      J = rollout(integral_constant<int, RCG_MODE_MPC>{}, rt{}, rt{});
-    } else if (P.mode == RCG_MODE_RQL && P.stage_kind == 0) {
-      switch (P.critic_struct) {
-        case RCG_CRITIC_QUAD_LIN: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUAD_LIN>{}); break;
-        case RCG_CRITIC_QUADRATIC: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUADRATIC>{}); break;
-        case RCG_CRITIC_QUAD_NOMIX: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUAD_NOMIX>{}); break;
-        default: J = rollout(integral_constant<int, RCG_MODE_RQL>{}, integral_constant<int, 0>{}, integral_constant<int, RCG_CRITIC_QUAD_MIX>{}); break;
-      }
-    } else if (P.mode == RCG_MODE_SQL) {  // no stage cost inside the SQL sum
-      switch (P.critic_struct) {
-        case RCG_CRITIC_QUAD_LIN: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUAD_LIN>{}); break;
-        case RCG_CRITIC_QUADRATIC: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUADRATIC>{}); break;
-        case RCG_CRITIC_QUAD_NOMIX: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUAD_NOMIX>{}); break;
-        default: J = rollout(integral_constant<int, RCG_MODE_SQL>{}, rt{}, integral_constant<int, RCG_CRITIC_QUAD_MIX>{}); break;
-      }
-    } else {  // RQL with a full-matrix / biquadratic stage cost
-      J = rollout(rt{}, rt{}, rt{});
-    }
+    const real J = rollout_dispatch<Sys, real, GENERIC, TGT, STREAM>(P, pre, N, xs, y0, urow, ugen, wget, u0);
 
     if (A.J && valid) A.J[b * K + k] = J;
     const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
@@ -424,21 +467,7 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
     }
   }
 
-  // ---- argmin over the segment: lower J wins, ties -> lower candidate index -------------------
-  for (int m = 1; m < seg; m <<= 1) {
-    const real oJ = __shfl_xor(bestJ, m, 64);
-    const int oI = __shfl_xor(bestI, m, 64);
-    real oU[DU];
-#pragma unroll
-    for (int c = 0; c < DU; ++c) oU[c] = __shfl_xor(bestU[c], m, 64);
-    const bool take = (oJ < bestJ) || (oJ == bestJ && oI < bestI);
-    if (take) {
-      bestJ = oJ;
-      bestI = oI;
-#pragma unroll
-      for (int c = 0; c < DU; ++c) bestU[c] = oU[c];
-    }
-  }
+  segment_argmin<DU, real>(seg, bestJ, bestI, bestU);
 
   if (kl == 0 && env_ok) {
 #pragma unroll
@@ -446,11 +475,7 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
       if (A.action_out) A.action_out[(long)c * B + b] = bestU[c];
     if (A.best_J) A.best_J[b] = bestJ;
     if (A.best_idx) A.best_idx[b] = bestI;
-    if (A.accum) {  // upd_accum_obj (controllers.py:1086-1093)
-      real chi[NCHI];
-      make_chi<DS, DU, TGT, real>(P, y0, bestU, chi);
-      A.accum[b] += stage_any<NCHI, real>(P, chi) * P.sampling_time;
-    }
+    if (A.accum) A.accum[b] = accum_update<Sys, TGT, real>(P, y0, bestU, A.accum[b]);
     if (A.step_idx) A.step_idx[b] += 1;
   }
 }
@@ -469,42 +494,66 @@ struct SimArgs {
   int n_sub;
 };
 
+// Simulator.sim_step x n_sub for one env held in registers (shared by k_sim and k_ticks): clip the held action
+// (systems.py:241-243), n_sub RK4 substeps; a frozen env (status bit 0) is not stepped; a non-finite result freezes the
+// env at its last finite state and sets the bit (error convention).  On success x / xp (the state before
+// the last substep) / accum (accum_every_substep only) are updated and true is returned.
+template <typename Sys, typename real, bool TGT>
+__device__ __forceinline__ bool env_substeps(const KParams<real>& P, const typename Sys::template Pre<real>& pre,
+                                             int n_sub, real* x, real* xp, const real* a_held, uint32_t& st,
+                                             real& accum) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  if (st & 1u) return false;  // frozen env
+  real u[DU], xn[DS], xq[DS];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) u[c] = P.clip ? clamp_r<real>(a_held[c], P.lo[c], P.hi[c]) : a_held[c];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) xq[c] = xn[c] = x[c];
+  real acc = 0;
+  for (int s = 0; s < n_sub; ++s) {
+#pragma unroll
+    for (int c = 0; c < DS; ++c) xq[c] = xn[c];
+    rk4_step<Sys, real>(pre, xn, u, P.dt_sim);
+    if (P.accum_every_substep) {
+      real chi[NCHI];
+      make_chi<DS, DU, TGT, real>(P, xn, u, chi);
+      acc = fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, acc);
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < DS; ++c) ok = ok && finite_r<real>(xn[c]);
+  if (!ok) {
+    st |= 1u;
+    return false;
+  }
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    x[c] = xn[c];
+    xp[c] = xq[c];
+  }
+  if (P.accum_every_substep) accum += acc;
+  return true;
+}
+
 template <typename Sys, typename real, bool TGT>
 __global__ __launch_bounds__(256) void k_sim(const SimArgs<real> A, const KParams<real> P) {
-  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  constexpr int DS = Sys::DS, DU = Sys::DU;
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long B = P.B;
   if (b >= B) return;
-  const uint32_t st = A.status[b];
+  uint32_t st = A.status[b];
   if (st & 1u) return;  // frozen env
 
   real x[DS], xp[DS], u[DU];
 #pragma unroll
   for (int c = 0; c < DS; ++c) xp[c] = x[c] = A.state[(long)c * B + b];
 #pragma unroll
-  for (int c = 0; c < DU; ++c) {
-    const real a = A.action[(long)c * B + b];
-    u[c] = P.clip ? clamp_r<real>(a, P.lo[c], P.hi[c]) : a;  // systems.py:241-243
-  }
+  for (int c = 0; c < DU; ++c) u[c] = A.action[(long)c * B + b];
   const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
-  real acc = 0;
-
-  for (int s = 0; s < A.n_sub; ++s) {
-#pragma unroll
-    for (int c = 0; c < DS; ++c) xp[c] = x[c];
-    rk4_step<Sys, real>(pre, x, u, P.dt_sim);
-    if (P.accum_every_substep) {
-      real chi[NCHI];
-      make_chi<DS, DU, TGT, real>(P, x, u, chi);
-      acc = fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, acc);
-    }
-  }
-
-  bool ok = true;
-#pragma unroll
-  for (int c = 0; c < DS; ++c) ok = ok && finite_r<real>(x[c]);
-  if (!ok) {  // freeze the env at its last finite state and flag it (error convention)
-    A.status[b] = st | 1u;
+  real accum = P.accum_every_substep ? A.accum[b] : (real)0;
+  if (!env_substeps<Sys, real, TGT>(P, pre, A.n_sub, x, xp, u, st, accum)) {
+    A.status[b] = st;  // became non-finite: frozen at its last finite state, nothing else is written
     return;
   }
 #pragma unroll
@@ -512,7 +561,115 @@ __global__ __launch_bounds__(256) void k_sim(const SimArgs<real> A, const KParam
     A.state[(long)c * B + b] = x[c];
     A.state_prev[(long)c * B + b] = xp[c];
   }
-  if (P.accum_every_substep) A.accum[b] += acc;
+  if (P.accum_every_substep) A.accum[b] = accum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ticks: T control ticks in ONE launch, generated candidates (rcg_control_ticks)
+// ---------------------------------------------------------------------------------------------
+// Envs never interact, so a tick needs no grid-wide step: the wave that owns an env (or, K < 64, a segment of it) keeps
+// the env's state, held action, accum and counters in registers and loops `T` times over {Simulator.sim_step,
+// K x _actor_cost, argmin, upd_accum_obj}.  Every lane of the env's segment integrates the env step redundantly (~100
+// VALU ops next to K/seg rollouts of N steps each) - no cross-lane traffic, no LDS, no barrier - and the argmin
+// butterfly leaves the winner in every lane, which becomes the held action of the next tick.  The arithmetic is the code
+// k_sim and k_actor run (env_substeps, rollout_dispatch, segment_argmin, accum_update), so T ticks here equal T calls of
+// rcg_control_tick bit for bit.  What it removes is the launch-bound regime of small batches: two launches (~8 us) per
+// tick against ~1 us of work at B = 1024, K = 64.
+template <typename real>
+struct TicksArgs {
+  real* state;          // [ds][B] in/out
+  real* state_prev;     // [ds][B] in/out
+  real* action;         // [du][B] in/out: the held action (ZOH)
+  const real* pars_env; // [np][B] or nullptr
+  real* accum;          // [B] in/out
+  int32_t* step_idx;    // [B] in/out
+  uint32_t* status;     // [B] in/out
+  real* best_J;         // [B] out (last tick)
+  int32_t* best_idx;    // [B] out (last tick)
+  int T;                // ticks
+  int n_sub;            // RK4 substeps per tick
+  int K, Kp, G, n_tiles, grid_g;  // as ActorArgs
+};
+
+template <typename Sys, typename real, bool GENERIC, bool TGT>
+__global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU;
+  const int lane = threadIdx.x & 63;
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+  const long B = P.B;
+  const int K = A.K, N = P.n_actor;
+  if (wave * A.G >= B) return;  // wave-uniform: every wave that stays runs all T ticks and exits
+
+  const bool big = K >= 64;
+  const int seg = big ? 64 : A.Kp;
+  const int e = big ? 0 : lane / seg;
+  const int kl = big ? lane : lane - e * seg;
+  const long b_raw = wave * A.G + e;
+  const bool env_ok = b_raw < B;
+  const long b = env_ok ? b_raw : B - 1;
+
+  real x[DS], xp[DS], u[DU];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    x[c] = A.state[(long)c * B + b];
+    xp[c] = A.state_prev[(long)c * B + b];
+  }
+#pragma unroll
+  for (int c = 0; c < DU; ++c) u[c] = A.action[(long)c * B + b];
+  const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
+  uint32_t st = A.status[b];
+  real accum = A.accum[b];
+  int32_t steps = A.step_idx[b];
+  auto wget = [&](int) -> real { return (real)0; };  // MPC: no critic
+  real bestJ = inf_r<real>();
+  int bestI = 0x7fffffff;
+
+  for (int t = 0; t < A.T; ++t) {
+    env_substeps<Sys, real, TGT>(P, pre, A.n_sub, x, xp, u, st, accum);  // k_sim
+    const real* const xs = P.ref_lag ? xp : x;                           // rcg_control_tick's state_sys
+    bestJ = inf_r<real>();
+    bestI = 0x7fffffff;
+    real bestU[DU];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) bestU[c] = 0;
+    for (int tl = 0; tl < A.n_tiles; ++tl) {  // k_actor, generated candidates
+      const int k = big ? tl * 64 + kl : kl;
+      const bool valid = env_ok && k < K;
+      real ugen[DU], u0[DU];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) ugen[c] = 0;
+      gen_candidate<DU, real>(P, A.grid_g, k, ugen);
+      const real J = rollout_dispatch<Sys, real, GENERIC, TGT, false>(P, pre, N, xs, x, nullptr, ugen, wget, u0);
+      const real Jc = (J != J) ? inf_r<real>() : J;
+      if (valid && (Jc < bestJ || bestI == 0x7fffffff)) {
+        bestJ = Jc;
+        bestI = k;
+#pragma unroll
+        for (int c = 0; c < DU; ++c) bestU[c] = u0[c];
+      }
+    }
+    segment_argmin<DU, real>(seg, bestJ, bestI, bestU);
+#pragma unroll
+    for (int c = 0; c < DU; ++c) u[c] = bestU[c];  // receive_action: held until the next tick
+    if (!P.accum_every_substep) accum = accum_update<Sys, TGT, real>(P, x, u, accum);
+    steps += 1;
+  }
+
+  if (kl == 0 && env_ok) {
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+      A.state[(long)c * B + b] = x[c];
+      A.state_prev[(long)c * B + b] = xp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < DU; ++c) A.action[(long)c * B + b] = u[c];
+    A.accum[b] = accum;
+    A.step_idx[b] = steps;
+    A.status[b] = st;
+    A.best_J[b] = bestJ;
+    A.best_idx[b] = bestI;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

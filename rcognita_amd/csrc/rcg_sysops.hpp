@@ -477,6 +477,58 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
   });
 }
 
+// rcg_control_ticks: T ticks with generated candidates in one launch (k_ticks).  The caller has checked mode / flags / K.
+template <typename Sys>
+static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
+  constexpr int DU = Sys::DU;
+  const rcg_cfg& c = h->cfg;
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    const KParams<real>& P = params<real>(h);
+    TicksArgs<real> A;
+    memset(&A, 0, sizeof A);
+    A.state = (real*)h->f[RCG_FIELD_STATE];
+    A.state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
+    A.action = (real*)h->f[RCG_FIELD_ACTION];
+    A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    A.accum = (real*)h->f[RCG_FIELD_ACCUM];
+    A.step_idx = (int32_t*)h->f[RCG_FIELD_STEP_IDX];
+    A.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+    A.best_J = (real*)h->f[RCG_FIELD_BEST_J];
+    A.best_idx = (int32_t*)h->f[RCG_FIELD_BEST_IDX];
+    A.T = T;
+    A.n_sub = c.substeps_per_tick;
+    A.K = K;
+    if (K >= 64) {  // the tiling of launch_actor for generated candidates
+      A.Kp = 64;
+      A.G = 1;
+      A.n_tiles = (K + 63) / 64;
+    } else {
+      int kp = 1;
+      while (kp < K) kp <<= 1;
+      A.Kp = kp;
+      A.G = 64 / kp;
+      A.n_tiles = 1;
+    }
+    A.grid_g = DU == 1 ? K : (int)std::floor(std::sqrt((double)K) + 1e-9);
+    const long n_waves = (c.batch + A.G - 1) / A.G;
+    const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
+    const bool generic = P.stage_kind != 0;
+    const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
+    ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+    if (generic && tgt)
+      hipLaunchKernelGGL((k_ticks<Sys, real, true, true>), grid, block, 0, h->stream, A, P);
+    else if (generic)
+      hipLaunchKernelGGL((k_ticks<Sys, real, true, false>), grid, block, 0, h->stream, A, P);
+    else if (tgt)
+      hipLaunchKernelGGL((k_ticks<Sys, real, false, true>), grid, block, 0, h->stream, A, P);
+    else
+      hipLaunchKernelGGL((k_ticks<Sys, real, false, false>), grid, block, 0, h->stream, A, P);
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
 // CtrlNominal3WRobot / CtrlNominal3WRobotNI for n points (tick: the handle's envs, with the tick epilogue)
 template <typename Sys>
 static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double gain,
@@ -513,7 +565,7 @@ struct SysInstances {
   static SysVTable table() {
     return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,        &op_critic_cost<Sys>, &op_actor<Sys>,
                      &op_sim_step<Sys>, &op_critic_update<Sys>, &op_optimize<Sys>, &op_nominal<Sys>,
-                     &op_rhs_full<Sys>};
+                     &op_ticks<Sys>,  &op_rhs_full<Sys>};
   }
 };
 

@@ -457,6 +457,11 @@ class Engine:
         if keep:  # temporaries were uploaded for this call: finish before they are freed
             self.synchronize()
 
+    def control_ticks(self, T, K):
+        """``T`` env.control-steps with the generated candidate grid in ONE launch (rcg_control_ticks): bit-identical
+        to ``T`` calls of ``control_tick(None, K)``; MPC handles without the disturbance model."""
+        N.check(N.lib().rcg_control_ticks(self._h, int(T), int(K)), self._h)
+
     def actor_optimize(self, iters=10, obs=None, state_sys=None, u_init=None):
         """On-device actor optimiser (rcg_actor_optimize): adjoint gradient + 64-way projected line search.
         ``u_init [B, N, du]`` (None: the reference's ``action_sqn_init``).  Returns

@@ -23,22 +23,23 @@ SPEC = {
     "3wrobot": dict(cls=systems.Sys3WRobot, dim_state=5, dim_input=2, dim_disturb=2, pars=[10, 1],
                     ctrl_bnds=[[-300, 300], [-100, 100]], dt=0.01, t1=10.0, state_init=["5", "5", "-3*pi/4", "0", "0"],
                     action_manual=[-5, -3], Nactor=5, mult=2.0, R_diag=[1, 10, 1, 0, 0, 0, 0], target=[],
-                    action_init=[], modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"]),
+                    action_init=[], modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"], ctrl_mode="nominal"),
     "3wrobotNI": dict(cls=systems.Sys3WRobotNI, dim_state=3, dim_input=2, dim_disturb=2, pars=[],
                       ctrl_bnds=[[-25, 25], [-5, 5]], dt=0.01, t1=10.0, state_init=["5", "5", "-3*pi/4"],
                       action_manual=[-5, -3], Nactor=3, mult=1.0, R_diag=[1, 10, 1, 0, 0], target=[], action_init=[],
-                      modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"]),
+                      modes=["manual", "nominal", "MPC", "RQL", "SQL", "JACS"], ctrl_mode="nominal"),
     "2tank": dict(cls=systems.Sys2Tank, dim_state=2, dim_input=1, dim_disturb=1, pars=[18.4, 24.4, 1.3, 1, 0.2],
                   ctrl_bnds=[[0, 1]], dt=0.1, t1=100.0, state_init=["2", "-2"], action_manual=[0.5], Nactor=10,
                   mult=2.0, R_diag=[10, 10, 1], target=[0.5, 0.5], action_init=[0.5],
-                  modes=["manual", "MPC", "RQL", "SQL"]),
+                  modes=["manual", "MPC", "RQL", "SQL"], ctrl_mode="MPC"),
 }
 
 
 def build_parser(name: str) -> argparse.ArgumentParser:
     s = SPEC[name]
     p = argparse.ArgumentParser(description=f"rcognita_amd preset: {name} (flags of the reference preset)")
-    p.add_argument("--ctrl_mode", type=str, choices=s["modes"], default="MPC")
+    # default: 'nominal' for the two robots, 'MPC' for the tanks (presets/main_3wrobot.py:57-64, main_2tank.py:55-60)
+    p.add_argument("--ctrl_mode", type=str, choices=s["modes"], default=s["ctrl_mode"])
     p.add_argument("--dt", type=float, default=s["dt"])
     p.add_argument("--t1", type=float, default=s["t1"])
     p.add_argument("--Nruns", type=int, default=1)
@@ -63,8 +64,7 @@ def build_parser(name: str) -> argparse.ArgumentParser:
     p.add_argument("--critic_period_multiplier", type=float, default=1.0)
     p.add_argument("--critic_struct", type=str, default="quad-nomix",
                    choices=["quad-lin", "quadratic", "quad-nomix", "quad-mix"])
-    p.add_argument("--actor_struct", type=str, default="quad-nomix",
-                   choices=["quad-lin", "quadratic", "quad-nomix", "quad-mix"])
+    p.add_argument("--actor_struct", type=str, default="quad-nomix", choices=["quad-lin", "quadratic", "quad-nomix"])
     # build-specific
     p.add_argument("--batch", type=int, default=1, help="number of envs run through the same objects")
     p.add_argument("--state_spread", type=float, default=0.5, help="uniform perturbation of state_init per env (batch>1)")

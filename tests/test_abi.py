@@ -83,3 +83,25 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(path, errors="replace").read()
                 code = re.sub(r"//.*?$|/\*.*?\*/", "", txt, flags=re.S | re.M)  # comments may CITE the oracle
                 assert "oracle" not in code, path  # no #include, dlopen or symbol of the oracle in product code
+
+
+def test_documented_stub_matches_the_header(tmp_path):
+    """The `rcg_cfg` ctypes stub a maintainer would copy out of INTEGRATION.md: same fields as the binding, and
+    sizeof == sizeof(rcg_cfg) as gcc sees include/rcg.h (rcg_create refuses any other struct_size)."""
+    from rcognita_amd import _native as N
+
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"# BEGIN rcg_cfg stub.*?\n(class rcg_cfg.*?)\n# END rcg_cfg stub", md, flags=re.S)
+    assert m, "INTEGRATION.md lost its generated rcg_cfg stub (tools/gen_integration_stub.py)"
+    ns = {"C": ctypes}
+    exec(m.group(1), ns)
+    doc = ns["rcg_cfg"]
+    assert [f[0] for f in doc._fields_] == [f[0] for f in N.RcgCfg._fields_]
+    for name, _ in doc._fields_:
+        assert getattr(doc, name).offset == getattr(N.RcgCfg, name).offset, name
+        assert getattr(doc, name).size == getattr(N.RcgCfg, name).size, name
+    src = tmp_path / "size.c"
+    src.write_text('#include <stdio.h>\n#include "rcg.h"\nint main(){printf("%zu\\n", sizeof(rcg_cfg));return 0;}')
+    exe = tmp_path / "size"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert int(subprocess.check_output([str(exe)]).decode()) == ctypes.sizeof(doc)

@@ -1,0 +1,115 @@
+"""rcg_control_ticks: T control ticks with generated candidates in ONE launch (k_ticks) must leave every field of the
+handle BIT-IDENTICAL to T calls of rcg_control_tick (same arithmetic, no launch per tick).  ``gpu`` marked."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import parity as PAR
+from oracle import rcg_oracle as O
+from tests.helpers import both, rand_states
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["FIELD_STATE", "FIELD_STATE_PREV", "FIELD_ACTION", "FIELD_ACCUM", "FIELD_STEP_IDX", "FIELD_STATUS",
+          "FIELD_BEST_J", "FIELD_BEST_IDX"]
+
+
+def _pair(name, B, dtype, **kw):
+    a, cfg = both(name, B, dtype, **kw)
+    b, _ = both(name, B, dtype, **kw)
+    return a, b, cfg
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name,K,B,kw", [
+    ("3wrobot", 64, 1024, {}),                                        # the small-batch corner it is for
+    ("3wrobot", 256, 300, dict(substeps_per_tick=3, gamma=0.97)),    # 4 tiles per env, several substeps, discount
+    ("3wrobot", 16, 1030, dict(ref_lag=True)),                        # 4 envs per wave, ragged last wave, ref_lag
+    ("3wrobotNI", 100, 77, dict(accum_every_substep=True, substeps_per_tick=2)),
+    ("2tank", 32, 515, {}),                                           # du = 1, target
+    ("2tank", 5, 19, dict(stage_obj_struct=O.STAGE_BIQUADRATIC, R2=np.diag([1.0, 2.0, 0.5]))),  # generic stage cost
+])
+def test_T_ticks_in_one_launch_equal_T_single_ticks(name, K, B, kw, dtype):
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(K + B)
+    T = 7
+    one, many, cfg = _pair(name, B, dtype, n_actor=6, **kw)
+    x0 = rand_states(rng, name, B)
+    one.set_state(x0)
+    many.set_state(x0)
+    for _ in range(T):
+        one.control_tick(None, K=K)
+    many.control_ticks(T, K)
+    for f in FIELDS:
+        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+    # and it continues identically: 3 more in one launch against 3 more single ticks, then an episode reset
+    for _ in range(3):
+        one.control_tick(None, K=K)
+    many.control_ticks(3, K)
+    for e in (one, many):
+        e.episode_reset()
+    one.control_tick(None, K=K)
+    many.control_ticks(1, K)
+    for f in FIELDS + ["FIELD_RETURNS", "FIELD_EPISODE_IDX"]:
+        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+
+
+def test_ticks_follow_the_oracle_and_freeze_nonfinite_envs():
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(2)
+    B, K, T = 64, 64, 5
+    eng, cfg = both("3wrobot", B, "f64", n_actor=5)
+    x0 = rand_states(rng, "3wrobot", B)
+    x0[7, 3] = 1e308  # overflows inside the first RK4 step: frozen at its last finite state, flagged
+    eng.set_state(x0)
+    env = O.new_batch(cfg, np.delete(x0, 7, axis=0))
+    grid = O.grid_candidates(cfg, K)
+    eng.control_ticks(T, K)
+    for _ in range(T):
+        O.control_tick(cfg, env, grid)
+    ok = np.arange(B) != 7
+    st = eng.get_field(N.FIELD_STATUS)
+    assert st[7] == 1 and not st[ok].any()
+    np.testing.assert_array_equal(eng.get_state()[7], x0[7])
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_BEST_IDX)[ok], env.best_idx)
+    assert PAR.rel_err_norm(eng.get_state()[ok], env.state) < 1e-10
+    assert PAR.rel_err_norm(eng.get_field(N.FIELD_ACCUM)[ok], env.accum, floor=float(np.max(np.abs(env.accum)))) < 1e-10
+
+
+def test_ticks_refusals_change_nothing():
+    from rcognita_amd import _native as N
+
+    eng, _ = both("2tank", 8, "f32", n_actor=4, mode=O.MODE_RQL, n_critic=3, buffer_size=5)
+    eng.set_state(rand_states(np.random.default_rng(0), "2tank", 8))
+    x = eng.get_state().copy()
+    with pytest.raises(N.NativeError) as ei:
+        eng.control_ticks(3, 16)  # RQL: the critic is refitted between ticks
+    assert ei.value.code == N.ERR_UNSUPPORTED
+    mpc, _ = both("3wrobot", 8, "f32", n_actor=4)
+    for T, K in ((0, 16), (2, 50), (2, 0)):
+        with pytest.raises(N.NativeError) as ei:
+            mpc.control_ticks(T, K)
+        assert ei.value.code == N.ERR_BAD_ARG
+    np.testing.assert_array_equal(eng.get_state(), x)
+    np.testing.assert_array_equal(mpc.get_field(N.FIELD_STEP_IDX), np.zeros(8, np.int32))
+
+
+def test_small_batch_is_no_longer_launch_bound():
+    """SURVEY.md 7 step 5 / VERDICT r1 item 8: B = 1024, K = 64 was 1.25e8 env.control-steps/s with two launches per
+    tick; T ticks per launch must beat that clearly (measured: see DESIGN.md 5)."""
+    B, K, T = 1024, 64, 512
+    eng, _ = both("3wrobot", B, "f32", n_actor=10)
+    eng.set_state(rand_states(np.random.default_rng(1), "3wrobot", B))
+    eng.control_ticks(T, K)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        eng.control_ticks(T, K)
+    eng.synchronize()
+    rate = 4 * T * B / (time.perf_counter() - t0)
+    print(f"persistent ticks: {rate:.3e} env.control-steps/s at B={B}, K={K}")
+    assert rate > 2.5e8
