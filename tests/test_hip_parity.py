@@ -118,6 +118,39 @@ def test_F4_actor_cost_golden(name, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name", SYSTEMS)
+def test_F4b_reference_actor_cost_through_the_production_kernel(name, dtype):
+    """Numbers the REFERENCE produced (fixture F4b: its _actor_cost, controllers.py:1273-1328, state_sys == obs, 64
+    sequences per env) through the streamed production kernel: f32 K = 64, rows of N*du <= 32 reals, diagonal R1 ->
+    k_actor_dma - the gamma == 1 per-component instance (G1), the discounted instance, and the critic instances (RQL,
+    four structures).  Both the operator (J of every sequence, staged in LDS) and the argmin.  Inputs are stored as
+    float32, so the kernel reads exactly what the reference evaluated."""
+    meta, z = load_golden(f"F4b_actor_cost_dma_{name}")
+    for c in meta["cases"]:
+        tag = c["tag"]
+        x, aseq, w, J_ref = z[f"{tag}__state"], z[f"{tag}__action_sqn"], z[f"{tag}__w"], z[f"{tag}__J"]
+        B, K = J_ref.shape
+        eng, _ = both(name, B, dtype, n_actor=c["N"], mode=O.MODE_IDS[c["mode"]], gamma=c["gamma"],
+                      critic_struct=O.CRITIC_IDS[c["critic_struct"]], pred_step_size=c["pred_step_size"], buffer_size=4)
+        eng.set_state(x)
+        from rcognita_amd import _native as N
+
+        if c["mode"] != "MPC":
+            eng.set_field(N.FIELD_W_CRITIC, w)
+        cand = eng.to_device(aseq.astype(eng.real))  # device-resident [B][K][N][du]: the streamed path
+        J = eng.actor_cost(cand)  # obs = state_sys = the handle's STATE
+        scale = np.max(np.abs(J_ref), axis=1, keepdims=True)
+        err = float(np.max(np.abs(J - J_ref) / scale))
+        assert err <= TOL[dtype], f"{tag}: J rel err {err:.3e}"
+        a, bj, bi = eng.actor_argmin(cand)
+        ref_i = np.argmin(J_ref, axis=1)
+        for e in range(B):  # a float32 near-tie may take the runner-up: its reference cost within rounding of the best
+            assert bi[e] == ref_i[e] or abs(J_ref[e, bi[e]] - J_ref[e, ref_i[e]]) <= 4 * TOL[dtype] * scale[e, 0], tag
+            np.testing.assert_array_equal(a[e], aseq[e, bi[e], 0, :].astype(eng.real))
+            assert abs(bj[e] - J_ref[e, bi[e]]) <= TOL[dtype] * scale[e, 0], tag
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", SYSTEMS)
 def test_F5_critic_cost_golden(name, dtype):
     meta, z = load_golden(f"F5_critic_cost_{name}")
     from rcognita_amd import _native as N

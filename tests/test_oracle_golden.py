@@ -101,6 +101,22 @@ def test_F4_actor_cost(name):
 
 
 @pytest.mark.parametrize("name", SYSTEMS)
+def test_F4b_actor_cost_on_the_production_shape(name):
+    """F4b: 2 envs x 64 sequences per case, state_sys == obs, MPC gamma in {1, 0.95} and RQL x 4 critic structures
+    (oracle/gen_f4b_fixture.py) - the shape k_actor_dma serves."""
+    meta, z = load_golden(f"F4b_actor_cost_dma_{name}")
+    assert len(meta["cases"]) >= 16
+    for c in meta["cases"]:
+        tag = c["tag"]
+        cfg = oracle_cfg(name, n_actor=c["N"], mode=O.MODE_IDS[c["mode"]], gamma=c["gamma"],
+                         critic_struct=O.CRITIC_IDS[c["critic_struct"]], pred_step_size=c["pred_step_size"])
+        x = z[f"{tag}__state"].astype(np.float64)
+        J = O.actor_cost(z[f"{tag}__action_sqn"].astype(np.float64), x[:, None, :], x[:, None, :], cfg,
+                         w_critic=z[f"{tag}__w"].astype(np.float64)[:, None, :])
+        assert J.shape == (2, 64) and rel_err(J, z[f"{tag}__J"]) < 1e-11, tag
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
 def test_F5_critic_cost(name):
     meta, z = load_golden(f"F5_critic_cost_{name}")
     for c in meta["cases"]:
