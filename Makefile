@@ -1,5 +1,5 @@
 # Build the MI355X-native library (gfx950 only) and the CPU oracle.
-#   make -j4        -> rcognita_amd/lib/librcg.so  +  oracle/_build/liboracle.so
+#   make -j8        -> rcognita_amd/lib/librcg.so  +  oracle/_build/liboracle.so
 #   make lib        -> HIP library only (hipcc cross-compiles without a GPU)
 #   make oracle     -> C oracle only (gcc)
 #   make dev        -> rcognita_amd/lib/librcg_dev.so: the same sources with -DRCG_DEV (timing-only switches RCG_DBG of
@@ -17,14 +17,22 @@ ORACLE  := $(ROOT)oracle
 
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -ffp-contract=fast \
             -I$(ROOT)include
+# the C ABI + one unit per environment (every system-templated kernel except k_actor_dma)
 UNITS   := rcg_api rcg_sys_3wrobot rcg_sys_3wrobotni rcg_sys_2tank
-OBJS    := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(UNITS)))
+# k_actor_dma instances: rcg_dma_inst.hip compiled once per (system, element type, group), see that file
+DMA     := Sys3WRobot.float.0 Sys3WRobot.float.1 Sys3WRobot.double.0 \
+           Sys3WRobotNI.float.0 Sys3WRobotNI.float.1 Sys3WRobotNI.double.0 \
+           Sys2Tank.float.0 Sys2Tank.float.1 Sys2Tank.double.0
+DMAFLAGS = -DRCG_INST_SYS=$(word 1,$(subst ., ,$*)) -DRCG_INST_REAL=$(word 2,$(subst ., ,$*)) \
+           -DRCG_INST_GROUP=$(word 3,$(subst ., ,$*))
+objs     = $(addprefix $(1)/,$(addsuffix .o,$(UNITS))) $(addprefix $(1)/rcg_dma.,$(addsuffix .o,$(DMA)))
+OBJS    := $(call objs,$(OBJDIR))
 HDRS    := $(wildcard $(CSRC)/*.hpp) $(ROOT)include/rcg.h
 
 DEVOBJDIR := $(ROOT)build/obj_dev
-DEVOBJS   := $(addprefix $(DEVOBJDIR)/,$(addsuffix .o,$(UNITS)))
+DEVOBJS   := $(call objs,$(DEVOBJDIR))
 ASANDIR   := $(ROOT)build/asan
-ASANOBJS  := $(addprefix $(ASANDIR)/,$(addsuffix .o,$(UNITS)))
+ASANOBJS  := $(call objs,$(ASANDIR))
 SANFLAGS  := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
 HOSTCLANG ?= /opt/rocm/lib/llvm/bin/clang
 
@@ -32,6 +40,10 @@ all: lib oracle
 
 lib: $(LIBDIR)/librcg.so
 oracle: $(ORACLE)/_build/liboracle.so
+
+$(OBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(DMAFLAGS) -c $< -o $@
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
@@ -47,6 +59,10 @@ $(ORACLE)/_build/liboracle.so: $(ORACLE)/oracle.c
 
 dev: $(LIBDIR)/librcg_dev.so
 
+$(DEVOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+	@mkdir -p $(DEVOBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DRCG_DEV $(DMAFLAGS) -c $< -o $@
+
 $(DEVOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(DEVOBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRCG_DEV -c $< -o $@
@@ -58,11 +74,16 @@ $(LIBDIR)/librcg_dev.so: $(DEVOBJS)
 # Sanitizer build (CPU only: GPU AddressSanitizer is not available on this pool).  --offload-host-only compiles the
 # host side of every .hip unit - the C ABI, argument checks, launch-geometry arithmetic - and drops the device code.
 asan: $(ASANDIR)/abi_asan
+ASANHIP := -std=c++17 --offload-arch=$(ARCH) --offload-host-only $(SANFLAGS) -fPIC -Wall -Wno-unused-function \
+           -ffp-contract=fast -I$(ROOT)include
+
+$(ASANDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+	@mkdir -p $(ASANDIR)
+	$(HIPCC) $(ASANHIP) $(DMAFLAGS) -c $< -o $@
 
 $(ASANDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(ASANDIR)
-	$(HIPCC) -std=c++17 --offload-arch=$(ARCH) --offload-host-only $(SANFLAGS) -fPIC -Wall -Wno-unused-function \
-	  -ffp-contract=fast -I$(ROOT)include -c $< -o $@
+	$(HIPCC) $(ASANHIP) -c $< -o $@
 
 $(ASANDIR)/asan_driver.o: $(ROOT)tests/asan_driver.c $(ORACLE)/oracle.c $(ROOT)include/rcg.h
 	@mkdir -p $(ASANDIR)

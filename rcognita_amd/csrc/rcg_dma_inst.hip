@@ -1,0 +1,12 @@
+// rcg_dma_inst.hip - the k_actor_dma instances of ONE (system, element type, group), selected by the Makefile:
+//   -DRCG_INST_SYS=Sys3WRobot|Sys3WRobotNI|Sys2Tank  -DRCG_INST_REAL=float|double  -DRCG_INST_GROUP=0|1
+// (group 0: MPC gamma == 1, MPC discounted, RQL; group 1: SQL x 4 critic structures, f32 only).
+#include "rcg_dma_launch.hpp"
+
+#if !defined(RCG_INST_SYS) || !defined(RCG_INST_REAL) || !defined(RCG_INST_GROUP)
+#error "compile with -DRCG_INST_SYS=... -DRCG_INST_REAL=... -DRCG_INST_GROUP=... (see the Makefile)"
+#endif
+
+template bool rcg::launch_dma<rcg::RCG_INST_SYS, RCG_INST_REAL, RCG_INST_GROUP>(int, int, dim3, dim3, size_t, hipStream_t,
+                                                                            const rcg::ActorArgs<RCG_INST_REAL>&,
+                                                                            const rcg::KParams<RCG_INST_REAL>&);

@@ -1,0 +1,56 @@
+// rcg_dma_launch.hpp - definition of launch_dma<Sys, real, GROUP> (declared in rcg_actor_dma.hpp): picks the
+// k_actor_dma<Sys, real, R, Sys::TGT, V> instance for a runtime row length and variant.  Included only by
+// rcg_dma_inst.hip, which is compiled once per (system, element type, group): the ~700 kernel instances of the library
+// are spread over nine objects that build in parallel.
+#pragma once
+#include <type_traits>
+
+#include "rcg_actor_dma.hpp"
+
+namespace rcg {
+
+template <typename Sys, typename real, int GROUP, int R>
+static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
+                         const KParams<real>& P) {
+  if constexpr (R > dma_max_row<real>()) {
+    return false;
+  } else {
+    if (r != R) return launch_dma_r<Sys, real, GROUP, R + 1>(r, variant, grid, block, lds, s, A, P);
+    if constexpr (R % Sys::DU != 0) {
+      return false;
+    } else {
+#define RCG_DMA_CASE(V)                                                                            \
+  case V: hipLaunchKernelGGL((k_actor_dma<Sys, real, R, Sys::TGT, V>), grid, block, lds, s, A, P); \
+    return true;
+      if constexpr (GROUP == 0) {
+        switch (variant) {
+          RCG_DMA_CASE(DMA_MPC_G1)
+          RCG_DMA_CASE(DMA_MPC)
+          case DMA_RQL:
+            if constexpr (std::is_same<real, float>::value) {
+              hipLaunchKernelGGL((k_actor_dma<Sys, real, R, Sys::TGT, DMA_RQL>), grid, block, lds, s, A, P);
+              return true;
+            }
+            return false;
+        }
+      } else if constexpr (std::is_same<real, float>::value) {
+        switch (variant) {
+          RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUAD_LIN)
+          RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUADRATIC)
+          RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUAD_NOMIX)
+          RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUAD_MIX)
+        }
+      }
+#undef RCG_DMA_CASE
+      return false;
+    }
+  }
+}
+
+template <typename Sys, typename real, int GROUP>
+bool launch_dma(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
+                const KParams<real>& P) {
+  return launch_dma_r<Sys, real, GROUP, 1>(r, variant, grid, block, lds, s, A, P);
+}
+
+}  // namespace rcg

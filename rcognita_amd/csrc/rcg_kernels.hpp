@@ -211,15 +211,8 @@ struct ActorArgs {
   int grid_g;             // generated grid: levels per input
   int vec_ok;             // rows are 16-B granular: stage with dwordx4
   int gpw;                // k_actor_dma: consecutive envs per (persistent) wave
-  int depth;              // k_actor_dma: tiles in flight per wave, 1 or 2 (2 needs K >= 128 and no J output)
   int jwave;              // k_actor_dma, J output: stage the costs of all envs of the wave in LDS (else env by env)
   int dbg;                // -DRCG_DEV builds only (env RCG_DBG): bits skip parts of k_actor_dma for timing
-  // k_actor_dma, fused env step of the tick (Simulator.sim_step inside the same launch): all nullptr / 0 otherwise
-  real* sim_state;          // [ds][B] in/out
-  real* sim_state_prev;     // [ds][B] out
-  const real* sim_action;   // [du][B] the held action (ZOH); the decision overwrites it at the wave's end
-  uint32_t* sim_status;     // [B]
-  int sim_nsub;             // RK4 substeps
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));  // one 16-B global_load_dwordx4 / ds_write_b128

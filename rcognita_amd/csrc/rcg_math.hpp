@@ -54,9 +54,42 @@ __device__ __forceinline__ void sincos_hw(float x, float* s, float* c) {
   *c = __builtin_amdgcn_cosf(t);
 }
 
+// f64 rollout fast path (k_actor_dma<double>): FMA-based two-constant Cody-Waite reduction by pi/2 (the third constant
+// would contribute k * 1e-33) and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4] (the published
+// fdlibm coefficients): ~35 f64 VALU ops for both values where the device libm's sincos costs several hundred and
+// made the float64 rollout VALU-bound (0.66 ms per C2 launch with the candidate stream needing 0.41 ms).  Reduction
+// error <= 1.2e-16 absolute for |x| <= 1e6; measured against float64 libm (tools/trig_probe.hip): max abs error 2.3e-16.
+__device__ __forceinline__ void sincos_fast(double x, double* s, double* c) {
+  const double kf = __builtin_rint(x * 0.63661977236758134308);
+  double r = __builtin_fma(kf, -1.57079632679489655800e+00, x);  // fl(pi/2)
+  r = __builtin_fma(kf, -6.12323399573676603587e-17, r);         // pi/2 - fl(pi/2)
+  const double z = r * r;
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  const double sr = __builtin_fma(ps * z, r, r);
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  const double cr = __builtin_fma(pc * z, z, __builtin_fma(z, -0.5, 1.0));
+  const int k = (int)kf;
+  const double ss = (k & 1) ? cr : sr;
+  const double cc = (k & 1) ? sr : cr;
+  *s = (k & 2) ? -ss : ss;
+  *c = ((k + 1) & 2) ? -cc : cc;
+}
+
 template <typename real, bool HW>
 __device__ __forceinline__ void sincos_sel(real x, real* s, real* c) {
   sincos_r<real>(x, s, c);
+}
+template <>
+__device__ __forceinline__ void sincos_sel<double, true>(double x, double* s, double* c) {
+  sincos_fast(x, s, c);
 }
 template <>
 __device__ __forceinline__ void sincos_sel<float, true>(float x, float* s, float* c) {

@@ -178,26 +178,22 @@ static int op_critic_update(rcg_handle* h, int32_t do_fit) {
 //   RCG_ACTOR_KERNEL=plain  force k_actor instead of k_actor_dma      RCG_GPW=<n>  envs per persistent wave
 //   RCG_DBG=<bits>          -DRCG_DEV builds only (librcg_dev.so): 1 skip the rollout, 2 skip argmin + writes, 4 skip
 //                           env-state loads - timing only, wrong results; the production library ignores it
-//   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL on k_actor
+//   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL / SQL on k_actor
 //   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
-//   RCG_DEPTH=2             two tiles in flight per wave               RCG_FUSE_SIM=1  env step in the actor's prologue
 //   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor
-// tests/test_hip_knobs.py checks that the scheduling variants reproduce the default launch bit for bit.
+// tests/test_hip_knobs.py checks that the scheduling variants reproduce the default launch bit for bit; bench.py
+// refuses to run with any RCG_* variable set.
 struct DevKnobs {
   int dbg = 0;
   bool force_plain = false, no_g1 = false;
   long gpw = 0;
   long lds_pad = 0;  // RCG_LDS_PAD=<bytes>: extra dynamic LDS per block, caps the resident blocks per CU (-1: no cap)
   int per_cu = 0;    // RCG_PER_CU=2|4|8: resident blocks per CU for k_actor_dma (0: by row length)
-  int depth = 0;     // RCG_DEPTH=2: two tiles in flight per wave (default: one)
-  bool fuse_sim = false;  // RCG_FUSE_SIM=1: the tick's env step runs in k_actor_dma's prologue (see launch_actor)
   // RCG_PLAIN_LDS=<bytes>: minimum dynamic-LDS request of the streamed k_actor, i.e. a residency cap.  Unlike
   // k_actor_dma, k_actor has no direct-to-LDS prefetch and hides latency with occupancy: 4 blocks/CU measured 7 %
   // slower than 8, 2 blocks/CU 68 % slower (configs[2], SQL, streamed) - the default is no cap.
   long plain_lds = 0;
-  bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL goes to k_actor too (the state before the CRIT instances existed)
-  // modes k_actor_dma serves: MPC, and RQL through its CRIT instances; SQL stays on k_actor (measured 18 % faster there)
-  bool dma_serves(int mode) const { return mode == RCG_MODE_MPC || (mode == RCG_MODE_RQL && !mpc_only); }
+  bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL and SQL go to k_actor (A/B against the critic instances)
 };
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
@@ -209,8 +205,6 @@ static inline const DevKnobs& dev_knobs() {
     if (const char* e = getenv("RCG_GPW")) v.gpw = atol(e);
     if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
     if (const char* e = getenv("RCG_PER_CU")) v.per_cu = atoi(e);
-    if (const char* e = getenv("RCG_DEPTH")) v.depth = atoi(e);
-    v.fuse_sim = getenv("RCG_FUSE_SIM") != nullptr;
     if (const char* e = getenv("RCG_PLAIN_LDS")) v.plain_lds = atol(e);
     v.mpc_only = getenv("RCG_DMA_MPC_ONLY") != nullptr;
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
@@ -220,36 +214,6 @@ static inline const DevKnobs& dev_knobs() {
 }
 
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
-// Pick the k_actor_dma<Sys, R> instance for a runtime row length (R = N*du floats, 1..32, multiple of du).
-template <typename Sys, int R>
-static bool launch_dma_r(int r, bool tgt, bool g1, bool crit, dim3 grid, dim3 block, size_t lds, hipStream_t s,
-                         const ActorArgs<float>& A, const KParams<float>& P) {
-  if constexpr (R > 32) {
-    return false;
-  } else {
-    if (r == R) {
-      if constexpr (R % Sys::DU == 0) {
-        if (crit && tgt)  // RQL / SQL (the gamma == 1 specialisation is an MPC one)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, false, true>), grid, block, lds, s, A, P);
-        else if (crit)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, false, true>), grid, block, lds, s, A, P);
-        else if (tgt && g1)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, true, false>), grid, block, lds, s, A, P);
-        else if (tgt)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, true, false, false>), grid, block, lds, s, A, P);
-        else if (g1)
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, true, false>), grid, block, lds, s, A, P);
-        else
-          hipLaunchKernelGGL((k_actor_dma<Sys, R, false, false, false>), grid, block, lds, s, A, P);
-        return true;
-      } else {
-        return false;
-      }
-    }
-    return launch_dma_r<Sys, R + 1>(r, tgt, g1, crit, grid, block, lds, s, A, P);
-  }
-}
-
 // `sim_first`: rcg_control_tick (MPC) - run the env step of the tick before the decision.
 template <typename Sys, typename real>
 static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K, const void* obs,
@@ -316,77 +280,67 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
 
-  // Production shape (f32, MPC + diagonal R1, K a multiple of 64, rows of R <= 32 floats) -> k_actor_dma.
+  // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K a multiple of 64, diagonal quadratic
+  // stage cost, rollout from the observation, the preset's observation target; f32: rows of <= 32 reals, MPC / RQL /
+  // SQL; f64: rows of <= 20 reals, MPC.
   const DevKnobs& knobs = dev_knobs();
   A.dbg = knobs.dbg;
-  const bool force_plain = knobs.force_plain;
-  bool dma_ok = false;
-  if constexpr (std::is_same<real, float>::value)
-    dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= 32 && P.stage_kind == 0 &&
-             knobs.dma_serves(c.mode) && A.obs == A.state_sys && !force_plain &&
-             !(A.J && (size_t)4 * 256 * R + (size_t)16 * K > (size_t)64 * 1024);  // J staging must fit next to the tiles
+  constexpr bool is_f32 = std::is_same<real, float>::value;
+  constexpr size_t esz = sizeof(real);
+  const size_t tile = (size_t)64 * R * esz;  // one wave's LDS tile
+  const bool mode_ok = c.mode == RCG_MODE_MPC || (is_f32 && !knobs.mpc_only);
+  const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 64) == 0 && R <= dma_max_row<real>() &&
+                      P.stage_kind == 0 && mode_ok && tgt == Sys::TGT && A.obs == A.state_sys && !knobs.force_plain &&
+                      !(A.J && 4 * tile + 4 * esz * K > (size_t)64 * 1024);  // J staging must fit next to the tiles
   // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
-  // RCG_FUSE_SIM=1 fuses it into k_actor_dma's prologue instead (same rk4_step code: every field bit-identical over a
-  // 7-tick ragged run) - measured a wash: the kernel gets 3-4 % slower (each wave integrates its envs in front of its
-  // first tile, not hidden at 2 waves per SIMD), the tick 0.206-0.210 ms against 0.2055-0.208 ms.  Off by default.
-  const bool fuse_sim = sim_first && dma_ok && knobs.fuse_sim &&
-                        !(c.flags & (RCG_FLAG_DISTURB | RCG_FLAG_ACCUM_EVERY_SUBSTEP));
-  if (sim_first && !fuse_sim) {
+  if (sim_first) {
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
     if (rc) return rc;
   }
   ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
-  if constexpr (std::is_same<real, float>::value) {
-    if (dma_ok) {
-      // Launch geometry, measured on MI355X at C2 (B = 65536, K = 256, N = 10):
-      //  * residency: 2 blocks (8 waves) per CU stream faster than 8 blocks per CU - 0.204 ms against 0.213-0.218 ms.
-      //    The dynamic-LDS request is raised to 56 KB so that at most two blocks fit into the CU's 160 KB;
-      //  * envs per wave (gpw): each wave writes the results of its gpw envs once, coalesced, so gpw >= 4 turns 6
-      //    scattered 4-byte writes per env into 16-64-byte segments; powers of two only (3, 6 measured 2-3 % slower);
-      //  * rounds: the grid must be several times the 512 resident blocks so that the CUs stay balanced (single-round
-      //    grids that do not divide evenly over 256 CUs lost 10 %: gpw = 20, 28, 48) - gpw is the largest power of
-      //    two <= 16 that still leaves >= 8192 waves.
-      long gpw = 1;
-      while (gpw < 16 && B / (gpw * 2) >= 8192) gpw *= 2;
-      if (knobs.gpw > 0) gpw = knobs.gpw;
-      gpw = gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
-      A.gpw = (int)gpw;
-      const long pw = (B + gpw - 1) / gpw;
-      const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
-      const bool g1 = c.gamma == 1.0 && !knobs.no_g1;  // per-component accumulation (rcg_actor_dma.hpp)
-      // blocks per CU: 2 for rows of >= 20 floats (a block keeps R KiB in flight), 4 for shorter rows, which need more
-      // waves to keep enough bytes on the wire (measured R = 6 ... 32: 2 vs 4 differ by 1-3 % either side of R = 20,
-      // R = 10 with 2 blocks/CU is 9 % slower than with 4; 8 blocks/CU is 5-15 % slower than the better of the two)
-      const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : (R >= 20 ? 2 : 4);
-      // RCG_DEPTH=2: two tiles in flight per wave (double-buffered LDS tile, exact vmcnt bookkeeping; needs an env of
-      // at least two tiles and no per-candidate J store inside the loop, because stores and loads retire out of order
-      // with respect to each other).  Measured 1.5-3 % SLOWER than one tile in flight on C2 and on N = 5, K = 128,
-      // K = 512 (+0.7 % only at N = 16): the default stays 1.
-      A.depth = (knobs.depth == 2 && K >= 128 && !A.J && !fuse_sim) ? 2 : 1;  // (the fused step's stores: as J)
-      if (fuse_sim) {
-        A.sim_state = (float*)h->f[RCG_FIELD_STATE];
-        A.sim_state_prev = (float*)h->f[RCG_FIELD_STATE_PREV];
-        A.sim_action = (const float*)h->f[RCG_FIELD_ACTION];
-        A.sim_status = (uint32_t*)h->f[RCG_FIELD_STATUS];
-        A.sim_nsub = c.substeps_per_tick;
-      }
-      // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
-      A.jwave = (A.J && (size_t)4 * 256 * R * A.depth + (size_t)16 * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
-      size_t lds_req = (size_t)4 * 256 * R * A.depth + (A.J ? (size_t)16 * K * (A.jwave ? gpw : 1) : 0);
-      if (knobs.lds_pad > 0) {
-        lds_req += (size_t)knobs.lds_pad;
-      } else if (knobs.lds_pad == 0) {  // RCG_LDS_PAD=-1: no residency cap
-        const size_t want = per_cu <= 2 ? (size_t)56 * 1024 : (per_cu <= 4 ? (size_t)36 * 1024 : 0);
-        if (lds_req < want) lds_req = want;
-      }
-      const bool crit = c.mode == RCG_MODE_RQL;  // the CRIT instances (critic weights travel with the env state)
-      // (blocks of 4 waves = one wave per SIMD: blocks of 2 or 1 waves at the same 8 resident waves per CU measured
-      // 10-13 % slower)
-      if (!launch_dma_r<Sys, 1>(R, tgt, g1 && !crit, crit, grid, block, lds_req, h->stream, A, P))
-        return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d floats", who, R);
-      HIPCHK(h, hipGetLastError());
-      return RCG_OK;
+  if (dma_ok) {
+    // Launch geometry, measured on MI355X at C2 (B = 65536, K = 256, N = 10):
+    //  * residency: 2 blocks (8 waves) per CU stream faster than 8 blocks per CU - 0.204 ms against 0.213-0.218 ms.
+    //    The dynamic-LDS request is raised to 56 KB so that at most two blocks fit into the CU's 160 KB;
+    //  * envs per wave (gpw): each wave writes the results of its gpw envs once, coalesced, so gpw >= 4 turns 6
+    //    scattered 4-byte writes per env into 16-64-byte segments; powers of two only (3, 6 measured 2-3 % slower);
+    //  * rounds: the grid must be several times the 512 resident blocks so that the CUs stay balanced (single-round
+    //    grids that do not divide evenly over 256 CUs lost 10 %: gpw = 20, 28, 48) - gpw is the largest power of
+    //    two <= 16 that still leaves >= 8192 waves.
+    long gpw = 1;
+    while (gpw < 16 && B / (gpw * 2) >= 8192) gpw *= 2;
+    if (knobs.gpw > 0) gpw = knobs.gpw;
+    gpw = gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
+    A.gpw = (int)gpw;
+    const long pw = (B + gpw - 1) / gpw;
+    const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
+    // blocks per CU: 2 for rows of >= 80 bytes (a block keeps R KiB in flight), 4 for shorter rows, which need more
+    // waves to keep enough bytes on the wire (measured R = 6 ... 32 floats: 2 vs 4 differ by 1-3 % either side of
+    // R = 20, R = 10 with 2 blocks/CU is 9 % slower than with 4; 8 blocks/CU is 5-15 % slower than the better of the two)
+    const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : (row_bytes >= 80 ? 2 : 4);
+    // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
+    A.jwave = (A.J && 4 * tile + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
+    size_t lds_req = 4 * tile + (A.J ? 4 * esz * K * (A.jwave ? gpw : 1) : 0);
+    if (knobs.lds_pad > 0) {
+      lds_req += (size_t)knobs.lds_pad;
+    } else if (knobs.lds_pad == 0) {  // RCG_LDS_PAD=-1: no residency cap
+      const size_t want = per_cu <= 2 ? (size_t)56 * 1024 : (per_cu <= 4 ? (size_t)36 * 1024 : 0);
+      if (lds_req < want) lds_req = want;
     }
+    // (blocks of 4 waves = one wave per SIMD: blocks of 2 or 1 waves at the same 8 resident waves per CU measured
+    // 10-13 % slower)
+    int variant;
+    if (c.mode == RCG_MODE_MPC)
+      variant = (c.gamma == 1.0 && !knobs.no_g1) ? DMA_MPC_G1 : DMA_MPC;  // per-component accumulation when gamma == 1
+    else if (c.mode == RCG_MODE_RQL)
+      variant = DMA_RQL;
+    else
+      variant = DMA_SQL_0 + c.critic_struct;
+    const bool ok = variant >= DMA_SQL_0 ? launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P)
+                                         : launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, A, P);
+    if (!ok) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d reals", who, R);
+    HIPCHK(h, hipGetLastError());
+    return RCG_OK;
   }
 #define RCG_LAUNCH_ACTOR(GEN, TGT, STR) \
   hipLaunchKernelGGL((k_actor<Sys, real, GEN, TGT, STR>), dim3(blocks), dim3(64 * wpb), lds, h->stream, A, P)

@@ -14,6 +14,7 @@ namespace rcg {
 // rcognita/systems.py:308-323  state = (x, y, alpha, v, omega), action = (F, M), pars = (m, I)
 struct Sys3WRobot {
   static constexpr int DS = 5, DU = 2, NP = 2;
+  static constexpr bool TGT = false;  // observation_target of the preset: [] (k_actor_dma instances exist for this value)
   template <typename real>
   struct Pre {
     real inv_m, inv_I;
@@ -51,6 +52,7 @@ struct Sys3WRobot {
 // rcognita/systems.py:370-382  state = (x, y, alpha), action = (v, omega), no pars
 struct Sys3WRobotNI {
   static constexpr int DS = 3, DU = 2, NP = 0;
+  static constexpr bool TGT = false;
   template <typename real>
   struct Pre {};
   template <typename real>
@@ -81,6 +83,7 @@ struct Sys3WRobotNI {
 // rcognita/systems.py:412-419  state = (h1, h2), action = (u), pars = (tau1, tau2, K1, K2, K3)
 struct Sys2Tank {
   static constexpr int DS = 2, DU = 1, NP = 5;
+  static constexpr bool TGT = true;  // main_2tank.py:211: observation_target = [0.5, 0.5]
   template <typename real>
   struct Pre {
     real inv_tau1, inv_tau2, K1, K2, K3;

@@ -28,8 +28,8 @@ def _run(env_extra):
 
 def test_scheduling_variants_are_bit_identical():
     base = _run({})
-    for knobs in ({"RCG_FUSE_SIM": "1"},                     # env step fused into the actor kernel's prologue
-                  {"RCG_DEPTH": "2"},                        # two tiles in flight per wave
-                  {"RCG_GPW": "1", "RCG_LDS_PAD": "-1"},     # one env per wave, no residency cap (the first geometry)
-                  {"RCG_GPW": "16", "RCG_PER_CU": "4"}):
+    for knobs in ({"RCG_GPW": "1", "RCG_LDS_PAD": "-1"},     # one env per wave, no residency cap (the first geometry)
+                  {"RCG_GPW": "16", "RCG_PER_CU": "4"},
+                  {"RCG_GPW": "3", "RCG_PER_CU": "8"},       # envs per wave not a power of two
+                  {"RCG_DBG": "7"}):                         # timing-only switches: compiled OUT of the production library
         assert _run(knobs) == base, knobs
