@@ -51,7 +51,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 
 $(LIBDIR)/librcg.so: $(OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined $(OBJS) -o $@
 
 $(ORACLE)/_build/liboracle.so: $(ORACLE)/oracle.c
 	@mkdir -p $(ORACLE)/_build
@@ -69,7 +69,7 @@ $(DEVOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 
 $(LIBDIR)/librcg_dev.so: $(DEVOBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(DEVOBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined $(DEVOBJS) -o $@
 
 # Sanitizer build (CPU only: GPU AddressSanitizer is not available on this pool).  --offload-host-only compiles the
 # host side of every .hip unit - the C ABI, argument checks, launch-geometry arithmetic - and drops the device code.

@@ -336,8 +336,12 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       variant = DMA_RQL;
     else
       variant = DMA_SQL_0 + c.critic_struct;
-    const bool ok = variant >= DMA_SQL_0 ? launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P)
-                                         : launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, A, P);
+    bool ok = false;
+    if (variant < DMA_SQL_0) {
+      ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, A, P);
+    } else {
+      if constexpr (is_f32) ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P);  // no f64 group 1
+    }
     if (!ok) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d reals", who, R);
     HIPCHK(h, hipGetLastError());
     return RCG_OK;
