@@ -502,7 +502,7 @@ def control_tick(cfg: OracleCfg, env: EnvBatch, cand, force_idx=None):
 # Build-defined actor optimiser (replacement of the SLSQP call in
 # CtrlOptPred._actor_optimizer, controllers.py:1330-1427): adjoint gradient + projected line search
 # ----------------------------------------------------------------------------------------------
-OPT_NALPHA = 64  # step lengths tried per iteration = lanes of the wave that owns the env
+OPT_NALPHA = 16  # step lengths tried per env and iteration = one row of 16 lanes (four envs share a wave per pass)
 
 
 def state_jac_T(sys_id, x, u, pars, lam):
@@ -558,12 +558,14 @@ def actor_grad(u, obs, state_sys, cfg: OracleCfg, pars=None):
 
 
 def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None):
-    """Projected, box-scaled steepest descent with a 64-way line search.
+    """Projected, box-scaled steepest descent with a 16-way line search.
 
     Per iteration: g = grad J(u); d = g * (hi - lo)^2 (the box-width metric makes the inputs commensurable);
-    the 64 candidates ``clip(u - alpha_l d)`` with ``alpha_l = 2^(2 - l/2) / max|d / (hi - lo)|``, l = 0..63 (from four
-    box widths down by sqrt(2) per lane) are evaluated with ``_actor_cost``; the best one (lower J, then lower l)
-    replaces u if it improves J, otherwise the search stops.  Returns ``(u [N, du], J, iterations used)``."""
+    the 16 candidates ``clip(u - alpha_l d)`` with ``alpha_l = 4^(1 - l) / max|d / (hi - lo)|``, l = 0..15 (from four
+    box widths down by a factor 4 per lane, to 2^-28) are evaluated with ``_actor_cost``; the best one (lower J, then
+    lower l) replaces u if it improves J, otherwise the search stops.  Returns ``(u [N, du], J, iterations used)``.
+    (Round 1 searched 64 step lengths of ratio sqrt 2 over the same range: on the F8 states both ladders reach the same
+    cost to five digits, tools/ladder_experiment.py, and the coarse one needs a quarter of the trial rollouts.)"""
     lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
     w = hi - lo
     u = np.array(u_init, dtype=np.float64).reshape(cfg.n_actor, cfg.du)
@@ -575,7 +577,7 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
         gn = float(np.max(np.abs(d) / w))
         if not (gn > 0.0) or not np.isfinite(gn):
             break
-        alphas = (1.0 / gn) * np.exp2(2.0 - 0.5 * np.arange(OPT_NALPHA))
+        alphas = (1.0 / gn) * np.exp2(2.0 - 2.0 * np.arange(OPT_NALPHA))
         cand = np.minimum(np.maximum(u[None] - alphas[:, None, None] * d[None], lo), hi)
         Js = actor_cost(cand, obs, state_sys, cfg, pars=pars)
         bj, bi = argmin_first(Js[None])

@@ -12,7 +12,7 @@ What differs from the reference, by construction (SURVEY.md hard part 1):
 * ``_actor_optimizer``: the reference calls SciPy SLSQP (finite-difference gradients, one env).  Here, for
   MPC with a diagonal quadratic stage cost (every preset), the decision is the on-device optimiser
   ``rcg_actor_optimize`` (``actor_opt='auto'|'gradient'``): ``opt_iters`` iterations of adjoint gradient +
-  64-way projected line search from the reference's start sequence; on the reference's own test states it
+  16-way projected line search from the reference's start sequence; on the reference's own test states it
   reaches SLSQP's cost within 0.2 %.  Otherwise (RQL/SQL, non-diagonal costs, ``actor_opt='sampling'``) the
   actor is a candidate search evaluated on the GPU: ``K`` action sequences per env go through ``_actor_cost``
   in one launch and the argmin wins (ties -> lower index); candidates are either given explicitly

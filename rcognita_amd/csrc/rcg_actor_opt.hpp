@@ -5,13 +5,17 @@
 //   1. lane e < 16 = env e: gradient of _actor_cost w.r.t. the whole action sequence u [N][du] by a forward Euler
 //      rollout (states to LDS) and a reverse (adjoint) sweep; direction d = g * (hi - lo)^2 (box-width metric) to LDS,
 //      gn = max |d / (hi - lo)| stays in the lane;
-//   2. for each env e in turn, all 64 lanes: 64 step lengths alpha_l = 2^(2 - l/2) / gn, ONE PER LANE; lane l
-//      evaluates _actor_cost of clip(u_e - alpha_l d_e) - the same rollout as k_actor, u and d from LDS (broadcast
-//      reads); wave argmin over (J, l) (lower J, then lower l; NaN = +inf); if it improves the incumbent, lanes
-//      i < N*du update u_e[i] in LDS, otherwise env e stops.
-// The first version of this kernel gave every env a whole wave and computed the gradient redundantly on all 64 lanes:
-// 55 % of its instruction stream.  Sharing a wave between 16 envs cuts the instructions per env and iteration from
-// ~2100 to ~800 with the same per-env arithmetic in the same order (results are bit-identical).
+//   2. four envs at a time, one per row of 16 lanes: OPT_NA = 16 step lengths alpha_l = 4^(1 - l) / gn, ONE PER LANE of
+//      the row; the lane evaluates _actor_cost of clip(u_e - alpha_l d_e) - the same rollout as k_actor, u and d from
+//      LDS (broadcast reads within the row); row argmin over (J, l) (lower J, then lower l; NaN = +inf; f32: four DPP
+//      stages, a DPP row IS 16 lanes); if it improves the incumbent, the row's lanes update u_e in LDS, otherwise env e
+//      stops.
+// History (profiles/r02_*_valu_pmc.json has the SQ counters): v1 gave every env a whole wave and computed the gradient
+// redundantly on all 64 lanes (55 % of its instruction stream); v2 shared a wave between 16 envs and searched 64 step
+// lengths (ratio sqrt 2) per env with the whole wave - 56 k VALU instructions per wave for 5 iterations, 90 % of them the
+// line search (16 passes of a full rollout per iteration), issue slots 93 % busy: VALU-bound on trial rollouts.  On the
+// reference's own F8 states a 16-step ladder of ratio 4 over the same range (4 .. 2^-28 box widths) reaches the same
+// cost to five digits (tools/ladder_experiment.py), so v3 runs four envs per pass: 4 x fewer trial rollouts.
 // No HBM traffic inside the loop.  Mirrors oracle/rcg_oracle.py::actor_optimize_single statement by statement; on the
 // reference's own test states it reaches SLSQP's cost within 0.2 % after 10 iterations
 // (tests/test_oracle_optimizer.py, tests/test_hip_optimizer.py).
@@ -20,7 +24,39 @@
 
 namespace rcg {
 
-constexpr int OPT_G = 16;  // envs per wave
+constexpr int OPT_G = 16;   // envs per wave
+constexpr int OPT_NA = 16;  // step lengths tried per env and iteration = lanes of one DPP row
+constexpr int OPT_EP = 64 / OPT_NA;  // envs per line-search pass
+
+// argmin over a row of 16 lanes of (cost, index): lower cost wins, ties -> lower index; every lane of the row ends with
+// the row's winner
+__device__ __forceinline__ void row16_argmin(float& bj, int& bi) {
+  unsigned long long k = ((unsigned long long)float_order_key(bj) << 32) | (unsigned)bi;
+#define RCG_DPP_MIN(CTRL)                                                                                          \
+  {                                                                                                                \
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, 0xF, 0xF, false);         \
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, 0xF, 0xF, false); \
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                              \
+    k = o < k ? o : k;                                                                                             \
+  }
+  RCG_DPP_MIN(0xB1)   // quad_perm [1,0,3,2]
+  RCG_DPP_MIN(0x4E)   // quad_perm [2,3,0,1]
+  RCG_DPP_MIN(0x141)  // row_half_mirror
+  RCG_DPP_MIN(0x140)  // row_mirror
+#undef RCG_DPP_MIN
+  bj = float_from_order_key((unsigned)(k >> 32));
+  bi = (int)(unsigned)k;
+}
+__device__ __forceinline__ void row16_argmin(double& bj, int& bi) {
+  for (int m = 1; m < 16; m <<= 1) {
+    const double oJ = __shfl_xor(bj, m, 64);
+    const int oI = __shfl_xor(bi, m, 64);
+    if ((oJ < bj) || (oJ == bj && oI < bi)) {
+      bj = oJ;
+      bi = oI;
+    }
+  }
+}
 
 template <typename real>
 struct OptArgs {
@@ -120,6 +156,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
   }
   wave_lds_sync();
 
+  const bool g1 = P.gamma == (real)1;
   // _actor_cost of clip(u_e - alpha d_e) from the state (y0, xs, pre): controllers.py:1284-1306
   auto cost_of = [&](const real* ue, const real* de, const real* y0, const real* xs,
                      const typename Sys::template Pre<real>& pre, real alpha) -> real {
@@ -132,6 +169,9 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
 #pragma unroll
     for (int c = 0; c < DU; ++c) up[c] = 0;
     real J = 0;
+    real S[NCHI];  // gamma == 1: per-component sums of squares, weighted once at the end (as the rollout kernels)
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) S[i] = 0;
     for (int k = 0; k < N; ++k) {
       real u[DU];
 #pragma unroll
@@ -149,9 +189,18 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
       }
       real chi[NCHI];
       make_chi<DS, DU, TGT, real>(P, y, u, chi);
-      J = fma_r(sg[k], stage_diag<NCHI, real>(P, chi), J);
+      if (g1) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
+      } else {
+        J = fma_r(sg[k], stage_diag<NCHI, real>(P, chi), J);
+      }
 #pragma unroll
       for (int c = 0; c < DU; ++c) up[c] = u[c];
+    }
+    if (g1) {
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[i], J);
     }
     return J;
   };
@@ -161,7 +210,8 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
   int used = 0;
   bool active = mine;
   real gn = 0;
-  const real ladder = (real)exp2((double)2 - 0.5 * (double)lane);  // alpha_l * gn
+  const int row = lane >> 4, tl = lane & (OPT_NA - 1);                    // row of 16 lanes = one env of the pass, trial
+  const real ladder = (real)exp2((double)2 - 2.0 * (double)tl);          // alpha_l * gn = 4^(1 - l)
 
   for (int it = 0; it < A.iters; ++it) {
     if (__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(__ballot(active))) == 0) break;
@@ -227,49 +277,57 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
     }
     wave_lds_sync();
 
-    // ---- 2. env by env, all 64 lanes: 64-way line search, accept or stop --------------------------------
-    for (int e = 0; e < ng; ++e) {
+    // ---- 2. four envs per pass, one per row of 16 lanes: 16-way line search, accept or stop ----------------
+    for (int e0 = 0; e0 < ng; e0 += OPT_EP) {
       const unsigned long long am = __ballot(active);
-      if (!((am >> e) & 1ull)) continue;  // wave-uniform
-      const real gn_e = __shfl(gn, e, 64);
-      const real Jinc_e = __shfl(Jinc, e, 64);
+      if (!((am >> e0) & ((1ull << OPT_EP) - 1))) continue;  // wave-uniform: none of the four is still running
+      const int e = e0 + row;                                 // this row's env (row-uniform)
+      const bool on = e < ng && ((am >> e) & 1ull);
+      const int es = on ? e : e0;                             // idle rows read a valid slot, their result is dropped
+      const real gn_e = __shfl(gn, es, 64);
+      const real Jinc_e = __shfl(Jinc, es, 64);
       real y0[DS], xs[DS], pv[NPS];
 #pragma unroll
       for (int c = 0; c < DS; ++c) {
-        y0[c] = sY[c * G + e];
-        xs[c] = sS[c * G + e];
+        y0[c] = sY[c * G + es];
+        xs[c] = sS[c * G + es];
       }
 #pragma unroll
-      for (int i = 0; i < NP; ++i) pv[i] = sP[i * G + e];
+      for (int i = 0; i < NP; ++i) pv[i] = sP[i * G + es];
       const auto pre = Sys::template prepare<real>(pv);
-      real* const ue = su + e * R;
-      const real* const de = sd + e * R;
+      real* const ue = su + es * R;
+      const real* const de = sd + es * R;
       const real alpha = ((real)1 / gn_e) * ladder;
-      const real J = cost_of(ue, de, y0, xs, pre, alpha);
-      real bj = (J != J) ? inf_r<real>() : J;
-      int bi = lane;
-      for (int m = 1; m < 64; m <<= 1) {
-        const real oJ = __shfl_xor(bj, m, 64);
-        const int oI = __shfl_xor(bi, m, 64);
-        if ((oJ < bj) || (oJ == bj && oI < bi)) {
-          bj = oJ;
-          bi = oI;
+      real bj = inf_r<real>();
+      if (on) {
+        const real J = cost_of(ue, de, y0, xs, pre, alpha);
+        bj = (J != J) ? inf_r<real>() : J;
+      }
+      int bi = tl;
+      row16_argmin(bj, bi);
+      const bool better = on && (bj < Jinc_e);  // row-uniform
+      // accept: u_e <- clip(u_e - alpha_best d_e); otherwise env e is done
+      const real abest = ((real)1 / gn_e) * (real)exp2((double)2 - 2.0 * (double)bi);
+      wave_lds_sync();  // every lane has finished reading its u_e
+      if (better) {
+        for (int i = tl; i < R; i += OPT_NA) {
+          const int c = i % DU;
+          ue[i] = clamp_r<real>(fma_r(-abest, de[i], ue[i]), P.lo[c], P.hi[c]);
         }
       }
-      if (!(bj < Jinc_e)) {  // wave-uniform: no improvement, env e is done
-        if (lane == e) active = false;
-        continue;
-      }
-      // accept: u_e <- clip(u_e - alpha_best d_e)
-      const real abest = ((real)1 / gn_e) * (real)exp2((double)2 - 0.5 * (double)bi);
-      wave_lds_sync();  // every lane has finished reading u_e
-      if (lane < R) {
-        const int c = lane % DU;
-        ue[lane] = clamp_r<real>(fma_r(-abest, de[lane], ue[lane]), P.lo[c], P.hi[c]);
-      }
-      if (lane == e) {
-        Jinc = bj;
-        ++used;
+      // hand the rows' results to the env-view lanes (env e0 + r lives in lane e0 + r; its row is lanes 16 r ...)
+      const int r_of_me = lane - e0;  // which row carries the env this lane stands for
+      const bool mine_now = r_of_me >= 0 && r_of_me < OPT_EP;
+      const int src = mine_now ? r_of_me * OPT_NA : 0;
+      const real bj_me = __shfl(bj, src, 64);
+      const int better_me = __shfl((int)better, src, 64);
+      if (mine_now && active) {
+        if (better_me) {
+          Jinc = bj_me;
+          ++used;
+        } else {
+          active = false;
+        }
       }
     }
     wave_lds_sync();

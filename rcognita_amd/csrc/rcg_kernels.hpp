@@ -264,7 +264,11 @@ __device__ __forceinline__ void gen_candidate(const KParams<real>& P, int g, int
 // (STREAM, step-major in LDS) or the constant sequence `ugen`.  MODE_C / SK_C / CS_C are compile-time values of mode /
 // stage_kind / critic_struct, -1 = read the runtime value: the caller dispatches once per tile, so the step loop
 // carries no mode / stage-structure / critic-structure branches (they cost more than the ~14 VALU ops of a 2tank step).
-template <typename Sys, typename real, bool TGT, bool STREAM, int MODE_C, int SK_C, int CS_C, typename WGet>
+// G1 (MPC, diagonal quadratic stage cost, gamma == 1 - every preset): the sum of weighted squares is accumulated per
+// component, S_i += chi_i^2, and weighted once at the end, J = sum_i R1_ii S_i - 7 fma per 3wrobot step instead of 14
+// ops + the discount bookkeeping, in a rollout of ~33 (the generated-candidate regime is VALU-issue-bound,
+// profiles/r02_*_valu_pmc.json; k_actor_dma has had the same variant since round 1).
+template <typename Sys, typename real, bool TGT, bool STREAM, int MODE_C, int SK_C, int CS_C, bool G1 = false, typename WGet>
 __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
                                              const real* xs, const real* y0, const real* urow, const real* ugen,
                                              WGet wget, real* u0) {
@@ -279,8 +283,12 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     x[c] = xs[c];
     y[c] = y0[c];
   }
+  static_assert(!G1 || (MODE_C == RCG_MODE_MPC && SK_C == 0), "the per-component sum is an MPC / diagonal-R1 variant");
   real J = 0, gk = 1;
   real u[DU], up[DU];
+  real S[G1 ? NCHI : 1];
+#pragma unroll
+  for (int i = 0; i < (G1 ? NCHI : 1); ++i) S[i] = 0;
 #pragma unroll
   for (int c = 0; c < DU; ++c) up[c] = 0;
   for (int kk = 0; kk < N; ++kk) {
@@ -302,7 +310,10 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     }
     real chi[NCHI];
     make_chi<DS, DU, TGT, real>(P, y, u, chi);
-    if (mode == RCG_MODE_MPC) {
+    if (G1) {
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) S[G1 ? i : 0] = fma_r(chi[i], chi[i], S[G1 ? i : 0]);
+    } else if (mode == RCG_MODE_MPC) {
       J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
     } else if (mode == RCG_MODE_RQL) {
       if (kk < N - 1)
@@ -312,9 +323,13 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     } else {  // SQL
       J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
     }
-    gk *= P.gamma;
+    if (!G1) gk *= P.gamma;
 #pragma unroll
     for (int c = 0; c < DU; ++c) up[c] = u[c];
+  }
+  if (G1) {
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[G1 ? i : 0], J);
   }
   return J;
 }
@@ -325,7 +340,11 @@ __device__ __forceinline__ real rollout_dispatch(const KParams<real>& P, const t
                                                  int N, const real* xs, const real* y0, const real* urow,
                                                  const real* ugen, WGet wget, real* u0) {
 #define RCG_ROLL(M, S, C) rollout_cost<Sys, real, TGT, STREAM, M, S, C>(P, pre, N, xs, y0, urow, ugen, wget, u0)
-  if (!GENERIC) return RCG_ROLL(RCG_MODE_MPC, 0, -1);  // MPC, quadratic, diagonal R1
+  if (!GENERIC) {  // MPC, quadratic, diagonal R1
+    if (P.gamma == (real)1)  // wave-uniform
+      return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, true>(P, pre, N, xs, y0, urow, ugen, wget, u0);
+    return RCG_ROLL(RCG_MODE_MPC, 0, -1);
+  }
   if (P.mode == RCG_MODE_MPC) return RCG_ROLL(RCG_MODE_MPC, -1, -1);
   if (P.mode == RCG_MODE_RQL && P.stage_kind == 0) {
     switch (P.critic_struct) {

@@ -463,7 +463,7 @@ class Engine:
         N.check(N.lib().rcg_control_ticks(self._h, int(T), int(K)), self._h)
 
     def actor_optimize(self, iters=10, obs=None, state_sys=None, u_init=None):
-        """On-device actor optimiser (rcg_actor_optimize): adjoint gradient + 64-way projected line search.
+        """On-device actor optimiser (rcg_actor_optimize): adjoint gradient + 16-way projected line search.
         ``u_init [B, N, du]`` (None: the reference's ``action_sqn_init``).  Returns
         ``(action [B, du], u_opt [B, N, du], best_J [B], n_iter [B] int32)``."""
         keep = []

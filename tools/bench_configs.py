@@ -96,7 +96,7 @@ def main():
         out[f"C2_3wrobot_B{B2}_N10_optimizer_iters{iters}"] = {
             "env_control_steps_per_s": B2 * a.steps / dt, "ms_per_tick": dt / a.steps * 1e3,
             "mean_iterations_used": float(used.mean()),
-            "note": "adjoint gradient + 64-way line search per iteration (about 65 _actor_cost evaluations each)"}
+            "note": "adjoint gradient + 16-way line search per iteration (17 _actor_cost-sized rollouts each)"}
         eng.close()
 
     # ---- the operator boundary itself (unit U1 of SURVEY 8d): rcg_actor_cost, J for every candidate ------

@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--key", help="bench.py workload key for pmc_traffic.json (k_actor entry)")
+    ap.add_argument("--valu", help="rocprofv3 --pmc SQ_* pass of tools/valu_probe.py (directory)")
+    ap.add_argument("--valu-units", help="the JSON line tools/valu_probe.py printed in that pass (file)")
     ap.add_argument("--kernel", default="rcg::k_actor")
     ap.add_argument("--tag", default="")
     a = ap.parse_args()
@@ -106,6 +108,63 @@ def main():
                             "read_bytes": hit[0].get("read_bytes_per_launch"), "write_bytes": hit[0].get("write_bytes_per_launch")}
                 json.dump(t, open(tf, "w"), indent=1, sort_keys=True)
                 print("updated", tf, a.key, t[a.key])
+
+
+    if a.valu:
+        valu_summary(a)
+
+
+VALU_PEAK_SURVEY = 7.9e13  # lane-instr/s, SURVEY.md 8d (157.3 TFLOP/s FMA / 2: counts packed issue)
+N_SIMD, CLK = 256 * 4, 2.4e9
+SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+               "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_SALU")
+
+
+def valu_summary(a):
+    """profiles/<round>_valu_pmc.json: per kernel, per launch - wave-level VALU instructions (SQ_INSTS_VALU), waves,
+    duration inside the counter pass; derived: lane-instructions/s = SQ_INSTS_VALU x 64 / duration against the SURVEY's
+    7.9e13 peak, and the issue-slot occupancy (4 cycles per wave64 instruction, 8 for v_sin/v_cos/v_rcp...) of the
+    1024 SIMDs at 2.4 GHz.  profiles/valu_instr.json: VALU instructions per _actor_cost evaluation for bench.py."""
+    per = {}
+    for c in SQ_COUNTERS:
+        for k, e in counters(a.valu, c).items():
+            if not k.startswith("rcg::"):
+                continue
+            d = per.setdefault(k, {"launches": e["n"], "avg_ns_pmc_pass": e["dur_ns"] / e["n"], "vgpr": e["vgpr"],
+                                   "grid": e["grid"], "wg": e["wg"]})
+            d[c + "_per_launch"] = e["sum"] / e["n"]
+    for k, d in per.items():
+        iv, it = d.get("SQ_INSTS_VALU_per_launch"), d.get("SQ_INSTS_VALU_TRANS_F32_per_launch", 0.0)
+        if not iv:
+            continue
+        sec = d["avg_ns_pmc_pass"] * 1e-9
+        d["lane_instr_per_s"] = iv * 64 / sec
+        d["frac_of_7.9e13_lane_instr_per_s"] = iv * 64 / sec / VALU_PEAK_SURVEY
+        d["issue_slot_occupancy"] = (iv * 4 + it * 4) / (N_SIMD * CLK * sec)  # transcendental: 8 cycles = 4 extra
+        d["valu_instr_per_wave"] = iv / d["SQ_WAVES_per_launch"] if d.get("SQ_WAVES_per_launch") else None
+    units = {}
+    if a.valu_units and os.path.exists(a.valu_units):
+        for line in open(a.valu_units):
+            if line.startswith("{"):
+                units = json.loads(line).get("units_per_launch", {})
+    dst = os.path.join(ROOT, "profiles", f"{a.round}_valu_pmc.json")
+    json.dump({"note": "SQ counters are summed over the 8 XCDs; instructions are wave-level (x64 lanes); durations are "
+                       "those of the counter pass (profiled clocks run a few % lower than un-profiled ones)",
+               "kernels": per, "units_per_launch": units}, open(dst, "w"), indent=1, sort_keys=True)
+    print("wrote", dst)
+    # instructions per evaluation for the generated-grid rollout of the bench workload (k_actor, Sys3WRobot, f32, GENERIC=0)
+    vi = os.path.join(ROOT, "profiles", "valu_instr.json")
+    t = json.load(open(vi)) if os.path.exists(vi) else {}
+    hit = [(k, d) for k, d in per.items() if k.startswith("rcg::k_actor<rcg::Sys3WRobot, float, false, false, false>")]
+    u = units.get("k_actor_generated_3wrobot_N10_f32")
+    if hit and u:
+        k, d = hit[0]
+        # the probe launches this instance for the C2 shape AND (N = 15) for the mixed pool: use the per-wave figure of
+        # the C2 grid (one wave = 64 evaluations) only when the launch counts say the kernel ran the C2 shape alone
+        t["k_actor_generated_3wrobot_N10_f32"] = {"valu_instr_per_eval": d["SQ_INSTS_VALU_per_launch"] * 64 / u["evals"],
+                                                  "round": a.round, "kernel": k, "launches": d["launches"]}
+        json.dump(t, open(vi, "w"), indent=1, sort_keys=True)
+        print("updated", vi, t["k_actor_generated_3wrobot_N10_f32"])
 
 
 if __name__ == "__main__":

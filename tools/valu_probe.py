@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""The VALU-bound kernels of the path, a few launches each, for a counter pass:
+
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES \
+              SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU -d gpurun_out/prof_valu -o v --output-format csv \
+              -- python3 tools/valu_probe.py
+
+(the program itself after `--`; tools/prof_summary.py --valu condenses the CSV into profiles/<round>_valu_pmc.json and
+profiles/valu_instr.json, which bench.py reads for `secondary.generated_grid.roofline_valu`).  Prints, per workload,
+the units one launch processes - the denominators of "instructions per evaluation".
+
+Workloads: generated-grid rollout (k_actor, C2 shape and configs[2] shape, MPC / RQL / SQL), the on-device optimiser
+(k_actor_opt), the critic fit (k_critic_fit), the nominal controllers (k_nominal), the persistent multi-tick kernel
+(k_ticks), the per-GPU shard of configs[4].
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def states(rng, name, n):
+    if name == "3wrobot":
+        return np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-np.pi, np.pi, n),
+                         rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], axis=-1)
+    if name == "3wrobotNI":
+        return np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-np.pi, np.pi, n)], axis=-1)
+    return np.stack([rng.uniform(0, 2, n), rng.uniform(-2, 2, n)], axis=-1)
+
+
+def main():
+    from rcognita_amd import Engine
+    from rcognita_amd.pool import MixedPool, preset_engine_config
+
+    rng = np.random.default_rng(1234)
+    n = int(os.environ.get("VALU_PROBE_LAUNCHES", "6"))
+    part = sys.argv[1] if len(sys.argv) > 1 else "main"  # "pool": configs[4] alone (it re-uses kernel instances of "main")
+    units = {}
+    if part == "pool":
+        total = 65536
+        counts = {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
+        pool = MixedPool(counts, Nactor=15, dtype="f32")
+        pool.set_states({s.name: states(rng, s.name, s.hi - s.lo) for s in pool.segments})
+        for _ in range(n):
+            pool.control_tick(256)
+        pool.synchronize()
+        for s in pool.segments:
+            units[f"k_actor_generated_{s.name}_N15_f32_C5"] = {"evals": (s.hi - s.lo) * 256, "envs": s.hi - s.lo}
+        pool.close()
+        print(json.dumps({"launches_each": n, "units_per_launch": units}))
+        return
+
+    def run(key, eng, tick, per_launch):
+        for _ in range(n):
+            tick()
+        eng.synchronize()
+        units[key] = per_launch
+        eng.close()
+
+    B, K = 65536, 256
+    e = Engine(preset_engine_config("3wrobot", B, Nactor=10))
+    e.set_state(states(rng, "3wrobot", B))
+    run("k_actor_generated_3wrobot_N10_f32", e, lambda: e.control_tick(None, K=K), {"evals": B * K, "envs": B})
+
+    B3 = 131072
+    for mode in ("MPC", "RQL", "SQL"):
+        kw = dict(Nactor=20, mode=mode, critic_struct="quadratic", Ncritic=4, buffer_size=10 if mode != "MPC" else 0)
+        e = Engine(preset_engine_config("2tank", B3, **kw))
+        e.set_state(states(rng, "2tank", B3))
+        run(f"k_actor_generated_2tank_N20_{mode}_f32", e, lambda: e.control_tick(None, K=K), {"evals": B3 * K, "envs": B3})
+
+    for iters in (5,):
+        e = Engine(preset_engine_config("3wrobot", B, Nactor=10))
+        e.set_state(states(rng, "3wrobot", B))
+        run(f"k_actor_opt_3wrobot_N10_iters{iters}_f32", e, lambda: e.control_tick_opt(iters=iters),
+            {"evals": B * iters * 17, "envs": B, "iters": iters})
+
+    for name, gain in (("3wrobotNI", 0.5), ("3wrobot", 5.0)):
+        e = Engine(preset_engine_config(name, B, Nactor=5))
+        e.set_state(states(rng, name, B))
+        run(f"k_nominal_{name}_f32", e, lambda: e.control_tick_nominal(gain), {"envs": B})
+
+    Bs, T = 1024, 64
+    e = Engine(preset_engine_config("3wrobot", Bs, Nactor=10))
+    e.set_state(states(rng, "3wrobot", Bs))
+    run("k_ticks_3wrobot_B1024_K64_T64_f32", e, lambda: e.control_ticks(T, 64), {"evals": Bs * 64 * T, "envs": Bs, "ticks": T})
+
+    print(json.dumps({"launches_each": n, "units_per_launch": units}))
+
+
+if __name__ == "__main__":
+    main()
