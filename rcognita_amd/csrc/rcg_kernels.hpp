@@ -386,121 +386,6 @@ __device__ __forceinline__ void segment_argmin(int seg, real& bestJ, int& bestI,
   }
 }
 
-// _actor_cost (MPC, diagonal quadratic stage cost) of GENERATED candidates - constant sequences `ugen` - for the value
-// type V: a scalar, or f32x2 = two candidates per lane on packed instructions (v_pk_fma_f32 ...).  The generated-
-// candidate regime is VALU-issue-bound (profiles/r02_*_valu_pmc.json: issue slots > 100 % busy on the 4-cycle model),
-// and a rollout step is ~24 plain f32 operations of which only the 4 transcendental ones have no packed form, so two
-// candidates per lane cost ~14 issue slots per candidate-step instead of 24.  Operation for operation the sequence of
-// rollout_cost<MPC, 0, -1, G1> with STREAM = false: a candidate's cost is the same bits whichever path evaluates it.
-template <typename Sys, typename real, typename V, bool TGT, bool G1>
-__device__ __forceinline__ V rollout_mpc_gen(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
-                                            const real* xs, const real* y0, const V* ugen) {
-  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
-  const V h = bcast<V>(P.h_pred);
-  V x[DS], y[DS];
-#pragma unroll
-  for (int c = 0; c < DS; ++c) {
-    x[c] = bcast<V>(xs[c]);
-    y[c] = bcast<V>(y0[c]);
-  }
-  V J = bcast<V>((real)0);
-  real gk = 1;
-  V S[G1 ? NCHI : 1];
-#pragma unroll
-  for (int i = 0; i < (G1 ? NCHI : 1); ++i) S[i] = bcast<V>((real)0);
-  for (int kk = 0; kk < N; ++kk) {
-    if (kk > 0) {
-      V d[DS];
-      Sys::template rhs<V, std::is_same<real, float>::value>(pre, x, ugen, d);  // unclipped: sys_rhs([], state, u[k-1])
-#pragma unroll
-      for (int c = 0; c < DS; ++c) {
-        x[c] = fma_r(h, d[c], x[c]);
-        y[c] = x[c];  // sys_out is the identity
-      }
-    }
-    V chi[NCHI];
-#pragma unroll
-    for (int c = 0; c < DS; ++c) chi[c] = TGT ? y[c] - bcast<V>(P.target[c]) : y[c];
-#pragma unroll
-    for (int c = 0; c < DU; ++c) chi[DS + c] = ugen[c];
-    if (G1) {
-#pragma unroll
-      for (int i = 0; i < NCHI; ++i) S[G1 ? i : 0] = fma_r(chi[i], chi[i], S[G1 ? i : 0]);
-    } else {
-      V q = bcast<V>((real)0);
-#pragma unroll
-      for (int i = 0; i < NCHI; ++i) q = fma_r(bcast<V>(P.R1d[i]) * chi[i], chi[i], q);
-      J = fma_r(bcast<V>(gk), q, J);
-      gk *= P.gamma;
-    }
-  }
-  if (G1) {
-#pragma unroll
-    for (int i = 0; i < NCHI; ++i) J = fma_r(bcast<V>(P.R1d[i]), S[G1 ? i : 0], J);
-  }
-  return J;
-}
-
-// The generated-candidate decision of one env segment (k_actor with cand == NULL, and every tick of k_ticks): all tiles
-// of the level grid through _actor_cost, running (bestJ, bestI, bestU) per lane.  f32 / MPC / diagonal R1: tiles go two
-// at a time through the packed rollout (candidates k and k + 64 in the two halves), an odd last tile through the scalar
-// instantiation of the same function.
-struct GenTiling {
-  int K, n_tiles, grid_g;  // candidates, ceil(K / 64) (1 when K < 64), levels per input
-};
-template <typename Sys, typename real, bool GENERIC, bool TGT, typename WGet>
-__device__ __forceinline__ void gen_tiles_argmin(const KParams<real>& P, const typename Sys::template Pre<real>& pre,
-                                                 const GenTiling& T, bool big, int kl, bool env_ok, const real* xs,
-                                                 const real* y0, WGet wget, real& bestJ, int& bestI, real* bestU) {
-  constexpr int DU = Sys::DU;
-  const int N = P.n_actor;
-  auto take = [&](real J, int k, const real* u0) {
-    const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
-    if (env_ok && k < T.K && (Jc < bestJ || bestI == 0x7fffffff)) {
-      bestJ = Jc;
-      bestI = k;
-#pragma unroll
-      for (int c = 0; c < DU; ++c) bestU[c] = u0[c];
-    }
-  };
-  const bool g1 = P.gamma == (real)1;  // wave-uniform
-  int t = 0;
-  if constexpr (!GENERIC && std::is_same<real, float>::value) {
-    for (; t + 1 < T.n_tiles; t += 2) {  // (n_tiles >= 2 implies K > 64: one env per wave, kl == lane)
-      const int k0 = t * 64 + kl, k1 = k0 + 64;
-      real ua[DU], ub[DU];
-#pragma unroll
-      for (int c = 0; c < DU; ++c) ua[c] = ub[c] = 0;
-      gen_candidate<DU, real>(P, T.grid_g, k0, ua);
-      gen_candidate<DU, real>(P, T.grid_g, k1, ub);
-      f32x2 u2[DU];
-#pragma unroll
-      for (int c = 0; c < DU; ++c) u2[c] = (f32x2){ua[c], ub[c]};
-      const f32x2 J2 = g1 ? rollout_mpc_gen<Sys, real, f32x2, TGT, true>(P, pre, N, xs, y0, u2)
-                          : rollout_mpc_gen<Sys, real, f32x2, TGT, false>(P, pre, N, xs, y0, u2);
-      take(J2.x, k0, ua);
-      take(J2.y, k1, ub);
-    }
-  }
-  for (; t < T.n_tiles; ++t) {
-    const int k = big ? t * 64 + kl : kl;
-    real ugen[DU], u0[DU];
-#pragma unroll
-    for (int c = 0; c < DU; ++c) ugen[c] = 0;
-    gen_candidate<DU, real>(P, T.grid_g, k, ugen);
-    real J;
-    if constexpr (!GENERIC) {
-      J = g1 ? rollout_mpc_gen<Sys, real, real, TGT, true>(P, pre, N, xs, y0, ugen)
-             : rollout_mpc_gen<Sys, real, real, TGT, false>(P, pre, N, xs, y0, ugen);
-#pragma unroll
-      for (int c = 0; c < DU; ++c) u0[c] = ugen[c];
-    } else {
-      J = rollout_dispatch<Sys, real, GENERIC, TGT, false>(P, pre, N, xs, y0, nullptr, ugen, wget, u0);
-    }
-    take(J, k, u0);
-  }
-}
-
 // upd_accum_obj (controllers.py:1086-1093): accum + rho(obs, action) * sampling_time, one rounding
 template <typename Sys, bool TGT, typename real>
 __device__ __forceinline__ real accum_update(const KParams<real>& P, const real* obs, const real* act, real accum) {
@@ -561,13 +446,14 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
 
   const int envs_here = big ? 1 : (int)((B - wave * A.G) < A.G ? (B - wave * A.G) : A.G);
 
-  if constexpr (!STREAM) {  // generated level grid (no per-candidate J output: rcg_actor_cost needs a tensor)
-    const GenTiling T{K, A.n_tiles, A.grid_g};
-    gen_tiles_argmin<Sys, real, GENERIC, TGT>(P, pre, T, big, kl, env_ok, xs, y0, wget, bestJ, bestI, bestU);
-  } else {
-    for (int t = 0; t < A.n_tiles; ++t) {
-      const int k = big ? t * 64 + kl : kl;
-      const bool valid = env_ok && k < K;
+  for (int t = 0; t < A.n_tiles; ++t) {
+    const int k = big ? t * 64 + kl : kl;
+    const bool valid = env_ok && k < K;
+    int r = 0;  // my row inside the tile
+    real ugen[DU];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) ugen[c] = 0;
+    if (STREAM) {
       const long row0 = big ? b * K + (long)t * 64 : wave * A.G * (long)K;
       const int nrows = big ? (K - t * 64 < 64 ? K - t * 64 : 64) : envs_here * K;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous tile's LDS reads are done
@@ -575,19 +461,21 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
       // LDS ops of one wave are executed in order; wait for our own writes, no workgroup barrier
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      const int r = valid ? (big ? kl : e * K + kl) : 0;  // my row inside the tile
-      const real* const urow = lds + (size_t)r * R;
-      real u0[DU];
-      const real J = rollout_dispatch<Sys, real, GENERIC, TGT, true>(P, pre, N, xs, y0, urow, nullptr, wget, u0);
+      r = valid ? (big ? kl : e * K + kl) : 0;
+    } else {
+      gen_candidate<DU, real>(P, A.grid_g, k, ugen);
+    }
+    const real* const urow = lds + (size_t)r * R;
+    real u0[DU];
+    const real J = rollout_dispatch<Sys, real, GENERIC, TGT, STREAM>(P, pre, N, xs, y0, urow, ugen, wget, u0);
 
-      if (A.J && valid) A.J[b * K + k] = J;
-      const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
-      if (valid && (Jc < bestJ || bestI == 0x7fffffff)) {
-        bestJ = Jc;
-        bestI = k;
+    if (A.J && valid) A.J[b * K + k] = J;
+    const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
+    if (valid && (Jc < bestJ || bestI == 0x7fffffff)) {
+      bestJ = Jc;
+      bestI = k;
 #pragma unroll
-        for (int c = 0; c < DU; ++c) bestU[c] = u0[c];
-      }
+      for (int c = 0; c < DU; ++c) bestU[c] = u0[c];
     }
   }
 
@@ -722,7 +610,7 @@ __global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KP
   const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
   const long B = P.B;
-  const int K = A.K;
+  const int K = A.K, N = P.n_actor;
   if (wave * A.G >= B) return;  // wave-uniform: every wave that stays runs all T ticks and exits
 
   const bool big = K >= 64;
@@ -757,8 +645,22 @@ __global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KP
     real bestU[DU];
 #pragma unroll
     for (int c = 0; c < DU; ++c) bestU[c] = 0;
-    const GenTiling T{K, A.n_tiles, A.grid_g};  // k_actor, generated candidates
-    gen_tiles_argmin<Sys, real, GENERIC, TGT>(P, pre, T, big, kl, env_ok, xs, x, wget, bestJ, bestI, bestU);
+    for (int tl = 0; tl < A.n_tiles; ++tl) {  // k_actor, generated candidates
+      const int k = big ? tl * 64 + kl : kl;
+      const bool valid = env_ok && k < K;
+      real ugen[DU], u0[DU];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) ugen[c] = 0;
+      gen_candidate<DU, real>(P, A.grid_g, k, ugen);
+      const real J = rollout_dispatch<Sys, real, GENERIC, TGT, false>(P, pre, N, xs, x, nullptr, ugen, wget, u0);
+      const real Jc = (J != J) ? inf_r<real>() : J;
+      if (valid && (Jc < bestJ || bestI == 0x7fffffff)) {
+        bestJ = Jc;
+        bestI = k;
+#pragma unroll
+        for (int c = 0; c < DU; ++c) bestU[c] = u0[c];
+      }
+    }
     segment_argmin<DU, real>(seg, bestJ, bestI, bestU);
 #pragma unroll
     for (int c = 0; c < DU; ++c) u[c] = bestU[c];  // receive_action: held until the next tick

@@ -101,33 +101,6 @@ __device__ __forceinline__ void sincos_sel<float, true>(float x, float* s, float
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// Two f32 values per lane: the VALU-bound rollouts (generated candidates) evaluate two candidates per lane with packed
-// instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and issue slot).  Each half goes
-// through exactly the scalar operation sequence, so a candidate's cost does not depend on which path evaluated it.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 fma_r(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
-// a scalar parameter as the value type V of a rollout (V itself, or both halves of an f32x2)
-template <typename V, typename S>
-__device__ __forceinline__ V bcast(S v) {
-  return (V)v;
-}
-template <>
-__device__ __forceinline__ f32x2 bcast<f32x2, float>(float v) {
-  return splat2(v);
-}
-// sincos_hw on both halves: the reduction packed, the four transcendental instructions scalar (no packed form)
-template <>
-__device__ __forceinline__ void sincos_sel<f32x2, true>(f32x2 x, f32x2* s, f32x2* c) {
-  const f32x2 q = x * splat2(0.15915494309189533577f);
-  const f32x2 kf = (f32x2){__builtin_rintf(q.x), __builtin_rintf(q.y)};
-  f32x2 r = fma_r(kf, splat2(-6.28318548202514648438f), x);
-  r = fma_r(kf, splat2(1.74845553146951715e-7f), r);
-  const f32x2 t = r * splat2(0.15915494309189533577f);
-  *s = (f32x2){__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
-  *c = (f32x2){__builtin_amdgcn_cosf(t.x), __builtin_amdgcn_cosf(t.y)};
-}
-
 template <typename real>
 __device__ __forceinline__ real clamp_r(real v, real lo, real hi) {
   // np.clip semantics (systems.py:243): min(max(v, lo), hi); NaN propagates

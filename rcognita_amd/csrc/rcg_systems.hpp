@@ -23,10 +23,8 @@ struct Sys3WRobot {
   __device__ __forceinline__ static Pre<real> prepare(const real* p) {
     return {(real)1 / p[0], (real)1 / p[1]};
   }
-  // `real` is the value type of x / u / d: a scalar, or f32x2 (two rollouts per lane, rcg_math.hpp); the per-env
-  // parameters `q` stay scalar
-  template <typename real, bool HW = false, typename PreT>
-  __device__ __forceinline__ static void rhs(const PreT& q, const real* x, const real* u, real* d) {
+  template <typename real, bool HW = false>
+  __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
     real s, c;
     sincos_sel<real, HW>(x[2], &s, &c);
     d[0] = x[3] * c;
@@ -61,8 +59,8 @@ struct Sys3WRobotNI {
   __device__ __forceinline__ static Pre<real> prepare(const real*) {
     return {};
   }
-  template <typename real, bool HW = false, typename PreT>
-  __device__ __forceinline__ static void rhs(const PreT&, const real* x, const real* u, real* d) {
+  template <typename real, bool HW = false>
+  __device__ __forceinline__ static void rhs(const Pre<real>&, const real* x, const real* u, real* d) {
     real s, c;
     sincos_sel<real, HW>(x[2], &s, &c);
     d[0] = u[0] * c;
@@ -94,12 +92,10 @@ struct Sys2Tank {
   __device__ __forceinline__ static Pre<real> prepare(const real* p) {
     return {(real)1 / p[0], (real)1 / p[1], p[2], p[3], p[4]};
   }
-  template <typename real, bool HW = false, typename PreT>
-  __device__ __forceinline__ static void rhs(const PreT& q, const real* x, const real* u, real* d) {
-    // 1/tau1 (-h1 + K1 u), 1/tau2 (-h2 + K2 h1 + K3 h2^2) (systems.py:416-417) with the multiply-adds written out,
-    // so that the scalar and the packed instantiation round identically
-    d[0] = q.inv_tau1 * fma_r(bcast<real>(q.K1), u[0], -x[0]);
-    d[1] = q.inv_tau2 * fma_r(bcast<real>(q.K3), x[1] * x[1], fma_r(bcast<real>(q.K2), x[0], -x[1]));
+  template <typename real, bool HW = false>
+  __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
+    d[0] = q.inv_tau1 * (-x[0] + q.K1 * u[0]);
+    d[1] = q.inv_tau2 * (-x[1] + q.K2 * x[0] + q.K3 * (x[1] * x[1]));
   }
   template <typename real>
   __device__ __forceinline__ static void jac_T(const Pre<real>& q, const real* x, const real*, const real* lam,
