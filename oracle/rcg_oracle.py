@@ -658,7 +658,7 @@ def _chol_solve(H, rhs, floor=0.0):
     return x
 
 
-def critic_fit_single(A, b, w0, lo, hi, stats=None):
+def critic_fit_single(A, b, w0, lo, hi, stats=None, w_start=None):
     """Bounded least squares of the TD stack for ONE env.
 
     The reference minimises ``Jc(w) = 1/2 |A w - b|^2`` over the box ``[Wmin, Wmax]`` with SLSQP started
@@ -680,6 +680,11 @@ def critic_fit_single(A, b, w0, lo, hi, stats=None):
     iterate moves.  Safeguard: ``w_init`` is returned if the result does not have ``Jc <= Jc(w_init)``
     (non-finite buffers).  The HIP kernel k_critic_fit mirrors this statement by statement, in float64
     whatever the handle's dtype.  ``stats`` (a list) receives the number of iterations used.
+
+    ``w_start`` (default ``w_init``): the feasible point the active-set walk starts from.  The minimiser is unique (the
+    problem is strictly convex), so the start only decides how many iterations the walk takes: the kernel starts from
+    the previous fit's weights, whose active set is usually already the optimal one (1-2 iterations instead of one per
+    bound the cold walk has to find).
     """
     A = np.asarray(A, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -695,7 +700,7 @@ def critic_fit_single(A, b, w0, lo, hi, stats=None):
     if not mu > 1e-30:
         mu = 1e-30
 
-    w = np.minimum(np.maximum(w0, lo), hi)
+    w = np.minimum(np.maximum(w0 if w_start is None else np.asarray(w_start, dtype=np.float64), lo), hi)
     free = (w > lo) & (w < hi)
     at_hi = (~free) & (w >= hi)
     blocked = np.zeros(dc, dtype=bool)
@@ -782,13 +787,15 @@ def critic_fit_single(A, b, w0, lo, hi, stats=None):
     return w if primal(w) <= primal(wi) else wi
 
 
-def critic_fit(cfg: OracleCfg, w_prev, obs_buf, act_buf, w_init=None):
-    """Batched wrapper: ``w_prev [B, dc]``, buffers ``[B, buffer_size, d]`` -> fitted ``w [B, dc]``."""
+def critic_fit(cfg: OracleCfg, w_prev, obs_buf, act_buf, w_init=None, w_start=None, stats=None):
+    """Batched wrapper: ``w_prev [B, dc]``, buffers ``[B, buffer_size, d]`` -> fitted ``w [B, dc]``; ``w_start [B, dc]``
+    as in :func:`critic_fit_single`."""
     A, b = critic_td_system(w_prev, obs_buf, act_buf, cfg)
     B = A.shape[0]
     lo, hi = critic_bounds(cfg.critic_struct, cfg.dc)
     w0 = np.ones(cfg.dc) if w_init is None else np.asarray(w_init, dtype=np.float64)
-    return np.stack([critic_fit_single(A[i], b[i], w0, lo, hi) for i in range(B)])
+    return np.stack([critic_fit_single(A[i], b[i], w0, lo, hi, stats=stats,
+                                       w_start=None if w_start is None else np.asarray(w_start)[i]) for i in range(B)])
 
 
 def control_tick_opt(cfg: OracleCfg, env: EnvBatch, iters: int, warm_start: bool = False, action_init=None):
