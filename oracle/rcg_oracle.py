@@ -626,35 +626,41 @@ def fit_max_iters(dc: int) -> int:
 
 
 def _chol_solve(H, rhs, floor=0.0):
-    """Solve the SPD system ``H x = rhs`` by an unpivoted Cholesky factorisation, written out in the
-    same operation order as the HIP kernel (rcg_critic_fit.hpp) so both take the same steps.  Pivots
-    are floored at ``floor`` (only reached when rounding makes a pivot of a near-singular H non-positive)."""
+    """Solve the SPD system ``H x = rhs`` by an unpivoted root-free Cholesky factorisation ``H = L D L^T`` (unit lower
+    ``L``), written out in the same operation order as the HIP kernel (rcg_critic_fit.hpp) so both take the same steps:
+    one reciprocal per pivot, no square root and no other division (the kernel is bound by float64 instruction issue and
+    a divide or square root costs ten to twenty of them; round 1 used L L^T with 3 m of each per solve).  Pivots are
+    floored at ``floor`` (only reached when rounding makes a pivot of a near-singular H non-positive)."""
     m = H.shape[0]
     L = np.array(H, dtype=np.float64)
+    d = np.zeros(m)
+    r = np.zeros(m)
     for j in range(m):
         dj = L[j, j]
         for k in range(j):
-            dj -= L[j, k] * L[j, k]
+            dj -= (L[j, k] * L[j, k]) * d[k]
         if not dj > floor:
             dj = floor
-        dj = np.sqrt(dj)
-        L[j, j] = dj
+        d[j] = dj
+        r[j] = 1.0 / dj
         for i in range(j + 1, m):
             s = L[i, j]
             for k in range(j):
-                s -= L[i, k] * L[j, k]
-            L[i, j] = s / dj
+                s -= (L[i, k] * L[j, k]) * d[k]
+            L[i, j] = s * r[j]
     x = np.zeros(m)
-    for i in range(m):
+    for i in range(m):  # L y = rhs
         s = rhs[i]
         for k in range(i):
             s -= L[i, k] * x[k]
-        x[i] = s / L[i, i]
-    for i in range(m - 1, -1, -1):
+        x[i] = s
+    for i in range(m):  # D z = y
+        x[i] = x[i] * r[i]
+    for i in range(m - 1, -1, -1):  # L^T x = z
         s = x[i]
         for k in range(i + 1, m):
             s -= L[k, i] * x[k]
-        x[i] = s / L[i, i]
+        x[i] = s
     return x
 
 

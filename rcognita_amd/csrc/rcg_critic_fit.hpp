@@ -10,7 +10,7 @@
 //   1/2 |A w - b|^2 + mu/2 |w - w_init|^2   in the box,  mu = 1e-8 * trace(A A^T) / m,
 // computed by a primal active-set method (bounded-variable least squares): each iteration solves the
 // problem on the free variables exactly through the m x m system (A_F A_F^T + mu I) lam = rhs
-// (Cholesky), then either moves towards that point until the first bound is hit and fixes that
+// (root-free Cholesky L D L^T), then either moves towards that point until the first bound is hit and fixes that
 // variable, or accepts it and releases the bound variable with the most wrong-signed multiplier
 // (none: optimal).  Feasible and monotone, so the result is never worse than w_init.  This mirrors
 // oracle/rcg_oracle.py::critic_fit_single statement by statement; all arithmetic is float64 whatever
@@ -66,11 +66,16 @@ __device__ __forceinline__ void critic_phi(const double* chi, const double* y, c
 
 template <typename real>
 struct FitArgs {
-  real* w_critic;         // [dc][B] out
-  real* w_prev;           // [dc][B] in (TD target weights), out (:= fitted w)
+  real* w_critic;         // [dc][B] out (nullptr: prefetch, see w_next)
+  real* w_prev;           // [dc][B] in (TD target weights), out (:= fitted w) unless w_next is given
+  real* w_next;           // [dc][B] or nullptr.  Prefetch mode (rcg_control_tick): the fit of the NEXT tick
+                          // is computed while this tick's actor kernel runs - the TD stack reads the OLDEST rows, which
+                          // after the next push are rows row0 .. row0 + m of the buffers as they are now - and written
+                          // here only; W_CRITIC / W_PREV receive it at the next tick
   const real* obs_buf;    // [buffer_size][dy][B]
   const real* act_buf;    // [buffer_size][du][B]
   const double* wcfg;     // [3][40]: w_init, w_min, w_max
+  int row0;               // first buffer row of the TD stack (0; 1 in prefetch mode)
 };
 
 template <typename Sys, typename real, int CS, int MAXM>
@@ -101,9 +106,9 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
     if (r <= m) {
       double y[DS], u[DU], chi[NCHI], phi[DC];
 #pragma unroll
-      for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)r * DS + c) * B + b];
+      for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)(F.row0 + r) * DS + c) * B + b];
 #pragma unroll
-      for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)r * DU + c) * B + b];
+      for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)(F.row0 + r) * DU + c) * B + b];
       if (P.has_target)
         make_chi<DS, DU, true, double>(P, y, u, chi);
       else
@@ -147,51 +152,65 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
   for (int it = 0; it < fit_max_iters(DC); ++it) {
     // rhs = b - A_B w_B - A_F w0_F,  M = A_F A_F^T + mu I  (rows >= m: M = mu I, rhs = 0 -> lam = 0)
     double L[MAXM][MAXM], lam[MAXM];
+    // A restricted to the free columns (bound columns zero: adding an exact zero leaves the sums' bits unchanged) and
+    // the point the bound part of the right-hand side is taken at, once per iteration instead of a select per term
+    double Af[MAXM][DC], wb[DC];
+#pragma unroll
+    for (int i = 0; i < DC; ++i) {
+      const bool fr = (fm >> i) & 1ull;
+      wb[i] = fr ? w0[i] : w[i];
+#pragma unroll
+      for (int r = 0; r < MAXM; ++r) Af[r][i] = fr ? A[r][i] : 0.0;
+    }
 #pragma unroll
     for (int r = 0; r < MAXM; ++r) {
       double s = bv[r];
 #pragma unroll
-      for (int i = 0; i < DC; ++i) s = fma_r(-A[r][i], ((fm >> i) & 1ull) ? w0[i] : w[i], s);
+      for (int i = 0; i < DC; ++i) s = fma_r(-A[r][i], wb[i], s);
       lam[r] = s;
 #pragma unroll
       for (int q = 0; q <= r; ++q) {
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < DC; ++i)
-          if ((fm >> i) & 1ull) acc = fma_r(A[r][i], A[q][i], acc);
+        for (int i = 0; i < DC; ++i) acc = fma_r(Af[r][i], Af[q][i], acc);
         L[r][q] = acc + (r == q ? mu : 0.0);
       }
     }
+    // root-free Cholesky M = L D L^T (unit lower L): one reciprocal per pivot, no sqrt, no other division - the kernel is
+    // bound by f64 instruction issue and a divide / square root is 10-20 instructions (round 1: L L^T, 3 m of each)
     const double floor_piv = mu * 1e-6;
+    double dg[MAXM], rc[MAXM];
 #pragma unroll
     for (int j = 0; j < MAXM; ++j) {
       double dj = L[j][j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k];
+      for (int k = 0; k < j; ++k) dj -= (L[j][k] * L[j][k]) * dg[k];
       if (!(dj > floor_piv)) dj = floor_piv;
-      dj = sqrt(dj);
-      L[j][j] = dj;
+      dg[j] = dj;
+      rc[j] = 1.0 / dj;
 #pragma unroll
       for (int i = j + 1; i < MAXM; ++i) {
         double s = L[i][j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-        L[i][j] = s / dj;
+        for (int k = 0; k < j; ++k) s -= (L[i][k] * L[j][k]) * dg[k];
+        L[i][j] = s * rc[j];
       }
     }
 #pragma unroll
-    for (int i = 0; i < MAXM; ++i) {  // forward: L x = rhs
+    for (int i = 0; i < MAXM; ++i) {  // forward: L y = rhs
       double s = lam[i];
 #pragma unroll
       for (int k = 0; k < i; ++k) s -= L[i][k] * lam[k];
-      lam[i] = s / L[i][i];
+      lam[i] = s;
     }
 #pragma unroll
-    for (int i = MAXM - 1; i >= 0; --i) {  // backward: L^T lam = x
+    for (int i = 0; i < MAXM; ++i) lam[i] = lam[i] * rc[i];  // D z = y
+#pragma unroll
+    for (int i = MAXM - 1; i >= 0; --i) {  // backward: L^T lam = z
       double s = lam[i];
 #pragma unroll
       for (int k = i + 1; k < MAXM; ++k) s -= L[k][i] * lam[k];
-      lam[i] = s / L[i][i];
+      lam[i] = s;
     }
     // z_F = w0_F + A_F^T lam and the ratio test towards it
     double alpha = 2.0;
@@ -290,8 +309,12 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
   for (int i = 0; i < DC; ++i) {
     const double wi = w0[i] < lo[i] ? lo[i] : (w0[i] > hi[i] ? hi[i] : w0[i]);
     const double v = keep ? w[i] : wi;
-    F.w_critic[(long)i * B + b] = (real)v;
-    F.w_prev[(long)i * B + b] = (real)v;  // w_critic_prev = w_critic (controllers.py:1471)
+    if (F.w_next) {
+      F.w_next[(long)i * B + b] = (real)v;
+    } else {
+      F.w_critic[(long)i * B + b] = (real)v;
+      F.w_prev[(long)i * B + b] = (real)v;  // w_critic_prev = w_critic (controllers.py:1471)
+    }
   }
 }
 
