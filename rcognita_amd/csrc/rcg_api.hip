@@ -124,22 +124,6 @@ __global__ void k_fill(real* p, long n, real v) {
   if (i < n) p[i] = v;
 }
 
-// RCG_NO_FIT_PREFETCH=1 (development knob, read once): the critic fit runs inside its own tick, on the main stream
-static bool dev_knobs_no_fit_prefetch() {
-  static const bool v = getenv("RCG_NO_FIT_PREFETCH") != nullptr;
-  return v;
-}
-
-template <typename real>
-__global__ void k_adopt_w(const real* __restrict__ w_next, real* __restrict__ w_critic, real* __restrict__ w_prev, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const real v = w_next[i];
-    w_critic[i] = v;
-    w_prev[i] = v;  // w_critic_prev = w_critic (controllers.py:1471)
-  }
-}
-
 template <typename real>
 static int fill_rows(rcg_handle* h, void* base, int rows, const double* vals) {
   const long B = h->cfg.batch;
@@ -213,11 +197,6 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->prof_stride = 1;
   memset(h->prof_seen, 0, sizeof h->prof_seen);
   h->tick_count = 0;
-  h->aux_stream = nullptr;
-  h->ev_main = h->ev_aux = nullptr;
-  h->w_next = nullptr;
-  h->prefetch_valid = false;
-  h->prefetch_tick = -1;
   h->sys = cfg->sys_id == RCG_SYS_3WROBOT ? &kVt3WRobot : (cfg->sys_id == RCG_SYS_3WROBOT_NI ? &kVt3WRobotNI : &kVt2Tank);
   memset(h->prof_ms, 0, sizeof h->prof_ms);
   memset(h->prof_n, 0, sizeof h->prof_n);
@@ -331,13 +310,6 @@ int rcg_destroy(rcg_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   for (int i = 0; i < RCG_FIELD_COUNT_; ++i)
     if (h->f[i]) (void)hipFree(h->f[i]);
-  if (h->aux_stream) {
-    (void)hipStreamSynchronize(h->aux_stream);
-    (void)hipStreamDestroy(h->aux_stream);
-  }
-  if (h->ev_main) (void)hipEventDestroy(h->ev_main);
-  if (h->ev_aux) (void)hipEventDestroy(h->ev_aux);
-  if (h->w_next) (void)hipFree(h->w_next);
   if (h->d_summary) (void)hipFree(h->d_summary);
   if (h->d_const) (void)hipFree(h->d_const);
   for (auto& p : h->ev_pending) {
@@ -349,15 +321,6 @@ int rcg_destroy(rcg_handle* h) {
   return RCG_OK;
 }
 
-// The prefetched critic fit (rcg_control_tick) is tied to the buffers, W_PREV and the episode's tick counter as they
-// were when it was issued: anything that changes those from outside the tick drops it (the fit then runs inside its
-// own tick, on the main stream).  Also the point where the auxiliary stream is drained.
-static void drop_prefetch(rcg_handle* h) {
-  if (h->aux_stream && h->prefetch_valid) (void)hipStreamSynchronize(h->aux_stream);
-  h->prefetch_valid = false;
-  h->prefetch_tick = -1;
-}
-
 int rcg_set_stream(rcg_handle* h, void* hip_stream) {
   DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
@@ -366,7 +329,6 @@ int rcg_set_stream(rcg_handle* h, void* hip_stream) {
   // not ordered with respect to each other (torch.cuda.Stream() is non-blocking)
   prof_drain(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  drop_prefetch(h);
   h->stream = (hipStream_t)hip_stream;
   return RCG_OK;
 }
@@ -374,7 +336,6 @@ int rcg_set_stream(rcg_handle* h, void* hip_stream) {
 int rcg_synchronize(rcg_handle* h) {
   DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
-  if (h->aux_stream) HIPCHK(h, hipStreamSynchronize(h->aux_stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return RCG_OK;
 }
@@ -423,8 +384,6 @@ int rcg_set_field(rcg_handle* h, int field, const void* src, int where) {
   int rc = check_field(h, field, "rcg_set_field");
   if (rc) return rc;
   if (!src) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_field: null src");
-  if (field == RCG_FIELD_OBS_BUF || field == RCG_FIELD_ACT_BUF || field == RCG_FIELD_W_PREV || field == RCG_FIELD_W_CRITIC)
-    drop_prefetch(h);
   const hipMemcpyKind kind = where == RCG_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   HIPCHK(h, hipMemcpyAsync(h->f[field], src, h->fbytes[field], kind, h->stream));
   if (field == RCG_FIELD_STATE)  // a freshly set state is also its own "previous" state
@@ -559,63 +518,11 @@ int rcg_critic_update(rcg_handle* h, int32_t do_fit) {
   if (do_fit && m > kFitMaxRows)
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_critic_update: the native critic fit needs Ncritic-1 <= %d (got %d)",
                     kFitMaxRows, m);
-  drop_prefetch(h);  // the buffers move under a prefetched fit
   if (do_fit && m < 1) {  // empty TD stack: push only, the weights stay at the (clipped) initial guess
-    const int rc = h->sys->critic_update(h, 1, 0, 0, nullptr, h->stream);
+    const int rc = h->sys->critic_update(h, 0);
     return rc ? rc : critic_keep_init(h);
   }
-  return h->sys->critic_update(h, 1, do_fit, 0, nullptr, h->stream);
-}
-
-// RQL / SQL part of the tick between the env step and the decision (controllers.py:1458-1477): push, and on a fit tick
-// the refit.  The TD stack reads the OLDEST buffer rows (controllers.py:1231-1234) - rows that do not depend on this
-// tick's env step - so the fit of tick t + 1 is issued on the auxiliary stream right after the bookkeeping of tick t and
-// runs WHILE tick t's actor kernel (and tick t + 1's env step) run on the main stream; tick t + 1 only waits for it and
-// copies the weights over.  The fit is latency-bound (one wave per 64 envs, a serial active-set walk: 40 % of the issue
-// slots) and the actor kernel is bandwidth- or issue-bound, so the two overlap almost for free: configs[2] RQL tick
-// 0.376 -> see DESIGN.md 5.  Same arithmetic on the same rows: bit-identical to the fit inside the tick.
-static int critic_bookkeeping(rcg_handle* h, bool do_fit) {
-  const int m = h->cfg.n_critic - 1;
-  const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
-  const bool can_prefetch = !dev_knobs_no_fit_prefetch() && m >= 1 && m + 1 <= h->cfg.buffer_size - 1;
-  int rc;
-  if (do_fit && h->prefetch_valid && h->prefetch_tick == h->tick_count) {
-    // the buffers are still being read by the prefetched fit: wait for it before the push moves them
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_aux, 0));
-    rc = h->sys->critic_update(h, 1, 0, 0, nullptr, h->stream);
-    if (rc) return rc;
-    const long n = (long)h->dc * h->cfg.batch;
-    ProfScope prof_scope(h, RCG_KERNEL_CRITIC);
-    if (h->cfg.dtype == RCG_F64)
-      hipLaunchKernelGGL((k_adopt_w<double>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const double*)h->w_next,
-                         (double*)h->f[RCG_FIELD_W_CRITIC], (double*)h->f[RCG_FIELD_W_PREV], n);
-    else
-      hipLaunchKernelGGL((k_adopt_w<float>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const float*)h->w_next,
-                         (float*)h->f[RCG_FIELD_W_CRITIC], (float*)h->f[RCG_FIELD_W_PREV], n);
-    HIPCHK(h, hipGetLastError());
-    h->prefetch_valid = false;
-  } else {
-    if (h->prefetch_valid) drop_prefetch(h);  // issued for another tick (e.g. the caller skipped ticks): discard
-    rc = rcg_critic_update(h, do_fit ? 1 : 0);
-    if (rc) return rc;
-  }
-  // issue the next tick's fit if the next tick is a fit tick
-  if (can_prefetch && ((h->tick_count + 2) % every) == 0) {
-    if (!h->aux_stream) {
-      HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-      HIPCHK(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
-      HIPCHK(h, hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming));
-      HIPCHK(h, hipMalloc(&h->w_next, h->fbytes[RCG_FIELD_W_CRITIC]));
-    }
-    HIPCHK(h, hipEventRecord(h->ev_main, h->stream));  // buffers pushed, W_PREV final for this tick
-    HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_main, 0));
-    rc = h->sys->critic_update(h, 0, 1, 1, h->w_next, h->aux_stream);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_aux, h->aux_stream));
-    h->prefetch_valid = true;
-    h->prefetch_tick = h->tick_count + 1;
-  }
-  return RCG_OK;
+  return h->sys->critic_update(h, do_fit);
 }
 
 // Argument checks of the decision step, made BEFORE the tick mutates anything (env step, buffer push): a refused
@@ -648,7 +555,7 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
     // t - critic_clock >= critic_period (controllers.py:1458-1471); tick j of an episode happens at t0 + (j+1)*dt, so
     // the fits fall on ticks every-1, 2*every-1, ...
     const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
-    rc = critic_bookkeeping(h, ((h->tick_count + 1) % every) == 0);
+    rc = rcg_critic_update(h, ((h->tick_count + 1) % every) == 0 ? 1 : 0);
     if (rc) return rc;
     sim_first = false;
   }
@@ -721,7 +628,6 @@ int rcg_episode_reset(rcg_handle* h) {
   // the tick counter belongs to the episode: the first decision of the new episode has no previous optimum to shift
   // (rcg_control_tick_opt warm start) and the critic period restarts with the controller clock
   h->tick_count = 0;
-  drop_prefetch(h);
   if (h->cfg.dtype == RCG_F64)
     hipLaunchKernelGGL((k_episode_reset<double>), dim3(blocks_for(B)), dim3(256), 0, h->stream,
                        (double*)h->f[RCG_FIELD_STATE], (double*)h->f[RCG_FIELD_STATE_PREV],

@@ -17,6 +17,15 @@
 // the handle's dtype (the systems are tiny - m <= 8, dc <= 35 - and badly scaled).  The active set is
 // held in 64-bit lane-private masks and every loop over variables is unrolled with a predicate, so no
 // array is indexed dynamically.
+//
+// Cost (profiles/r02_*; tools/critic_fit_probe.py): 10 us per launch at B = 131072 while the oldest buffer rows are still
+// zeros, 56-62 us in the steady state of an RQL closed loop (quadratic critic, m = 3): ~7000 VALU instructions per wave of
+// which 2100 are f64 fma, 40 % of the issue slots - a wave runs as many active-set iterations as its slowest lane (11-13
+// where the mean over envs is 2.2).  Tried in round 2: root-free L D L^T instead of L L^T (kept: 3 reciprocals instead
+// of 12 divides / square roots per solve, 3 % faster); warm-starting the walk from the previous fit (not adopted: on
+// rank-deficient stacks the end point depends on the start); running the NEXT tick's fit on a second stream while the
+// actor kernel runs - legal because the TD stack reads only the oldest rows - which hid the fit but slowed the actor
+// kernel by almost as much (configs[2] RQL tick 0.380 -> 0.371 ms generated, 0.549 -> 0.547 ms streamed): dropped.
 #pragma once
 #include "rcg_kernels.hpp"
 
@@ -66,16 +75,11 @@ __device__ __forceinline__ void critic_phi(const double* chi, const double* y, c
 
 template <typename real>
 struct FitArgs {
-  real* w_critic;         // [dc][B] out (nullptr: prefetch, see w_next)
-  real* w_prev;           // [dc][B] in (TD target weights), out (:= fitted w) unless w_next is given
-  real* w_next;           // [dc][B] or nullptr.  Prefetch mode (rcg_control_tick): the fit of the NEXT tick
-                          // is computed while this tick's actor kernel runs - the TD stack reads the OLDEST rows, which
-                          // after the next push are rows row0 .. row0 + m of the buffers as they are now - and written
-                          // here only; W_CRITIC / W_PREV receive it at the next tick
+  real* w_critic;         // [dc][B] out
+  real* w_prev;           // [dc][B] in (TD target weights), out (:= fitted w)
   const real* obs_buf;    // [buffer_size][dy][B]
   const real* act_buf;    // [buffer_size][du][B]
   const double* wcfg;     // [3][40]: w_init, w_min, w_max
-  int row0;               // first buffer row of the TD stack (0; 1 in prefetch mode)
 };
 
 template <typename Sys, typename real, int CS, int MAXM>
@@ -106,9 +110,9 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
     if (r <= m) {
       double y[DS], u[DU], chi[NCHI], phi[DC];
 #pragma unroll
-      for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)(F.row0 + r) * DS + c) * B + b];
+      for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)r * DS + c) * B + b];
 #pragma unroll
-      for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)(F.row0 + r) * DU + c) * B + b];
+      for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)r * DU + c) * B + b];
       if (P.has_target)
         make_chi<DS, DU, true, double>(P, y, u, chi);
       else
@@ -309,12 +313,8 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
   for (int i = 0; i < DC; ++i) {
     const double wi = w0[i] < lo[i] ? lo[i] : (w0[i] > hi[i] ? hi[i] : w0[i]);
     const double v = keep ? w[i] : wi;
-    if (F.w_next) {
-      F.w_next[(long)i * B + b] = (real)v;
-    } else {
-      F.w_critic[(long)i * B + b] = (real)v;
-      F.w_prev[(long)i * B + b] = (real)v;  // w_critic_prev = w_critic (controllers.py:1471)
-    }
+    F.w_critic[(long)i * B + b] = (real)v;
+    F.w_prev[(long)i * B + b] = (real)v;  // w_critic_prev = w_critic (controllers.py:1471)
   }
 }
 

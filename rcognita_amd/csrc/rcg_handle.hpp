@@ -20,14 +20,7 @@ struct rcg_handle {
   void* f[RCG_FIELD_COUNT_];
   size_t fbytes[RCG_FIELD_COUNT_];
   double* d_summary;
-  long tick_count;  // control ticks issued in the current episode (drives the critic period and the warm start)
-  // critic-fit prefetch (rcg_control_tick, RQL / SQL): the next tick's fit runs on `aux_stream` while this tick's actor
-  // kernel runs on `stream`; w_next receives it
-  hipStream_t aux_stream;
-  hipEvent_t ev_main, ev_aux;  // main -> aux: buffers and W_PREV ready; aux -> main: w_next ready, buffers no longer read
-  void* w_next;                // [dc][B]
-  bool prefetch_valid;         // w_next holds the fit of tick `prefetch_tick` of this episode (or will, after ev_aux)
-  long prefetch_tick;
+  long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
   void* d_const;    // constant block in HBM, layout kConst* below
   rcg::KParams<float> p32;
   rcg::KParams<double> p64;
@@ -69,8 +62,8 @@ struct ProfScope {
   int kernel;
   bool on;
   ProfScope(rcg_handle* h_, int kernel_)
-      : h(h_), a(nullptr), b(nullptr), kernel(kernel_), on(kernel_ >= 0 && ((h_->prof_mask >> kernel_) & 1u)) {
-    if (!on) return;  // (kernel_ < 0: a launch that is not on the handle's main stream is never bracketed)
+      : h(h_), a(nullptr), b(nullptr), kernel(kernel_), on((h_->prof_mask >> kernel_) & 1u) {
+    if (!on) return;
     // sampled: only every prof_stride-th launch of this kernel is bracketed (each event is a marker packet
     // on the stream; bracketing every launch of a ~230 us kernel costs a few percent of throughput)
     if ((h->prof_seen[kernel]++ % h->prof_stride) != 0) {
@@ -117,9 +110,7 @@ struct SysVTable {
   int (*actor)(rcg_handle*, const char* who, const void* cand, int K, const void* obs, const void* state_sys,
                const void* w, void* J, void* action, void* best_J, int32_t* best_idx, bool tick, bool sim_first);
   int (*sim_step)(rcg_handle*, int32_t n_substeps);
-  // push (action_curr, obs) into the buffers and / or fit: the fit reads buffer rows row0 .. row0 + m and writes
-  // W_CRITIC + W_PREV (w_next == nullptr) or w_next only, on `s`
-  int (*critic_update)(rcg_handle*, int32_t do_push, int32_t do_fit, int32_t row0, void* w_next, hipStream_t s);
+  int (*critic_update)(rcg_handle*, int32_t do_fit);
   int (*optimize)(rcg_handle*, int32_t iters, const void* obs, const void* state_sys, const void* u_init, int shift,
                   void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick);
   int (*nominal)(rcg_handle*, const void* obs, void* action, void* lyap, int32_t n, double gain, const double* ctrl_pars,

@@ -137,31 +137,28 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
 }
 
 template <typename Sys>
-static int op_critic_update(rcg_handle* h, int32_t do_push, int32_t do_fit, int32_t row0, void* w_next, hipStream_t s) {
+static int op_critic_update(rcg_handle* h, int32_t do_fit) {
   const int m = h->cfg.n_critic - 1;
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
-    ProfScope prof_scope(h, s == h->stream ? RCG_KERNEL_CRITIC : -1);
-    if (do_push)
-      hipLaunchKernelGGL((k_critic_push<Sys, real>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, s,
-                         (real*)h->f[RCG_FIELD_OBS_BUF], (real*)h->f[RCG_FIELD_ACT_BUF],
-                         (const real*)h->f[RCG_FIELD_STATE], (const real*)h->f[RCG_FIELD_ACTION], params<real>(h));
+    ProfScope prof_scope(h, RCG_KERNEL_CRITIC);
+    hipLaunchKernelGGL((k_critic_push<Sys, real>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream,
+                       (real*)h->f[RCG_FIELD_OBS_BUF], (real*)h->f[RCG_FIELD_ACT_BUF],
+                       (const real*)h->f[RCG_FIELD_STATE], (const real*)h->f[RCG_FIELD_ACTION], params<real>(h));
     if (do_fit) {
       FitArgs<real> F;
       F.w_critic = (real*)h->f[RCG_FIELD_W_CRITIC];
       F.w_prev = (real*)h->f[RCG_FIELD_W_PREV];
-      F.w_next = (real*)w_next;
       F.obs_buf = (const real*)h->f[RCG_FIELD_OBS_BUF];
       F.act_buf = (const real*)h->f[RCG_FIELD_ACT_BUF];
       F.wcfg = reinterpret_cast<const double*>((unsigned char*)h->d_const + kConstW);
-      F.row0 = row0;
       const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
-#define RCG_FIT(CS)                                                                                \
-  do {                                                                                             \
-    if (m <= 3)                                                                                    \
-      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, 3>), grid, block, 0, s, F, h->p64);           \
-    else                                                                                           \
-      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, s, F, h->p64); \
+#define RCG_FIT(CS)                                                                                         \
+  do {                                                                                                      \
+    if (m <= 3)                                                                                             \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, 3>), grid, block, 0, h->stream, F, h->p64);           \
+    else                                                                                                    \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, h->stream, F, h->p64); \
   } while (0)
       switch (h->cfg.critic_struct) {
         case RCG_CRITIC_QUAD_LIN: RCG_FIT(RCG_CRITIC_QUAD_LIN); break;
@@ -183,8 +180,7 @@ static int op_critic_update(rcg_handle* h, int32_t do_push, int32_t do_fit, int3
 //                           env-state loads - timing only, wrong results; the production library ignores it
 //   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL / SQL on k_actor
 //   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
-//   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor      RCG_NO_FIT_PREFETCH=1  critic fit inside its own tick
-//                                                                      (read in rcg_api.hip)
+//   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor
 // tests/test_hip_knobs.py checks that the scheduling variants reproduce the default launch bit for bit; bench.py
 // refuses to run with any RCG_* variable set.
 struct DevKnobs {

@@ -27,23 +27,6 @@ def main():
     for f in (N.FIELD_STATE, N.FIELD_STATE_PREV, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_STEP_IDX, N.FIELD_BEST_IDX,
               N.FIELD_BEST_J, N.FIELD_STATUS):
         h.update(np.ascontiguousarray(eng.get_field(f)).tobytes())
-    # an RQL closed loop with the critic refitted every tick / every 2nd tick (the fit of the next tick is prefetched
-    # on an auxiliary stream unless RCG_NO_FIT_PREFETCH is set), an episode reset and a set_field in between
-    for every in (1, 2):
-        B2 = 1000
-        e2 = Engine(preset_engine_config("2tank", B2, Nactor=6, mode="RQL", critic_struct="quadratic", Ncritic=4,
-                                         buffer_size=7, critic_every_ticks=every))
-        e2.set_state(np.stack([rng.uniform(0, 2, B2), rng.uniform(-2, 2, B2)], -1).astype(np.float32))
-        for t in range(14):
-            e2.control_tick(None, K=32)
-            if t == 6:
-                e2.episode_reset()
-            if t == 9:
-                e2.set_field(N.FIELD_W_PREV, e2.get_field(N.FIELD_W_PREV) * np.float32(1.5))
-        for f in (N.FIELD_STATE, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_W_CRITIC, N.FIELD_W_PREV, N.FIELD_OBS_BUF,
-                  N.FIELD_ACT_BUF, N.FIELD_BEST_IDX, N.FIELD_BEST_J):
-            h.update(np.ascontiguousarray(e2.get_field(f)).tobytes())
-        e2.close()
     print("HASH", h.hexdigest())
 
 

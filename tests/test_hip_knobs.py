@@ -31,6 +31,5 @@ def test_scheduling_variants_are_bit_identical():
     for knobs in ({"RCG_GPW": "1", "RCG_LDS_PAD": "-1"},     # one env per wave, no residency cap (the first geometry)
                   {"RCG_GPW": "16", "RCG_PER_CU": "4"},
                   {"RCG_GPW": "3", "RCG_PER_CU": "8"},       # envs per wave not a power of two
-                  {"RCG_NO_FIT_PREFETCH": "1"},              # critic fit inside its own tick instead of prefetched
                   {"RCG_DBG": "7"}):                         # timing-only switches: compiled OUT of the production library
         assert _run(knobs) == base, knobs
