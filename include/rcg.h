@@ -236,8 +236,9 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398), MPC with a
  * diagonal R1: `iters` iterations of {adjoint gradient of _actor_cost w.r.t. the whole sequence, box-scaled
- * projected line search over 16 step lengths (4 box widths down to 2^-28, ratio 4)}.  obs / state_sys as rcg_actor_cost; u_init [B][N][du] (NULL:
- * action_sqn_init = action_init tiled, as the reference starts every call); outputs, each may be NULL:
+ * projected line search over 16 step lengths (4 box widths down to 2^-28, ratio 4)}.  obs / state_sys as
+ * rcg_actor_cost; u_init [B][N][du] (NULL: action_sqn_init = action_init tiled, as the reference starts every call);
+ * outputs, each may be NULL:
  * u_opt [B][N][du], action [du][B] (first du entries, controllers.py:1427), best_J [B], n_iter [B] int32. */
 int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
                        void* u_opt, void* action, void* best_J, int32_t* n_iter);

@@ -1,10 +1,11 @@
 // rcg_actor_dma.hpp - k_actor_dma: the production kernel of the streamed rollout
 // (CtrlOptPred._actor_cost for K candidates per env + argmin + tick epilogue; controllers.py:1273-1427).
 //
-// Shape it serves: diagonal quadratic stage cost (every reference preset), K a multiple of 64, rollout started from the
-// observation (state_sys == obs: the control tick without ref_lag), the observation target as the system's preset has
-// it; f32: candidate rows of R = N*du <= 32 reals, modes MPC, RQL and SQL; f64 (the reference's own arithmetic width):
-// rows of <= 20 reals, MPC.  Everything else goes to k_actor (rcg_kernels.hpp).
+// Shape it serves: diagonal quadratic stage cost (every reference preset), K a multiple of 64, the observation target as
+// the system's preset has it; the rollout starts from `state_sys` with `obs` as y_0 (controllers.py:1286-1296) - the same
+// vector in the plain tick, the state before the last substep with RCG_FLAG_REF_LAG (the reference's loop order);
+// f32: candidate rows of R = N*du <= 32 reals, modes MPC, RQL and SQL; f64 (the reference's own arithmetic width): rows
+// of <= 20 reals, MPC.  Everything else goes to k_actor (rcg_kernels.hpp).
 //
 //   per tile of 64 candidate rows (64*R*sizeof(real) bytes, contiguous in HBM):
 //     1. direct-to-LDS loads: global_load_lds_dwordx4 (64 lanes x 16 B = 1 KiB each) plus global_load_lds_dword (256 B
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
   // "pointer ? load : default" selects (a default written into a register with a load in flight would force a
   // vmcnt(0) on the spot).
-  real y0[DS], yn[DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1], wc[DCMAX], wn[DCMAX];
+  real y0[DS], yn[DS], x0[DS], xn[DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1], wc[DCMAX], wn[DCMAX];
+  const bool lag = A.state_sys != A.obs;  // wave-uniform: a second state vector per env (20 B more per 20 KB of rows)
 #pragma unroll
   for (int i = 0; i < NP; ++i) pn[i] = P.pars[i];
 #pragma unroll
@@ -147,11 +149,15 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   auto fetch_env = [&](long b) {
     if (RCG_DBG(A, 4)) {  // development: no env-state loads
 #pragma unroll
-      for (int c = 0; c < DS; ++c) yn[c] = (real)0.5;
+      for (int c = 0; c < DS; ++c) yn[c] = xn[c] = (real)0.5;
       return;
     }
 #pragma unroll
     for (int c = 0; c < DS; ++c) yn[c] = A.obs[(long)c * B + b];
+    if (lag) {
+#pragma unroll
+      for (int c = 0; c < DS; ++c) xn[c] = A.state_sys[(long)c * B + b];
+    }
     if (A.pars_env) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) pn[i] = A.pars_env[(long)i * B + b];
@@ -185,7 +191,10 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   for (int g = 0; g < n_tiles; ++g) {
     if (t == 0) {  // first tile of env b: adopt the state requested one tile ago
 #pragma unroll
-      for (int c = 0; c < DS; ++c) y0[c] = yn[c];
+      for (int c = 0; c < DS; ++c) {
+        y0[c] = yn[c];
+        x0[c] = lag ? xn[c] : yn[c];
+      }
 #pragma unroll
       for (int i = 0; i < NP; ++i) pv[i] = pn[i];
       pre_env = Sys::template prepare<real>(pv);
@@ -214,7 +223,10 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
     // 4. _actor_cost of this lane's row (controllers.py:1284-1326), registers only
     real x[DS], y[DS];
 #pragma unroll
-    for (int c = 0; c < DS; ++c) x[c] = y[c] = y0[c];  // state_sys == observation (see the launcher)
+    for (int c = 0; c < DS; ++c) {
+      x[c] = x0[c];  // state_sys
+      y[c] = y0[c];  // observation_sqn[0] = observation
+    }
     real J = 0, gk = 1;
     real S[NCHI];
 #pragma unroll

@@ -22,6 +22,20 @@ def test_c_actor_cost_golden(name):
 
 
 @pytest.mark.parametrize("name", SYSTEMS)
+def test_c_actor_cost_golden_production_shape(name):
+    """F4b (64 sequences per env, state_sys == obs): the C oracle is the timed CPU baseline of exactly this shape."""
+    meta, z = load_golden(f"F4b_actor_cost_dma_{name}")
+    for c in meta["cases"]:
+        tag = c["tag"]
+        cfg = oracle_cfg(name, n_actor=c["N"], mode=O.MODE_IDS[c["mode"]], gamma=c["gamma"],
+                         critic_struct=O.CRITIC_IDS[c["critic_struct"]], pred_step_size=c["pred_step_size"])
+        x = z[f"{tag}__state"].astype(np.float64)
+        J = CO.actor_cost(cfg, z[f"{tag}__action_sqn"].astype(np.float64), x, x, w=z[f"{tag}__w"].astype(np.float64),
+                          nthreads=2)
+        assert J.shape == (2, 64) and rel_err(J, z[f"{tag}__J"]) < 1e-11, tag
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
 @pytest.mark.parametrize("per_env", [False, True])
 def test_c_control_tick_equals_numpy_oracle(name, per_env):
     rng = np.random.default_rng(21)

@@ -144,6 +144,60 @@ def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B):
     assert summ["count"] == B and summ["n_failed"] == 0
 
 
+def test_C4_job_sharded_eight_ways_equals_the_unsharded_job():
+    """configs[3] by construction on one GPU: the 524288-env Sys3WRobot job as ONE handle, and as the 8 shards
+    `shard_range` gives 8 ranks (65536 envs each, run one after the other here), same global states and candidate rows.
+    The concatenation of the shards' per-env returns - what the ranks all_gather - must equal the unsharded job's bit for
+    bit, the merged 6-number summaries must agree, integer counters exact, and a sample follows the oracle at 1e-5."""
+    from oracle import parity as PAR
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.parallel import merge_summaries, shard_config, shard_range
+    from rcognita_amd.pool import preset_engine_config
+
+    total, world, K, Nh, T = 524288, 8, 64, 5, 3
+    rng = np.random.default_rng(524288)
+    x0 = rand_states(rng, "3wrobot", total).astype(np.float32)
+    cfg = oracle_cfg("3wrobot", n_actor=Nh)
+    lo, hi = cfg.ctrl_bnds[:, 0].astype(np.float32), cfg.ctrl_bnds[:, 1].astype(np.float32)
+    cand = (lo + (hi - lo) * rng.random((total, K, Nh, 2), dtype=np.float32))  # 1.3 GB, the job's candidate tensor
+    base = preset_engine_config("3wrobot", total, Nactor=Nh)
+    whole = Engine(base)
+    whole.set_state(x0)
+    dc = whole.to_device(cand)
+    sel = np.sort(rng.choice(total, 64, replace=False))
+    env = O.new_batch(cfg, x0[sel].astype(np.float64))
+    for t in range(T):
+        whole.control_tick(dc, K=K)
+        dev = {k: v[sel] for k, v in PAR.device_fields(whole, N).items()}
+        env = PAR.check_tick(cfg, env, cand[sel].astype(np.float64), dev, tol=1e-5, what=f"C4 t={t}")
+    summ_whole, ret_whole = whole.episode_stats(from_accum=True, want_returns=True)
+    np.testing.assert_array_equal(whole.get_field(N.FIELD_STEP_IDX), np.full(total, T, np.int32))
+    act_whole = whole.get_field(N.FIELD_ACTION)
+    dc.free()
+    whole.close()
+    parts, rets, acts = [], [], []
+    for r in range(world):
+        ecfg, (a, b) = shard_config(base, total, r, world)
+        assert (a, b) == shard_range(total, r, world) and b - a == 65536 and ecfg.env_id_base == a
+        e = Engine(ecfg)
+        e.set_state(x0[a:b])
+        d = e.to_device(cand[a:b])
+        for _ in range(T):
+            e.control_tick(d, K=K)
+        s, ret = e.episode_stats(from_accum=True, want_returns=True)
+        parts.append(s)
+        rets.append(ret)
+        acts.append(e.get_field(N.FIELD_ACTION))
+        d.free()
+        e.close()
+    np.testing.assert_array_equal(np.concatenate(rets), ret_whole)   # the all_gather payload
+    np.testing.assert_array_equal(np.concatenate(acts), act_whole)
+    merged = merge_summaries(parts)
+    assert merged["count"] == total == summ_whole["count"] and merged["n_failed"] == 0
+    assert merged["min"] == summ_whole["min"] and merged["max"] == summ_whole["max"]
+    np.testing.assert_allclose(merged["sum"], summ_whole["sum"], rtol=1e-12)
+
+
 def test_one_million_envs():
     """Size edge: B = 2^20 envs (16x the bench batch) through the tick with generated candidates, an episode reset in
     the middle.  Integer fields exact for every env, the summary consistent with the per-env returns, and a random
