@@ -86,24 +86,34 @@ def _wrap(theta):
 
 
 def theta_star(xNI, eta):
-    """Build-defined replacement of _minimizer_theta (controllers.py:1625-1634).  Fc is 2 pi periodic in theta:
-    (1) evaluate it at theta_j = -pi + j h, h = 2 pi / 64, non-finite = +inf, first minimum wins;
+    """Build-defined replacement of _minimizer_theta (controllers.py:1618-1627), which runs SciPy trust-constr from
+    theta = 0: a LOCAL search.  Fc is 2 pi periodic in theta:
+    (1) on the grid theta_j = -pi + j h, h = 2 pi / 64, walk downhill from theta = 0 (j = 32): step to the lower
+        neighbour (the left one on a tie) while it is lower than the current point, at most 64 steps, non-finite = +inf;
     (2) GOLD_ITERS golden-section steps on [theta_j* - h, theta_j* + h] (ties keep the left part);
-    (3) midpoint of the final bracket, wrapped into [-pi, pi].  The HIP kernel k_nominal mirrors this exactly."""
+    (3) midpoint of the final bracket, wrapped into [-pi, pi].  The HIP kernel k_nominal mirrors this exactly.
+    On the F10 states this lands on the reference's minimiser for 93 % of them (round 1 took the GLOBAL minimum of the
+    64-point scan: never a worse Fc than the reference, but the reference's own basin for only 72 %)."""
     B = xNI.shape[0]
     h = 2 * np.pi / N_THETA
     with np.errstate(all="ignore"):
-        best, bj = np.full(B, np.inf), np.zeros(B, dtype=np.int64)
-        for j in range(N_THETA):
-            f = Fc(xNI, eta, np.full(B, -np.pi + j * h))
-            f = np.where(np.isfinite(f), f, np.inf)
-            upd = f < best
-            best, bj = np.where(upd, f, best), np.where(upd, j, bj)
+        fin = lambda th: (lambda f: np.where(np.isfinite(f), f, np.inf))(Fc(xNI, eta, th))
+        grid = lambda j: -np.pi + np.mod(j, N_THETA) * h
+        bj = np.full(B, N_THETA // 2, dtype=np.int64)
+        fc = fin(grid(bj))
+        for _ in range(N_THETA):
+            fl, fr = fin(grid(bj - 1)), fin(grid(bj + 1))
+            go_l = (fl < fc) & (fl <= fr)
+            go_r = (~go_l) & (fr < fc)
+            if not (go_l | go_r).any():
+                break
+            bj = np.where(go_l, bj - 1, np.where(go_r, bj + 1, bj))
+            fc = np.where(go_l, fl, np.where(go_r, fr, fc))
+        bj = np.mod(bj, N_THETA)
         a = -np.pi + (bj - 1) * h
         b = -np.pi + (bj + 1) * h
         x1 = b - INV_PHI * (b - a)
         x2 = a + INV_PHI * (b - a)
-        fin = lambda th: (lambda f: np.where(np.isfinite(f), f, np.inf))(Fc(xNI, eta, th))
         f1, f2 = fin(x1), fin(x2)
         for _ in range(GOLD_ITERS):
             left = f1 <= f2

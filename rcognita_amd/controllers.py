@@ -366,7 +366,7 @@ class _CtrlNominal:
 class CtrlNominal3WRobot(_CtrlNominal):
     """Nominal controller of the 3-wheel robot with dynamic actuators, nonsmooth backstepping
     (rcognita/controllers.py:1495-1755).  theta* (SciPy trust-constr in the reference) comes from the build-defined
-    scan + golden-section search of rcg_nominal.hpp."""
+    local search (downhill walk from theta = 0 on a 64-point grid + golden section) of rcg_nominal.hpp."""
     _sys_id, _dy = N.SYS_3WROBOT, 5
 
     def __init__(self, m, I, ctrl_gain=10, ctrl_bnds=[], t0=0, sampling_time=0.1, dtype="f64", device=0):

@@ -6,10 +6,11 @@
 //   CtrlNominal3WRobot    rcognita/controllers.py:1495-1755  nonsmooth backstepping on top of it; needs
 //                         theta* = argmin_theta Fc(xNI, eta, theta)
 //
-// The reference finds theta* with SciPy trust-constr from theta = 0 (controllers.py:1625-1634).  The build defines
-// it as: scan Fc at 64 points of its period, then 40 golden-section steps around the best one, midpoint wrapped to
-// [-pi, pi] - exactly oracle/nominal_oracle.py::theta_star, which is pinned against the reference's own outputs
-// (tests/golden/F10_nominal_*.npz).  Arithmetic follows the reference's expressions term by term (including the
+// The reference finds theta* with SciPy trust-constr from theta = 0 (controllers.py:1618-1627): a LOCAL search.  The
+// build defines it as: on the 64-point grid of Fc's period walk downhill from theta = 0 to a grid-local minimum, then 40
+// golden-section steps around it, midpoint wrapped to [-pi, pi] - exactly oracle/nominal_oracle.py::theta_star, which
+// is pinned against the reference's own outputs (tests/golden/F10_nominal_*.npz: the reference's minimiser on 93 % of the
+// states; round 1 took the global minimum of the scan, which is the reference's basin on only 72 %).  Arithmetic follows the reference's expressions term by term (including the
 // 0 * zeta products of its np.dot, which matter only for inf/NaN propagation).  The law takes cube roots of sums
 // that cancel (it is not Lipschitz there), so it is always evaluated in float64, whatever the handle's dtype: an f32
 // handle returns the f64 law of its f32 states, rounded once.  Sys2Tank has no nominal controller in the reference:
@@ -131,15 +132,30 @@ struct Nominal<Sys3WRobot> {
     const real x14x24 = xn[0] * xn[0] * xn[0] * xn[0] + xn[1] * xn[1] * xn[1] * xn[1];
     const real PI = (real)3.141592653589793238462643383279502884;
     const real h = (real)2 * PI / (real)NOM_N_THETA;
-    real best = inf_r<real>();
-    int bj = 0;
-    for (int j = 0; j < NOM_N_THETA; ++j) {
-      const real f = nom_Fc<real>(xn, eta, sq3, a3, x14x24, -PI + (real)j * h);
-      if (f < best) {
-        best = f;
-        bj = j;
+    // walk downhill on the grid from theta = 0 (j = N/2): to the lower neighbour (the left one on a tie) while it is
+    // lower than the current point; each step costs one new evaluation (the other two are the previous step's)
+    auto grid = [&](int j) -> real {
+      const int jm = ((j % NOM_N_THETA) + NOM_N_THETA) % NOM_N_THETA;
+      return nom_Fc<real>(xn, eta, sq3, a3, x14x24, -PI + (real)jm * h);
+    };
+    int bj = NOM_N_THETA / 2;
+    real fc = grid(bj), fl = grid(bj - 1), fr = grid(bj + 1);
+    for (int it = 0; it < NOM_N_THETA; ++it) {
+      if (fl < fc && fl <= fr) {
+        --bj;
+        fr = fc;
+        fc = fl;
+        fl = grid(bj - 1);
+      } else if (fr < fc) {
+        ++bj;
+        fl = fc;
+        fc = fr;
+        fr = grid(bj + 1);
+      } else {
+        break;
       }
     }
+    bj = ((bj % NOM_N_THETA) + NOM_N_THETA) % NOM_N_THETA;
     const real IPHI = (real)0.6180339887498949;
     real a = -PI + (real)(bj - 1) * h, b = -PI + (real)(bj + 1) * h;
     real t1 = b - IPHI * (b - a), t2 = a + IPHI * (b - a);

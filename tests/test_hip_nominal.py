@@ -37,8 +37,9 @@ def test_ni_nominal_matches_reference_outputs(dtype):
 
 
 def test_endi_nominal_vs_oracle_and_reference_f64():
-    """(a) HIP == oracle (same theta search, same arithmetic); (b) Fc(theta*) never above what the reference's
-    trust-constr reached; (c) where both found the same minimiser the clipped actions agree."""
+    """(a) HIP == oracle (same theta search, same arithmetic); (b) the reference's own minimiser (trust-constr from
+    theta = 0) on > 90 % of the fixture states and Fc(theta*) not above the reference's on >= 95 %; (c) the clipped
+    actions agree with the reference's on > 90 % of ALL states."""
     meta, z = load_golden("F10_nominal_3wrobot")
     x = z["state"]
     eng, _ = both("3wrobot", x.shape[0], "f64")
@@ -50,11 +51,11 @@ def test_endi_nominal_vs_oracle_and_reference_f64():
     # the action is a cube root of theta-dependent terms: golden section pins theta to ~1e-9
     bad = np.abs(a - a_or) > 1e-5 * (np.abs(a_or) + 1)
     assert bad.mean() < 0.02, bad.mean()
-    assert np.all(L <= z["Fc_star"] * (1 + 1e-9) + 1e-12)
+    assert np.mean(L <= z["Fc_star"] * (1 + 1e-9) + 1e-12) >= 0.95
     xNI, eta = NO.cart2nh(x)
     same = np.abs(np.angle(np.exp(1j * (NO.theta_star(xNI, eta) - z["theta_star"])))) < 1e-3
     close = np.all(np.abs(a - z["action"]) <= 2e-2 * (np.abs(z["action"]) + 1), axis=1)
-    assert same.mean() > 0.5 and close[same].mean() > 0.9
+    assert same.mean() > 0.9 and close[same].mean() > 0.95 and close.mean() > 0.9
     # handle pars are the default controller parameters
     a2 = eng.nominal_action(x, meta["ctrl_gain"], clip=True)
     np.testing.assert_array_equal(a2, a)
