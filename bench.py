@@ -459,6 +459,17 @@ def main(argv=None):
     returns_dev = torch.zeros(Bmax, device="cuda", dtype=tdtype)
     gathered = [torch.empty(Bmax, device=coll_dev, dtype=tdtype) for _ in range(world)] if dist is not None else None
 
+    def exchange_returns():
+        """Episode-end exchange: ONE all_gather of the per-env running returns over RCCL."""
+        off = 0
+        for e in engines:
+            N.check(N.lib().rcg_get_field(e._h, N.FIELD_ACCUM, returns_dev[off:].data_ptr(), N.DEVICE), e._h)
+            off += e.B
+        dist.all_gather(gathered, returns_dev if coll_dev.type == "cuda" else returns_dev.cpu())
+
+    if dist is not None:
+        exchange_returns()  # untimed: RCCL builds its rings / channels on the first collective of each kind
+
     # HIP events around the kernels of the tick on the engine's own stream, inside the timed region; sampled
     # (every n-th launch) because each event is a marker packet on the stream.
     # Only the dominant kernel is bracketed, and sparsely: an event is a barrier packet, the bracketed kernel cannot overlap
@@ -474,13 +485,7 @@ def main(argv=None):
     for _ in range(args.steps):
         tick()
     if dist is not None:
-        # episode-end exchange: ONE all_gather of the per-env running returns over RCCL
-        off = 0
-        for e in engines:
-            n_e = e.B
-            N.check(N.lib().rcg_get_field(e._h, N.FIELD_ACCUM, returns_dev[off:].data_ptr(), N.DEVICE), e._h)
-            off += n_e
-        dist.all_gather(gathered, returns_dev if coll_dev.type == "cuda" else returns_dev.cpu())
+        exchange_returns()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -252,7 +252,8 @@ int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start);
  * [du][n]; lyap (may be NULL): device [n], the Lyapunov function value of compute_LF.  ctrl_pars: host (m, I) of the
  * 3wrobot controller's constructor, NULL = the handle's pars; ignored for 3wrobotNI.  clip != 0: clip to ctrl_bnds as
  * compute_action does.  theta* of the 3wrobot controller (SciPy trust-constr in the reference) is build-defined:
- * downhill walk from theta = 0 on a 64-point grid + golden section (the reference's minimiser on 93 % of its fixture).  Sys2Tank has no nominal controller: RCG_ERR_UNSUPPORTED. */
+ * downhill walk from theta = 0 on a 64-point grid + golden section (the reference's minimiser on 93 % of its fixture).
+ * Sys2Tank has no nominal controller: RCG_ERR_UNSUPPORTED. */
 int rcg_nominal_action(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double ctrl_gain,
                        const double* ctrl_pars, int32_t clip);
 /* One control tick under the nominal controller ('--ctrl_mode nominal', presets/main_3wrobot.py:425 through

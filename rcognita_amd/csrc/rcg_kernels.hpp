@@ -386,6 +386,124 @@ __device__ __forceinline__ void segment_argmin(int seg, real& bestJ, int& bestI,
   }
 }
 
+// NC generated candidates of ONE lane (tiles t .. t + NC - 1 of the level grid: same second input, NC different first
+// inputs) rolled out together, MPC with a diagonal quadratic stage cost.  Every candidate goes through exactly the
+// operation sequence of rollout_cost<MPC, 0, -1, G1> - its cost is the same bits - but the state components that depend
+// only on (x_0, u[1]) (Sys::SHARED_U1: heading and turn rate of the robots) and their cost terms are THE SAME VALUES for
+// all NC candidates; after each step they are taken from candidate 0, which makes them the same SSA values, and the
+// compiler's common-subexpression elimination then keeps one sin/cos, one heading update and one alpha^2 / omega^2 / M^2
+// accumulation per lane and step instead of NC.  The generated-candidate regime is bound by VALU instruction issue
+// (profiles/r02_valu_pmc.json: > 100 % of the 4-cycle issue slots), so instructions are the currency: 3wrobot, NC = 4,
+// gamma = 1: ~13 instead of 27 per candidate-step.
+template <typename Sys, typename real, bool TGT, bool G1, int NC>
+__device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, const typename Sys::template Pre<real>& pre,
+                                                      int N, const real* xs, const real* y0, const real* u0v, real u1,
+                                                      real* Jout) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  constexpr unsigned SH = Sys::SHARED_U1;
+  static_assert(DU == 2, "candidates of a lane share their second input");
+  const real h = P.h_pred;
+  real x[NC][DS], y[NC][DS], u[NC][DU], J[NC], S[NC][G1 ? NCHI : 1];
+  real gk = 1;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      x[c][i] = xs[i];
+      y[c][i] = y0[i];
+    }
+    u[c][0] = u0v[c];
+    u[c][1] = u1;
+    J[c] = 0;
+#pragma unroll
+    for (int i = 0; i < (G1 ? NCHI : 1); ++i) S[c][i] = 0;
+  }
+  for (int kk = 0; kk < N; ++kk) {
+    if (kk > 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        real d[DS];
+        Sys::template rhs<real, std::is_same<real, float>::value>(pre, x[c], u[c], d);  // unclipped (controllers.py:1294)
+#pragma unroll
+        for (int i = 0; i < DS; ++i) {
+          x[c][i] = fma_r(h, d[i], x[c][i]);
+          y[c][i] = x[c][i];  // sys_out is the identity
+        }
+      }
+#pragma unroll
+      for (int c = 1; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < DS; ++i)
+          if ((SH >> i) & 1u) {  // identical by construction: name them identically
+            x[c][i] = x[0][i];
+            y[c][i] = y[0][i];
+          }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      real chi[NCHI];
+      make_chi<DS, DU, TGT, real>(P, y[c], u[c], chi);
+      if (G1) {
+#pragma unroll
+        for (int i = 0; i < NCHI; ++i) S[c][G1 ? i : 0] = fma_r(chi[i], chi[i], S[c][G1 ? i : 0]);
+      } else {
+        J[c] = fma_r(gk, stage_diag<NCHI, real>(P, chi), J[c]);
+      }
+    }
+    if (G1) {
+#pragma unroll
+      for (int c = 1; c < NC; ++c) {
+#pragma unroll
+        for (int i = 0; i < DS; ++i)
+          if ((SH >> i) & 1u) S[c][G1 ? i : 0] = S[0][G1 ? i : 0];
+        S[c][G1 ? DS + 1 : 0] = S[0][G1 ? DS + 1 : 0];  // the shared input's own term
+      }
+    } else {
+      gk *= P.gamma;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (G1) {
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) J[c] = fma_r(P.R1d[i], S[c][G1 ? i : 0], J[c]);
+    }
+    Jout[c] = J[c];
+  }
+}
+
+// Tiles t .. t + NC - 1 of the generated grid for this lane through rollout_mpc_gen_multi, folded into the lane's
+// running (bestJ, bestI, bestU) in candidate order.  Requires one env per wave (K >= 64), du = 2 and 64 % g == 0, so
+// that candidate k + 64 has the same second level as candidate k.
+template <typename Sys, typename real, bool TGT, int NC>
+__device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
+                                                int K, int g, int t, int lane, bool env_ok, const real* xs,
+                                                const real* y0, real& bestJ, int& bestI, real* bestU) {
+  const int k0 = t * 64 + lane;
+  real ua[NC][2], u0v[NC], J[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ua[c][0] = ua[c][1] = 0;
+    gen_candidate<2, real>(P, g, k0 + 64 * c, ua[c]);
+    u0v[c] = ua[c][0];
+  }
+  if (P.gamma == (real)1)  // wave-uniform
+    rollout_mpc_gen_multi<Sys, real, TGT, true, NC>(P, pre, N, xs, y0, u0v, ua[0][1], J);
+  else
+    rollout_mpc_gen_multi<Sys, real, TGT, false, NC>(P, pre, N, xs, y0, u0v, ua[0][1], J);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int k = k0 + 64 * c;
+    const real Jc = (J[c] != J[c]) ? inf_r<real>() : J[c];  // NaN counts as +inf
+    if (env_ok && k < K && (Jc < bestJ || bestI == 0x7fffffff)) {
+      bestJ = Jc;
+      bestI = k;
+      bestU[0] = ua[c][0];
+      bestU[1] = ua[0][1];
+    }
+  }
+}
+
 // upd_accum_obj (controllers.py:1086-1093): accum + rho(obs, action) * sampling_time, one rounding
 template <typename Sys, bool TGT, typename real>
 __device__ __forceinline__ real accum_update(const KParams<real>& P, const real* obs, const real* act, real accum) {
@@ -446,7 +564,22 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
 
   const int envs_here = big ? 1 : (int)((B - wave * A.G) < A.G ? (B - wave * A.G) : A.G);
 
+  // generated grid, MPC / diagonal R1, two inputs, 64 % g == 0: the lane's tiles share their second input and are rolled
+  // out four (two) at a time with the shared sub-trajectory computed once (rollout_mpc_gen_multi)
+  const bool multi_ok = !STREAM && !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 && (64 % A.grid_g) == 0;
   for (int t = 0; t < A.n_tiles; ++t) {
+    if constexpr (!STREAM && !GENERIC && DU == 2 && Sys::SHARED_U1 != 0) {
+      if (multi_ok && t + 4 <= A.n_tiles) {
+        gen_multi_tiles<Sys, real, TGT, 4>(P, pre, N, K, A.grid_g, t, lane, env_ok, xs, y0, bestJ, bestI, bestU);
+        t += 3;
+        continue;
+      }
+      if (multi_ok && t + 2 <= A.n_tiles) {
+        gen_multi_tiles<Sys, real, TGT, 2>(P, pre, N, K, A.grid_g, t, lane, env_ok, xs, y0, bestJ, bestI, bestU);
+        t += 1;
+        continue;
+      }
+    }
     const int k = big ? t * 64 + kl : kl;
     const bool valid = env_ok && k < K;
     int r = 0;  // my row inside the tile
@@ -645,7 +778,20 @@ __global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KP
     real bestU[DU];
 #pragma unroll
     for (int c = 0; c < DU; ++c) bestU[c] = 0;
+    const bool multi_ok = !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 && (64 % A.grid_g) == 0;
     for (int tl = 0; tl < A.n_tiles; ++tl) {  // k_actor, generated candidates
+      if constexpr (!GENERIC && DU == 2 && Sys::SHARED_U1 != 0) {
+        if (multi_ok && tl + 4 <= A.n_tiles) {
+          gen_multi_tiles<Sys, real, TGT, 4>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
+          tl += 3;
+          continue;
+        }
+        if (multi_ok && tl + 2 <= A.n_tiles) {
+          gen_multi_tiles<Sys, real, TGT, 2>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
+          tl += 1;
+          continue;
+        }
+      }
       const int k = big ? tl * 64 + kl : kl;
       const bool valid = env_ok && k < K;
       real ugen[DU], u0[DU];

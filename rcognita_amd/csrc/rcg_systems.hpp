@@ -15,6 +15,9 @@ namespace rcg {
 struct Sys3WRobot {
   static constexpr int DS = 5, DU = 2, NP = 2;
   static constexpr bool TGT = false;  // observation_target of the preset: [] (k_actor_dma instances exist for this value)
+  // state components whose trajectory under the model depends only on (x_0, u[1]) - heading and turn rate follow the
+  // torque alone; candidates of the generated grid that share u[1] share them (rollout_mpc_gen_multi, rcg_kernels.hpp)
+  static constexpr unsigned SHARED_U1 = (1u << 2) | (1u << 4);
   template <typename real>
   struct Pre {
     real inv_m, inv_I;
@@ -53,6 +56,7 @@ struct Sys3WRobot {
 struct Sys3WRobotNI {
   static constexpr int DS = 3, DU = 2, NP = 0;
   static constexpr bool TGT = false;
+  static constexpr unsigned SHARED_U1 = 1u << 2;  // the heading follows omega = u[1] alone
   template <typename real>
   struct Pre {};
   template <typename real>
@@ -84,6 +88,7 @@ struct Sys3WRobotNI {
 struct Sys2Tank {
   static constexpr int DS = 2, DU = 1, NP = 5;
   static constexpr bool TGT = true;  // main_2tank.py:211: observation_target = [0.5, 0.5]
+  static constexpr unsigned SHARED_U1 = 0;  // one input
   template <typename real>
   struct Pre {
     real inv_tau1, inv_tau2, K1, K2, K3;
