@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 110 /* 0.1.1 */
+#define RCG_VERSION 111 /* 0.1.1 + checkpoint counter */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -270,6 +270,16 @@ int rcg_episode_reset(rcg_handle* h);
 /* Summary of `RETURNS` (from_accum == 0) or of the running ACCUM (from_accum != 0) over this
  * handle's envs; returns_out (host, [B] real, may be NULL) receives the per-env values. */
 int rcg_episode_stats(rcg_handle* h, int32_t from_accum, void* returns_out, rcg_summary* out);
+
+/* ---- checkpoint / resume --------------------------------------------------------------------- */
+/* Everything a handle carries between ticks is the per-env tensors above (rcg_get_field / rcg_set_field) plus ONE host
+ * counter: the control ticks issued in the current episode, which drives the critic period (fits on ticks k-1, 2k-1, ...
+ * of an episode) and the warm start of rcg_control_tick_opt.  A checkpoint = all allocated fields + this counter; a
+ * handle created with the same rcg_cfg and restored from it continues bit-identically
+ * (rcognita_amd.Engine.checkpoint / restore).  The reference has no checkpointing: learned parameters persist in the
+ * controller object (controllers.py:1046-1054). */
+int64_t rcg_tick_count(const rcg_handle* h);
+int rcg_set_tick_count(rcg_handle* h, int64_t ticks);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 typedef enum rcg_kernel { RCG_KERNEL_ACTOR = 0, RCG_KERNEL_SIM = 1, RCG_KERNEL_CRITIC = 2, RCG_KERNEL_COUNT_ = 3 } rcg_kernel;

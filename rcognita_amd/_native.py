@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCG_LIB") or os.path.join(_HERE, "lib", "librcg.so")
 
 # ---- enums (include/rcg.h) -------------------------------------------------------------------
-RCG_VERSION = 110
+RCG_VERSION = 111
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
 SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
 MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
@@ -30,6 +30,7 @@ DIM_DISTURB = {0: 2, 1: 2, 2: 1}  # sys_id -> dim_disturb (presets/main_*.py)
 (FIELD_STATE, FIELD_ACTION, FIELD_ACCUM, FIELD_STEP_IDX, FIELD_EPISODE_IDX, FIELD_STATUS, FIELD_PARS,
  FIELD_STATE_INIT, FIELD_STATE_PREV, FIELD_BEST_J, FIELD_BEST_IDX, FIELD_W_CRITIC, FIELD_W_PREV, FIELD_OBS_BUF,
  FIELD_ACT_BUF, FIELD_RETURNS, FIELD_ACTION_SQN, FIELD_DISTURB, FIELD_SUBSTEP_IDX) = range(19)
+FIELD_COUNT = 19
 
 MODE_IDS = {"MPC": MODE_MPC, "RQL": MODE_RQL, "SQL": MODE_SQL}
 STAGE_IDS = {"quadratic": STAGE_QUADRATIC, "biquadratic": STAGE_BIQUADRATIC}
@@ -45,7 +46,7 @@ SYMBOLS = [
     "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
     "rcg_critic_update", "rcg_control_ticks", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
-    "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_profile", "rcg_profile_read",
+    "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 
@@ -134,6 +135,8 @@ def lib():
         "rcg_disturb_noise": (C.c_int, [vp, vp, vp]),
         "rcg_episode_reset": (C.c_int, [vp]),
         "rcg_episode_stats": (C.c_int, [vp, i32, vp, C.POINTER(RcgSummary)]),
+        "rcg_tick_count": (i64, [vp]),
+        "rcg_set_tick_count": (C.c_int, [vp, i64]),
         "rcg_profile": (C.c_int, [vp, i32]),
         "rcg_profile_read": (C.c_int, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
     }

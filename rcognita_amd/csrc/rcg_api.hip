@@ -681,6 +681,16 @@ int rcg_episode_stats(rcg_handle* h, int32_t from_accum, void* returns_out, rcg_
                   : RCG_OK;
 }
 
+// ---- checkpoint / resume --------------------------------------------------------------------
+int64_t rcg_tick_count(const rcg_handle* h) { return h ? (int64_t)h->tick_count : -1; }
+
+int rcg_set_tick_count(rcg_handle* h, int64_t ticks) {
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (ticks < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_tick_count: ticks must be >= 0");
+  h->tick_count = (long)ticks;
+  return RCG_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------
 int rcg_profile(rcg_handle* h, int32_t enable) {
   DeviceGuard dev_guard(h);

@@ -520,6 +520,40 @@ class Engine:
                                           C.byref(s)), self._h, allow=(N.ERR_NONFINITE,))
         return {k: getattr(s, k) for k in ("count", "sum", "sumsq", "min", "max", "n_failed")}, out
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything the handle carries between ticks: every allocated per-env tensor (host arrays in the reference's
+        shapes) plus the episode's tick counter (rcg_tick_count)."""
+        out = {"tick_count": np.int64(N.lib().rcg_tick_count(self._h)), "batch": np.int64(self.B),
+               "sys_id": np.int64(self.cfg.sys_id), "dtype": np.str_(self.cfg.dtype)}
+        for f in range(N.FIELD_COUNT):
+            if N.lib().rcg_field_bytes(self._h, f) > 0:
+                out[f"field_{f}"] = self.get_field(f)
+        return out
+
+    def load_state_dict(self, sd):
+        if int(sd["batch"]) != self.B or int(sd["sys_id"]) != int(self.cfg.sys_id) or str(sd["dtype"]) != self.cfg.dtype:
+            raise ValueError("checkpoint was written by a handle with another batch / system / dtype")
+        for f in range(N.FIELD_COUNT):
+            have = N.lib().rcg_field_bytes(self._h, f) > 0
+            if have != (f"field_{f}" in sd):
+                raise ValueError(f"checkpoint and handle disagree on field {f} (different mode / flags)")
+        # STATE first: rcg_set_field(STATE) also resets STATE_PREV, which is then restored from its own entry
+        order = [N.FIELD_STATE] + [f for f in range(N.FIELD_COUNT) if f != N.FIELD_STATE]
+        for f in order:
+            if f"field_{f}" in sd:
+                self.set_field(f, sd[f"field_{f}"])
+        N.check(N.lib().rcg_set_tick_count(self._h, int(sd["tick_count"])), self._h)
+
+    def checkpoint(self, path):
+        """Write :meth:`state_dict` to ``path`` (.npz).  A handle created with the same EngineConfig and restored from
+        the file continues bit-identically."""
+        np.savez(path, **self.state_dict())
+
+    def restore(self, path):
+        with np.load(path, allow_pickle=False) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
+
     # ------------------------------------------------------------------ measurement
     def profile(self, kernels=(N.KERNEL_ACTOR, N.KERNEL_SIM, N.KERNEL_CRITIC), stride=1):
         """Bracket every ``stride``-th launch of the given kernels with HIP events on the engine's own

@@ -168,6 +168,8 @@ static void abi_host_side(void) {
   EXPECT(rcg_episode_stats(NULL, 0, NULL, &s) < 0);
   EXPECT(rcg_profile(NULL, 1) < 0);
   EXPECT(rcg_profile_read(NULL, 0, &ms, &nl) < 0);
+  EXPECT(rcg_tick_count(NULL) < 0);
+  EXPECT(rcg_set_tick_count(NULL, 3) < 0);
   EXPECT(rcg_last_error(NULL)[0] != '\0');
 }
 

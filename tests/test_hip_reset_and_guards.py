@@ -93,6 +93,44 @@ def test_episode_reset_keeps_critic_state_and_restarts_the_clock(mode, every, dt
     np.testing.assert_array_equal(eng.get_field(N.FIELD_EPISODE_IDX), env.episode_idx)
 
 
+@pytest.mark.parametrize("name,mode,kw", [
+    ("2tank", O.MODE_RQL, dict(critic_struct=O.CRITIC_QUADRATIC, n_critic=4, buffer_size=7, critic_every_ticks=3)),
+    ("3wrobot", O.MODE_MPC, dict(per_env_pars=True)),
+    ("3wrobotNI", O.MODE_SQL, dict(critic_struct=O.CRITIC_QUAD_MIX, n_critic=3, buffer_size=5, ref_lag=True)),
+])
+def test_checkpoint_restore_continues_bit_identically(name, mode, kw, tmp_path):
+    """SURVEY.md 5 (checkpoint / resume): a handle is its per-env tensors plus one host counter.  Run 5 ticks, write
+    a checkpoint, run 6 more; a FRESH handle restored from the file and run for the same 6 ticks ends with every field
+    bit-identical (critic period phase, buffers, weights, counters included)."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(44)
+    B, K = 33, 16
+    a, _ = both(name, B, "f32", n_actor=5, mode=mode, **kw)
+    b, _ = both(name, B, "f32", n_actor=5, mode=mode, **kw)
+    if kw.get("per_env_pars"):
+        pars = np.stack([rng.uniform(5, 20, B), rng.uniform(0.5, 2, B)], axis=-1)
+        a.set_field(N.FIELD_PARS, pars)
+    a.set_state(rand_states(rng, name, B))
+    for _ in range(5):
+        a.control_tick(None, K=K)
+    path = str(tmp_path / "ck.npz")
+    a.checkpoint(path)
+    for _ in range(6):
+        a.control_tick(None, K=K)
+    b.restore(path)
+    assert N.lib().rcg_tick_count(b._h) == 5
+    for _ in range(6):
+        b.control_tick(None, K=K)
+    for f in range(N.FIELD_COUNT):
+        if N.lib().rcg_field_bytes(a._h, f) > 0:
+            np.testing.assert_array_equal(b.get_field(f), a.get_field(f), err_msg=f"field {f}")
+    assert N.lib().rcg_tick_count(b._h) == N.lib().rcg_tick_count(a._h) == 11
+    other, _ = both(name, B + 1, "f32", n_actor=5, mode=mode, **kw)
+    with pytest.raises(ValueError):
+        other.restore(path)
+
+
 def test_warm_start_does_not_cross_an_episode_boundary():
     """rcg_control_tick_opt(warm_start=1): the first decision of an episode starts from action_sqn_init like the
     reference does on every call - the previous episode's optimum is not shifted into it."""
