@@ -212,6 +212,7 @@ struct ActorArgs {
   int vec_ok;             // rows are 16-B granular: stage with dwordx4
   int gpw;                // k_actor_dma: consecutive envs per (persistent) wave
   int jwave;              // k_actor_dma, J output: stage the costs of all envs of the wave in LDS (else env by env)
+  int no_multi;           // development (env RCG_NO_GEN_MULTI): generated tiles one at a time (A/B of rollout_mpc_gen_multi)
   int dbg;                // -DRCG_DEV builds only (env RCG_DBG): bits skip parts of k_actor_dma for timing
 };
 
@@ -564,19 +565,16 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
 
   const int envs_here = big ? 1 : (int)((B - wave * A.G) < A.G ? (B - wave * A.G) : A.G);
 
-  // generated grid, MPC / diagonal R1, two inputs, 64 % g == 0: the lane's tiles share their second input and are rolled
-  // out four (two) at a time with the shared sub-trajectory computed once (rollout_mpc_gen_multi)
-  const bool multi_ok = !STREAM && !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 && (64 % A.grid_g) == 0;
+  // generated grid, MPC / diagonal R1, two inputs, 64 % g == 0 (K = g * g in {256, 1024, 4096}: a multiple of four
+  // tiles): the lane's tiles share their second input and are rolled out four at a time with the shared sub-trajectory
+  // computed once (rollout_mpc_gen_multi)
+  const bool multi_ok = !STREAM && !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 &&
+                        (64 % A.grid_g) == 0 && !A.no_multi;
   for (int t = 0; t < A.n_tiles; ++t) {
     if constexpr (!STREAM && !GENERIC && DU == 2 && Sys::SHARED_U1 != 0) {
       if (multi_ok && t + 4 <= A.n_tiles) {
         gen_multi_tiles<Sys, real, TGT, 4>(P, pre, N, K, A.grid_g, t, lane, env_ok, xs, y0, bestJ, bestI, bestU);
         t += 3;
-        continue;
-      }
-      if (multi_ok && t + 2 <= A.n_tiles) {
-        gen_multi_tiles<Sys, real, TGT, 2>(P, pre, N, K, A.grid_g, t, lane, env_ok, xs, y0, bestJ, bestI, bestU);
-        t += 1;
         continue;
       }
     }
@@ -734,6 +732,7 @@ struct TicksArgs {
   int T;                // ticks
   int n_sub;            // RK4 substeps per tick
   int K, Kp, G, n_tiles, grid_g;  // as ActorArgs
+  int no_multi;                   // as ActorArgs
 };
 
 template <typename Sys, typename real, bool GENERIC, bool TGT>
@@ -778,17 +777,13 @@ __global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KP
     real bestU[DU];
 #pragma unroll
     for (int c = 0; c < DU; ++c) bestU[c] = 0;
-    const bool multi_ok = !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 && (64 % A.grid_g) == 0;
+    const bool multi_ok = !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 && (64 % A.grid_g) == 0 &&
+                          !A.no_multi;
     for (int tl = 0; tl < A.n_tiles; ++tl) {  // k_actor, generated candidates
       if constexpr (!GENERIC && DU == 2 && Sys::SHARED_U1 != 0) {
         if (multi_ok && tl + 4 <= A.n_tiles) {
           gen_multi_tiles<Sys, real, TGT, 4>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
           tl += 3;
-          continue;
-        }
-        if (multi_ok && tl + 2 <= A.n_tiles) {
-          gen_multi_tiles<Sys, real, TGT, 2>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
-          tl += 1;
           continue;
         }
       }

@@ -180,7 +180,7 @@ static int op_critic_update(rcg_handle* h, int32_t do_fit) {
 //                           env-state loads - timing only, wrong results; the production library ignores it
 //   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL / SQL on k_actor
 //   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
-//   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor
+//   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor      RCG_NO_GEN_MULTI=1  generated tiles one at a time
 // tests/test_hip_knobs.py checks that the scheduling variants reproduce the default launch bit for bit; bench.py
 // refuses to run with any RCG_* variable set.
 struct DevKnobs {
@@ -194,6 +194,7 @@ struct DevKnobs {
   // slower than 8, 2 blocks/CU 68 % slower (configs[2], SQL, streamed) - the default is no cap.
   long plain_lds = 0;
   bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL and SQL go to k_actor (A/B against the critic instances)
+  bool no_gen_multi = false;  // RCG_NO_GEN_MULTI=1: generated tiles one at a time (no shared sub-trajectory)
 };
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
@@ -207,6 +208,7 @@ static inline const DevKnobs& dev_knobs() {
     if (const char* e = getenv("RCG_PER_CU")) v.per_cu = atoi(e);
     if (const char* e = getenv("RCG_PLAIN_LDS")) v.plain_lds = atol(e);
     v.mpc_only = getenv("RCG_DMA_MPC_ONLY") != nullptr;
+    v.no_gen_multi = getenv("RCG_NO_GEN_MULTI") != nullptr;
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
     return v;
   }();
@@ -255,6 +257,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     A.n_tiles = 1;
   }
   A.grid_g = 0;
+  A.no_multi = dev_knobs().no_gen_multi ? 1 : 0;
   if (!cand) {
     if (DU == 1) {
       A.grid_g = K;
@@ -468,6 +471,7 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
       A.n_tiles = 1;
     }
     A.grid_g = DU == 1 ? K : (int)std::floor(std::sqrt((double)K) + 1e-9);
+    A.no_multi = dev_knobs().no_gen_multi ? 1 : 0;
     const long n_waves = (c.batch + A.G - 1) / A.G;
     const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
     const bool generic = P.stage_kind != 0;

@@ -27,6 +27,19 @@ def main():
     for f in (N.FIELD_STATE, N.FIELD_STATE_PREV, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_STEP_IDX, N.FIELD_BEST_IDX,
               N.FIELD_BEST_J, N.FIELD_STATUS):
         h.update(np.ascontiguousarray(eng.get_field(f)).tobytes())
+    # generated level grid on both robots, K = 256 (four tiles per lane: rolled out together with the shared heading
+    # sub-trajectory unless RCG_NO_GEN_MULTI is set), single ticks and T ticks per launch
+    for name in ("3wrobot", "3wrobotNI"):
+        B3 = 777
+        e3 = Engine(preset_engine_config(name, B3, Nactor=7, gamma=0.97 if name == "3wrobotNI" else 1.0))
+        ds = 5 if name == "3wrobot" else 3
+        e3.set_state(rng.uniform(-3, 3, (B3, ds)).astype(np.float32))
+        for _ in range(3):
+            e3.control_tick(None, K=256)
+        e3.control_ticks(4, 256)
+        for f in (N.FIELD_STATE, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_BEST_IDX, N.FIELD_BEST_J):
+            h.update(np.ascontiguousarray(e3.get_field(f)).tobytes())
+        e3.close()
     print("HASH", h.hexdigest())
 
 

@@ -31,5 +31,6 @@ def test_scheduling_variants_are_bit_identical():
     for knobs in ({"RCG_GPW": "1", "RCG_LDS_PAD": "-1"},     # one env per wave, no residency cap (the first geometry)
                   {"RCG_GPW": "16", "RCG_PER_CU": "4"},
                   {"RCG_GPW": "3", "RCG_PER_CU": "8"},       # envs per wave not a power of two
+                  {"RCG_NO_GEN_MULTI": "1"},                 # generated tiles one at a time: each candidate's cost the same bits
                   {"RCG_DBG": "7"}):                         # timing-only switches: compiled OUT of the production library
         assert _run(knobs) == base, knobs

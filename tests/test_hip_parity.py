@@ -227,9 +227,11 @@ def test_actor_cost_and_argmin_vs_oracle(name, N, K, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_argmin_ties_and_nan(dtype):
-    """Lower index wins ties; NaN costs count as +inf; an all-NaN env returns index 0."""
-    name, N, K, B = "3wrobot", 5, 130, 4
+@pytest.mark.parametrize("K", [130, 128, 256])
+def test_argmin_ties_and_nan(dtype, K):
+    """Lower index wins ties; NaN costs count as +inf; an all-NaN env returns index 0.  K = 130: the generic kernel
+    (ragged last tile); K = 128, 256: the production kernel's DPP (f32) / shuffle (f64) wave argmin."""
+    name, N, B = "3wrobot", 5, 4
     rng = np.random.default_rng(5)
     eng, cfg = both(name, B, dtype, n_actor=N)
     x = rand_states(rng, name, B)
@@ -252,9 +254,10 @@ def test_argmin_ties_and_nan(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name", SYSTEMS)
-@pytest.mark.parametrize("K", [1, 9, 64, 256])
+@pytest.mark.parametrize("K", [1, 9, 64, 256, 1024])
 def test_generated_grid_vs_oracle(name, K, dtype):
-    """cand == NULL: the generated level grid equals oracle.grid_candidates evaluated by the oracle."""
+    """cand == NULL: the generated level grid equals oracle.grid_candidates evaluated by the oracle.  K = 256, 1024 on
+    the robots: four tiles per lane rolled out together with the shared heading sub-trajectory (rollout_mpc_gen_multi)."""
     if PRESETS[name]["sys_id"] != O.SYS_2TANK and int(np.sqrt(K)) ** 2 != K:
         pytest.skip("du = 2 needs a square K")
     rng = np.random.default_rng(77 + K)
