@@ -284,7 +284,8 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     x[c] = xs[c];
     y[c] = y0[c];
   }
-  static_assert(!G1 || (MODE_C == RCG_MODE_MPC && SK_C == 0), "the per-component sum is an MPC / diagonal-R1 variant");
+  static_assert(!G1 || ((MODE_C == RCG_MODE_MPC || MODE_C == RCG_MODE_RQL) && SK_C == 0),
+                "the per-component sum is a variant of the diagonal-R1 stage sums (MPC: all N steps, RQL: the first N - 1)");
   real J = 0, gk = 1;
   real u[DU], up[DU];
   real S[G1 ? NCHI : 1];
@@ -311,9 +312,11 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     }
     real chi[NCHI];
     make_chi<DS, DU, TGT, real>(P, y, u, chi);
-    if (G1) {
+    if (G1 && (MODE_C == RCG_MODE_MPC || kk < N - 1)) {
 #pragma unroll
       for (int i = 0; i < NCHI; ++i) S[G1 ? i : 0] = fma_r(chi[i], chi[i], S[G1 ? i : 0]);
+    } else if (G1) {  // RQL, last step: Q_w(y_{N-1}, u_{N-1}) (controllers.py:1310)
+      J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
     } else if (mode == RCG_MODE_MPC) {
       J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
     } else if (mode == RCG_MODE_RQL) {
@@ -348,6 +351,16 @@ __device__ __forceinline__ real rollout_dispatch(const KParams<real>& P, const t
   }
   if (P.mode == RCG_MODE_MPC) return RCG_ROLL(RCG_MODE_MPC, -1, -1);
   if (P.mode == RCG_MODE_RQL && P.stage_kind == 0) {
+#define RCG_ROLL_G1(C) rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_RQL, 0, C, true>(P, pre, N, xs, y0, urow, ugen, wget, u0)
+    if (P.gamma == (real)1) {  // wave-uniform: per-component stage sums over the first N - 1 steps
+      switch (P.critic_struct) {
+        case RCG_CRITIC_QUAD_LIN: return RCG_ROLL_G1(RCG_CRITIC_QUAD_LIN);
+        case RCG_CRITIC_QUADRATIC: return RCG_ROLL_G1(RCG_CRITIC_QUADRATIC);
+        case RCG_CRITIC_QUAD_NOMIX: return RCG_ROLL_G1(RCG_CRITIC_QUAD_NOMIX);
+        default: return RCG_ROLL_G1(RCG_CRITIC_QUAD_MIX);
+      }
+    }
+#undef RCG_ROLL_G1
     switch (P.critic_struct) {
       case RCG_CRITIC_QUAD_LIN: return RCG_ROLL(RCG_MODE_RQL, 0, RCG_CRITIC_QUAD_LIN);
       case RCG_CRITIC_QUADRATIC: return RCG_ROLL(RCG_MODE_RQL, 0, RCG_CRITIC_QUADRATIC);
