@@ -19,8 +19,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=120,
+                    help="untimed ticks per case: the GPU needs ~20 ms of continuous work to reach its steady clock "
+                         "(tools/clock_ramp.py) and the RQL / SQL buffers ~10 ticks to fill")
     a = ap.parse_args()
     from rcognita_amd import Engine
     from rcognita_amd import _native as N

@@ -29,7 +29,7 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu -
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu_pool -o v -- \
   python3 tools/valu_probe.py pool > gpurun_out/valu_units_pool.json 2> gpurun_out/prof_valu_pool.log
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_configs -o kt -- \
-  python3 tools/bench_configs.py --steps 30 > "gpurun_out/bench_configs_${ROUND}_profiled.json" 2> gpurun_out/prof_kt_configs.log
-python tools/bench_configs.py --steps 30 > "gpurun_out/bench_configs_${ROUND}.json" 2> gpurun_out/bench_configs.err
+  python3 tools/bench_configs.py > "gpurun_out/bench_configs_${ROUND}_profiled.json" 2> gpurun_out/prof_kt_configs.log
+python tools/bench_configs.py > "gpurun_out/bench_configs_${ROUND}.json" 2> gpurun_out/bench_configs.err
 ls gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_valu gpurun_out/prof_kt_configs
 head -c 600 "gpurun_out/bench_${ROUND}.json"
