@@ -585,6 +585,30 @@ def main(argv=None):
         "returns_summary": total,
     }
 
+    if not streamed:
+        # the generated-candidate regime is bound by VALU instruction issue, not by HBM: price it in lane-instructions/s
+        #  with the instruction counts of the stored SQ_INSTS_VALU pass
+        lane_instr, missing = 0.0, False
+        for e in engines:
+            name = {N.SYS_3WROBOT: "3wrobot", N.SYS_3WROBOT_NI: "3wrobotNI", N.SYS_2TANK: "2tank"}[int(e.cfg.sys_id)]
+            key = (f"k_actor_generated_{name}_N{Nh}_{args.dtype}_C5" if args.config == "C5"
+                   else f"k_actor_generated_{name}_N{Nh}_{args.dtype}")
+            ipe = valu_instr_per_eval(key)
+            if not ipe:
+                missing = True
+                break
+            lane_instr += e.B * K * ipe["valu_instr_per_eval"]
+        hbm = dict(out["roofline"])
+        if not missing and actor_avg_s > 0:
+            out["roofline"] = {"bound": "valu", "kernel": "k_actor (generated level grid)",
+                               "achieved": lane_instr / actor_avg_s, "peak": VALU_PEAK, "unit": "lane-instr/s",
+                               "frac": lane_instr / actor_avg_s / VALU_PEAK, "traffic": None,
+                               "lane_instructions_per_tick": lane_instr, "avg_actor_ms_per_tick": actor_avg_s * 1e3,
+                               "source": "profiles/valu_instr.json (rocprofv3 --pmc SQ_INSTS_VALU pass, stored) x this "
+                                         "run's kernel time; peak = 157.3 TFLOP/s FMA / 2 (assumes packed f32 issue: the "
+                                         "4-cycle wave64 issue model tops out at 3.9e13)",
+                               "hbm_frac_for_completeness": hbm["frac"]}
+
     if not args.no_parity and args.config != "C5":
         out["parity"] = parity_check(args, local_rank, stream_ptr, x0, cand, K)
 

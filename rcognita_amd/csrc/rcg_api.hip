@@ -519,10 +519,10 @@ int rcg_critic_update(rcg_handle* h, int32_t do_fit) {
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_critic_update: the native critic fit needs Ncritic-1 <= %d (got %d)",
                     kFitMaxRows, m);
   if (do_fit && m < 1) {  // empty TD stack: push only, the weights stay at the (clipped) initial guess
-    const int rc = h->sys->critic_update(h, 0);
+    const int rc = h->sys->critic_update(h, 0, 1, 0);
     return rc ? rc : critic_keep_init(h);
   }
-  return h->sys->critic_update(h, do_fit);
+  return h->sys->critic_update(h, 0, 1, do_fit ? 1 : 0);
 }
 
 // Argument checks of the decision step, made BEFORE the tick mutates anything (env step, buffer push): a refused
@@ -549,13 +549,19 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
     if (h->cfg.n_critic - 1 > kFitMaxRows)
       return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick: the native critic fit needs Ncritic-1 <= %d (got %d)",
                       kFitMaxRows, h->cfg.n_critic - 1);
-    rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
-    if (rc) return rc;
     // critic_period = critic_every_ticks * sampling_time.  The reference starts critic_clock at t0 and refits when
     // t - critic_clock >= critic_period (controllers.py:1458-1471); tick j of an episode happens at t0 + (j+1)*dt, so
     // the fits fall on ticks every-1, 2*every-1, ...
     const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
-    rc = rcg_critic_update(h, ((h->tick_count + 1) % every) == 0 ? 1 : 0);
+    const bool do_fit = ((h->tick_count + 1) % every) == 0;
+    const int m = h->cfg.n_critic - 1;
+    if ((h->cfg.flags & RCG_FLAG_DISTURB) || (do_fit && m < 1)) {  // the disturbed env step has its own kernel
+      rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
+      if (rc) return rc;
+      rc = rcg_critic_update(h, do_fit ? 1 : 0);
+    } else {  // env step + buffer push + fit: one launch (rcg_critic_fit.hpp)
+      rc = h->sys->critic_update(h, h->cfg.substeps_per_tick, 1, do_fit ? 1 : 0);
+    }
     if (rc) return rc;
     sim_first = false;
   }

@@ -77,18 +77,68 @@ template <typename real>
 struct FitArgs {
   real* w_critic;         // [dc][B] out
   real* w_prev;           // [dc][B] in (TD target weights), out (:= fitted w)
-  const real* obs_buf;    // [buffer_size][dy][B]
-  const real* act_buf;    // [buffer_size][du][B]
+  real* obs_buf;          // [buffer_size][dy][B]
+  real* act_buf;          // [buffer_size][du][B]
   const double* wcfg;     // [3][40]: w_init, w_min, w_max
+  // Everything an RQL / SQL tick does between two decisions is lane == env work on the same few numbers, so
+  // rcg_control_tick issues it as ONE launch (three dependent launches cost ~7 us of dispatch gap each at this size,
+  // plus the former push kernel's own 11 us): do_sim: Simulator.sim_step (env_substeps, the code k_sim runs); do_push:
+  // push_vec of (action_curr, obs) (utilities.py:78-79); do_fit: the fit.  Same arithmetic as the separate launches.
+  int do_sim, do_push, do_fit;
+  SimArgs<real> sim;      // do_sim
+  const real* state;      // [ds][B] do_push: the observation to push (= sim.state)
+  const real* action;     // [du][B] do_push: the held action (action_curr)
 };
 
 template <typename Sys, typename real, int CS, int MAXM>
-__global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const KParams<double> P) {
+__global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, DC = CriticDim<CS, DS, DU>::value;
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long B = P.B;
   if (b >= B) return;
   const int m = P.n_critic - 1;  // rows of the TD stack, 1 <= m <= MAXM (checked on the host)
+
+  if (F.do_sim || F.do_push) {
+    real xs[DS], xp[DS], ua[DU];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) xp[c] = xs[c] = F.state[(long)c * B + b];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) ua[c] = F.action[(long)c * B + b];
+    if (F.do_sim) {  // k_sim
+      uint32_t st = F.sim.status[b];
+      if (!(st & 1u)) {
+        const auto pre = load_pre<Sys, real>(Pr, F.sim.pars_env, b);
+        real accum = Pr.accum_every_substep ? F.sim.accum[b] : (real)0;
+        const bool tgt = Pr.has_target != 0;
+        const bool ok = tgt ? env_substeps<Sys, real, true>(Pr, pre, F.sim.n_sub, xs, xp, ua, st, accum)
+                            : env_substeps<Sys, real, false>(Pr, pre, F.sim.n_sub, xs, xp, ua, st, accum);
+        if (!ok) {
+          F.sim.status[b] = st;  // became non-finite: frozen at its last finite state
+        } else {
+#pragma unroll
+          for (int c = 0; c < DS; ++c) {
+            F.sim.state[(long)c * B + b] = xs[c];
+            F.sim.state_prev[(long)c * B + b] = xp[c];
+          }
+          if (Pr.accum_every_substep) F.sim.accum[b] = accum;
+        }
+      }
+    }
+    if (F.do_push) {  // push_vec on both buffers: drop row 0, append (obs, action_curr) at the bottom (utilities.py:78-79)
+      const int bs = Pr.buffer_size;
+      for (int r = 0; r < bs - 1; ++r) {
+#pragma unroll
+        for (int c = 0; c < DS; ++c) F.obs_buf[((long)r * DS + c) * B + b] = F.obs_buf[((long)(r + 1) * DS + c) * B + b];
+#pragma unroll
+        for (int c = 0; c < DU; ++c) F.act_buf[((long)r * DU + c) * B + b] = F.act_buf[((long)(r + 1) * DU + c) * B + b];
+      }
+#pragma unroll
+      for (int c = 0; c < DS; ++c) F.obs_buf[((long)(bs - 1) * DS + c) * B + b] = xs[c];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) F.act_buf[((long)(bs - 1) * DU + c) * B + b] = ua[c];
+    }
+    if (!F.do_fit) return;
+  }
 
   double A[MAXM][DC], bv[MAXM], wp[DC], w0[DC], lo[DC], hi[DC];
 #pragma unroll

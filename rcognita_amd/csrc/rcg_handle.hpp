@@ -110,7 +110,8 @@ struct SysVTable {
   int (*actor)(rcg_handle*, const char* who, const void* cand, int K, const void* obs, const void* state_sys,
                const void* w, void* J, void* action, void* best_J, int32_t* best_idx, bool tick, bool sim_first);
   int (*sim_step)(rcg_handle*, int32_t n_substeps);
-  int (*critic_update)(rcg_handle*, int32_t do_fit);
+  // RQL / SQL bookkeeping between two decisions in ONE launch: [sim_step x n_substeps] -> [push] -> [fit]
+  int (*critic_update)(rcg_handle*, int32_t n_substeps /* 0: no env step */, int32_t do_push, int32_t do_fit);
   int (*optimize)(rcg_handle*, int32_t iters, const void* obs, const void* state_sys, const void* u_init, int shift,
                   void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick);
   int (*nominal)(rcg_handle*, const void* obs, void* action, void* lyap, int32_t n, double gain, const double* ctrl_pars,

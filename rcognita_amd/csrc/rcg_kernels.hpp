@@ -14,7 +14,7 @@
 //   k_sim     closed_loop_rhs + fixed-step RK4, lane == env.
 //   k_rhs / k_stage_obj / k_critic / k_critic_cost   the reference's operators, lane == point,
 //             for unit parity.
-//   k_critic_push, k_episode_reset, k_stats          bookkeeping.
+//   k_episode_reset, k_stats                         bookkeeping (push_vec of the critic buffers: rcg_critic_fit.hpp).
 #pragma once
 #include <stdint.h>
 
@@ -931,26 +931,6 @@ __global__ void k_critic_cost(const real* w, const real* w_prev, const real* obs
     acc += (real)0.5 * e * e;
   }
   Jc[b] = acc;
-}
-
-// push_vec (utilities.py:78-79) on both buffers: drop row 0, append (obs, action) at the bottom
-template <typename Sys, typename real>
-__global__ void k_critic_push(real* obs_buf, real* act_buf, const real* obs, const real* action, const KParams<real> P) {
-  constexpr int DS = Sys::DS, DU = Sys::DU;
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long B = P.B;
-  if (b >= B) return;
-  const int bs = P.buffer_size;
-  for (int r = 0; r < bs - 1; ++r) {
-#pragma unroll
-    for (int c = 0; c < DS; ++c) obs_buf[((long)r * DS + c) * B + b] = obs_buf[((long)(r + 1) * DS + c) * B + b];
-#pragma unroll
-    for (int c = 0; c < DU; ++c) act_buf[((long)r * DU + c) * B + b] = act_buf[((long)(r + 1) * DU + c) * B + b];
-  }
-#pragma unroll
-  for (int c = 0; c < DS; ++c) obs_buf[((long)(bs - 1) * DS + c) * B + b] = obs[(long)c * B + b];
-#pragma unroll
-  for (int c = 0; c < DU; ++c) act_buf[((long)(bs - 1) * DU + c) * B + b] = action[(long)c * B + b];
 }
 
 template <typename real>

@@ -137,37 +137,46 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
 }
 
 template <typename Sys>
-static int op_critic_update(rcg_handle* h, int32_t do_fit) {
+static int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t do_fit) {
   const int m = h->cfg.n_critic - 1;
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
     ProfScope prof_scope(h, RCG_KERNEL_CRITIC);
-    hipLaunchKernelGGL((k_critic_push<Sys, real>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream,
-                       (real*)h->f[RCG_FIELD_OBS_BUF], (real*)h->f[RCG_FIELD_ACT_BUF],
-                       (const real*)h->f[RCG_FIELD_STATE], (const real*)h->f[RCG_FIELD_ACTION], params<real>(h));
-    if (do_fit) {
-      FitArgs<real> F;
-      F.w_critic = (real*)h->f[RCG_FIELD_W_CRITIC];
-      F.w_prev = (real*)h->f[RCG_FIELD_W_PREV];
-      F.obs_buf = (const real*)h->f[RCG_FIELD_OBS_BUF];
-      F.act_buf = (const real*)h->f[RCG_FIELD_ACT_BUF];
-      F.wcfg = reinterpret_cast<const double*>((unsigned char*)h->d_const + kConstW);
-      const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
-#define RCG_FIT(CS)                                                                                         \
-  do {                                                                                                      \
-    if (m <= 3)                                                                                             \
-      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, 3>), grid, block, 0, h->stream, F, h->p64);           \
-    else                                                                                                    \
-      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, h->stream, F, h->p64); \
+    FitArgs<real> F;
+    memset(&F, 0, sizeof F);
+    F.w_critic = (real*)h->f[RCG_FIELD_W_CRITIC];
+    F.w_prev = (real*)h->f[RCG_FIELD_W_PREV];
+    F.obs_buf = (real*)h->f[RCG_FIELD_OBS_BUF];
+    F.act_buf = (real*)h->f[RCG_FIELD_ACT_BUF];
+    F.wcfg = reinterpret_cast<const double*>((unsigned char*)h->d_const + kConstW);
+    F.do_sim = n_substeps > 0;
+    F.do_push = do_push;
+    F.do_fit = do_fit;
+    F.state = (const real*)h->f[RCG_FIELD_STATE];
+    F.action = (const real*)h->f[RCG_FIELD_ACTION];
+    F.sim.state = (real*)h->f[RCG_FIELD_STATE];
+    F.sim.state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
+    F.sim.action = (const real*)h->f[RCG_FIELD_ACTION];
+    F.sim.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    F.sim.accum = (real*)h->f[RCG_FIELD_ACCUM];
+    F.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+    F.sim.n_sub = n_substeps;
+    const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
+#define RCG_FIT(CS)                                                                                                    \
+  do {                                                                                                                 \
+    if (m <= 3)                                                                                                        \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, 3>), grid, block, 0, h->stream, F, h->p64, params<real>(h));     \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, h->stream, F, h->p64,             \
+                         params<real>(h));                                                                             \
   } while (0)
-      switch (h->cfg.critic_struct) {
-        case RCG_CRITIC_QUAD_LIN: RCG_FIT(RCG_CRITIC_QUAD_LIN); break;
-        case RCG_CRITIC_QUADRATIC: RCG_FIT(RCG_CRITIC_QUADRATIC); break;
-        case RCG_CRITIC_QUAD_NOMIX: RCG_FIT(RCG_CRITIC_QUAD_NOMIX); break;
-        default: RCG_FIT(RCG_CRITIC_QUAD_MIX); break;
-      }
-#undef RCG_FIT
+    switch (h->cfg.critic_struct) {
+      case RCG_CRITIC_QUAD_LIN: RCG_FIT(RCG_CRITIC_QUAD_LIN); break;
+      case RCG_CRITIC_QUADRATIC: RCG_FIT(RCG_CRITIC_QUADRATIC); break;
+      case RCG_CRITIC_QUAD_NOMIX: RCG_FIT(RCG_CRITIC_QUAD_NOMIX); break;
+      default: RCG_FIT(RCG_CRITIC_QUAD_MIX); break;
     }
+#undef RCG_FIT
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });

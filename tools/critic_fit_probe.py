@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Steady-state cost of the critic fit (k_critic_push + k_critic_fit) on the configs[2] shape: RQL closed loop,
+"""Steady-state cost of the critic fit (env step + buffer push + fit: one launch of k_critic_fit) on the configs[2] shape: RQL closed loop,
 per-tick HIP-event time of the critic update after the buffers have filled."""
 import os
 import sys

@@ -155,8 +155,20 @@ def valu_summary(a):
     # instructions per evaluation for the generated-grid rollout of the bench workload (k_actor, Sys3WRobot, f32, GENERIC=0)
     vi = os.path.join(ROOT, "profiles", "valu_instr.json")
     t = json.load(open(vi)) if os.path.exists(vi) else {}
+    # the mixed pool of configs[4] (valu_probe.py pool): one generated-grid kernel per system type, K = 256, N = 15
+    for sysname, tgt in (("Sys3WRobot", "false"), ("Sys3WRobotNI", "false"), ("Sys2Tank", "true")):
+        key = {"Sys3WRobot": "3wrobot", "Sys3WRobotNI": "3wrobotNI", "Sys2Tank": "2tank"}[sysname]
+        uu = units.get(f"k_actor_generated_{key}_N15_f32_C5")
+        hh = [(k, d) for k, d in per.items() if k.startswith(f"rcg::k_actor<rcg::{sysname}, float, false, {tgt}, false>")]
+        if uu and hh:
+            k, d = hh[0]
+            t[f"k_actor_generated_{key}_N15_f32_C5"] = {
+                "valu_instr_per_eval": d["SQ_INSTS_VALU_per_launch"] * 64 / uu["evals"], "round": a.round, "kernel": k,
+                "launches": d["launches"]}
     hit = [(k, d) for k, d in per.items() if k.startswith("rcg::k_actor<rcg::Sys3WRobot, float, false, false, false>")]
     u = units.get("k_actor_generated_3wrobot_N10_f32")
+    if t:
+        json.dump(t, open(vi, "w"), indent=1, sort_keys=True)
     if hit and u:
         k, d = hit[0]
         # the probe launches this instance for the C2 shape AND (N = 15) for the mixed pool: use the per-wave figure of
