@@ -150,6 +150,49 @@ __device__ __forceinline__ real critic_with(const real* chi, const real* y, cons
   }
   return acc;
 }
+// SQL sums the critic over the horizon, J = sum_k w . phi(chi_k) = w . sum_k phi(chi_k): the regressor is accumulated
+// per feature (one fma per feature and step) and dotted with the weights once, instead of a product AND an fma per
+// feature at every step.  Feature order = critic_with's.  `cs` must be a compile-time constant at the call site.
+template <int DS, int DU>
+__host__ __device__ constexpr int critic_dim(int cs) {
+  return cs == RCG_CRITIC_QUAD_LIN ? (DS + DU) * (DS + DU + 1) / 2 + (DS + DU)
+                                   : (cs == RCG_CRITIC_QUADRATIC ? (DS + DU) * (DS + DU + 1) / 2
+                                                                 : (cs == RCG_CRITIC_QUAD_NOMIX ? DS + DU : DS + DS * DU + DU));
+}
+template <int DS, int DU, typename real>
+__device__ __forceinline__ void critic_phi_accum(const real* chi, const real* y, const real* u, real* Phi, const int cs) {
+  constexpr int NCHI = DS + DU;
+  if (cs == RCG_CRITIC_QUAD_LIN || cs == RCG_CRITIC_QUADRATIC) {
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i)
+#pragma unroll
+      for (int j = i; j < NCHI; ++j) {
+        Phi[idx] = fma_r(chi[i], chi[j], Phi[idx]);
+        ++idx;
+      }
+    if (cs == RCG_CRITIC_QUAD_LIN) {
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) {
+        Phi[idx] += chi[i];
+        ++idx;
+      }
+    }
+  } else if (cs == RCG_CRITIC_QUAD_NOMIX) {
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) Phi[i] = fma_r(chi[i], chi[i], Phi[i]);
+  } else {  // quad-mix: [obs**2, kron(obs, act), act**2] on the RAW observation (controllers.py:1212)
+#pragma unroll
+    for (int i = 0; i < DS; ++i) Phi[i] = fma_r(y[i], y[i], Phi[i]);
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+#pragma unroll
+      for (int c = 0; c < DU; ++c) Phi[DS + i * DU + c] = fma_r(y[i], u[c], Phi[DS + i * DU + c]);
+#pragma unroll
+    for (int c = 0; c < DU; ++c) Phi[DS + DS * DU + c] = fma_r(u[c], u[c], Phi[DS + DS * DU + c]);
+  }
+}
+
 template <int DS, int DU, typename real, typename WGet>
 __device__ __forceinline__ real critic_value(const KParams<real>& P, const real* chi, const real* y,
                                              const real* u, WGet w) {
@@ -291,6 +334,11 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
   real S[G1 ? NCHI : 1];
 #pragma unroll
   for (int i = 0; i < (G1 ? NCHI : 1); ++i) S[i] = 0;
+  constexpr bool SUMF = MODE_C == RCG_MODE_SQL && CS_C >= 0;  // SQL: per-feature sums (critic_phi_accum)
+  constexpr int NPHI = SUMF ? critic_dim<DS, DU>(CS_C >= 0 ? CS_C : 0) : 1;
+  real Phi[NPHI];
+#pragma unroll
+  for (int i = 0; i < NPHI; ++i) Phi[i] = 0;
 #pragma unroll
   for (int c = 0; c < DU; ++c) up[c] = 0;
   for (int kk = 0; kk < N; ++kk) {
@@ -324,6 +372,8 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
         J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
       else
         J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
+    } else if (SUMF) {  // SQL, compile-time structure
+      critic_phi_accum<DS, DU, real>(chi, y, u, Phi, CS_C);
     } else {  // SQL
       J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
     }
@@ -334,6 +384,10 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
   if (G1) {
 #pragma unroll
     for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[G1 ? i : 0], J);
+  }
+  if (SUMF) {
+#pragma unroll
+    for (int i = 0; i < NPHI; ++i) J = fma_r(wget(i), Phi[i], J);
   }
   return J;
 }
