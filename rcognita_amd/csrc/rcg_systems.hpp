@@ -37,11 +37,11 @@ struct Sys3WRobot {
     d[4] = q.inv_I * u[1];  // 1/I * action[1]
   }
   // (A^T lam, B^T lam), A = d f/d x, B = d f/d u at (x, u): the adjoint sweep of k_actor_opt
-  template <typename real>
+  template <typename real, bool HW = false>
   __device__ __forceinline__ static void jac_T(const Pre<real>& q, const real* x, const real*, const real* lam,
                                                real* ax, real* bu) {
     real s, c;
-    sincos_r<real>(x[2], &s, &c);
+    sincos_sel<real, HW>(x[2], &s, &c);
     ax[0] = 0;
     ax[1] = 0;
     ax[2] = x[3] * (lam[1] * c - lam[0] * s);
@@ -71,11 +71,11 @@ struct Sys3WRobotNI {
     d[1] = u[0] * s;
     d[2] = u[1];
   }
-  template <typename real>
+  template <typename real, bool HW = false>
   __device__ __forceinline__ static void jac_T(const Pre<real>&, const real* x, const real* u, const real* lam,
                                                real* ax, real* bu) {
     real s, c;
-    sincos_r<real>(x[2], &s, &c);
+    sincos_sel<real, HW>(x[2], &s, &c);
     ax[0] = 0;
     ax[1] = 0;
     ax[2] = u[0] * (lam[1] * c - lam[0] * s);
@@ -102,7 +102,7 @@ struct Sys2Tank {
     d[0] = q.inv_tau1 * (-x[0] + q.K1 * u[0]);
     d[1] = q.inv_tau2 * (-x[1] + q.K2 * x[0] + q.K3 * (x[1] * x[1]));
   }
-  template <typename real>
+  template <typename real, bool HW = false>
   __device__ __forceinline__ static void jac_T(const Pre<real>& q, const real* x, const real*, const real* lam,
                                                real* ax, real* bu) {
     ax[0] = -lam[0] * q.inv_tau1 + lam[1] * q.inv_tau2 * q.K2;
