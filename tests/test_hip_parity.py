@@ -489,3 +489,39 @@ def test_full_size_C2_properties():
     eng.control_tick(dcand)
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.ones(B, np.int32))
     assert np.all(np.isfinite(eng.get_state()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,N", [("3wrobot", 32), ("2tank", 64), ("3wrobotNI", 1), ("2tank", 1)])
+def test_horizon_limits(name, N, dtype):
+    """Size edges of the candidate row: the longest horizon the ABI takes (N * du = RCG_MAX_ROW = 64 reals per row:
+    Nactor = 32 for the robots, 64 for the tanks) and the shortest (Nactor = 1: no rollout at all, J = rho(y_0, u_0));
+    streamed (K = 64 and a ragged K = 7) and generated candidates against the oracle; one step beyond is refused."""
+    from rcognita_amd import Engine, _native as Nn
+    from tests.helpers import engine_cfg
+
+    rng = np.random.default_rng(N)
+    B = 6
+    eng, cfg = both(name, B, dtype, n_actor=N, gamma=0.9)
+    x = rand_states(rng, name, B).astype(eng.real)
+    eng.set_state(x)
+    x64 = x.astype(np.float64)
+    for K in (64, 7):
+        cand = rand_actions(rng, name, (B, K, N)).astype(eng.real)
+        J = eng.actor_cost(cand)
+        J_or = O.actor_cost(cand.astype(np.float64), x64[:, None, :], x64[:, None, :], cfg)
+        scale = np.maximum(np.max(np.abs(J_or), axis=1, keepdims=True), 1.0)
+        assert np.max(np.abs(J - J_or) / scale) <= TOL[dtype], (name, N, K)
+        a, bj, bi = eng.actor_argmin(cand)
+        ref = np.argmin(J_or, axis=1)
+        for e in range(B):
+            assert bi[e] == ref[e] or abs(J_or[e, bi[e]] - J_or[e, ref[e]]) <= 4 * TOL[dtype] * scale[e, 0]
+    Kg = 64 if cfg.du == 2 else 50
+    a, bj, bi = eng.actor_argmin(None, K=Kg)
+    grid = O.grid_candidates(cfg, Kg)
+    Jg = O.actor_cost(grid[None], x64[:, None, :], x64[:, None, :], cfg)
+    _close(bj, np.min(Jg, axis=1), dtype, msg="generated best_J")
+    if N > 1:
+        with pytest.raises(Nn.NativeError) as ei:
+            Engine(engine_cfg(name, B, dtype, n_actor=N + 1))
+        assert ei.value.code == Nn.ERR_BAD_ARG and "Nactor" in str(ei.value)
