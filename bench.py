@@ -409,7 +409,8 @@ def main(argv=None):
         pool = MixedPool(counts, rank=rank, world=world, device=local_rank, dtype=args.dtype, Nactor=Nh)
         rng = np.random.default_rng(1234 + rank)
         pool.set_states({s.name: pool_states(rng, s.name, s.hi - s.lo) for s in pool.segments})
-        pool.set_streams([stream_ptr] * len(pool.segments))
+        # (the three homogeneous segments are independent: MixedPool gives each handle a HIP stream of its own, so the
+        # tail of one segment's kernel overlaps the head of the next - each is a short launch of ~5 500 waves)
         engines = [s.engine for s in pool.segments]
         B = pool.n_envs
         tick = lambda: pool.control_tick(K)
@@ -465,6 +466,8 @@ def main(argv=None):
         for e in engines:
             N.check(N.lib().rcg_get_field(e._h, N.FIELD_ACCUM, returns_dev[off:].data_ptr(), N.DEVICE), e._h)
             off += e.B
+        if pool is not None:  # the segments' copies ran on their own streams: finish them before the collective reads
+            pool.synchronize()
         dist.all_gather(gathered, returns_dev if coll_dev.type == "cuda" else returns_dev.cpu())
 
     if dist is not None:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 111 /* 0.1.1 + checkpoint counter */
+#define RCG_VERSION 112 /* 0.1.1 + checkpoint counter, own stream */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -163,6 +163,9 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out);
 int rcg_destroy(rcg_handle* h);
 /* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
 int rcg_set_stream(rcg_handle* h, void* hip_stream);
+/* Give the handle a non-blocking HIP stream of its own (created here, destroyed by rcg_destroy) and switch to it: for
+ * callers without a stream library that drive several independent handles - the segments of a mixed pool - side by side. */
+int rcg_use_own_stream(rcg_handle* h);
 int rcg_synchronize(rcg_handle* h);
 
 /* Device-memory helpers so that a host language without a GPU array library can drive the ABI. */

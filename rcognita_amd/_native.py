@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCG_LIB") or os.path.join(_HERE, "lib", "librcg.so")
 
 # ---- enums (include/rcg.h) -------------------------------------------------------------------
-RCG_VERSION = 111
+RCG_VERSION = 112
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
 SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
 MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
@@ -41,7 +41,7 @@ SYS_DIMS = {SYS_3WROBOT: (5, 2, 2), SYS_3WROBOT_NI: (3, 2, 0), SYS_2TANK: (2, 1,
 
 # every symbol include/rcg.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "rcg_version", "rcg_last_error", "rcg_device_count", "rcg_create", "rcg_destroy", "rcg_set_stream",
+    "rcg_version", "rcg_last_error", "rcg_device_count", "rcg_create", "rcg_destroy", "rcg_set_stream", "rcg_use_own_stream",
     "rcg_synchronize", "rcg_dev_alloc", "rcg_dev_free", "rcg_memcpy_h2d", "rcg_memcpy_d2h", "rcg_set_field",
     "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
@@ -108,6 +108,7 @@ def lib():
         "rcg_create": (C.c_int, [C.POINTER(RcgCfg), C.POINTER(vp)]),
         "rcg_destroy": (C.c_int, [vp]),
         "rcg_set_stream": (C.c_int, [vp, vp]),
+        "rcg_use_own_stream": (C.c_int, [vp]),
         "rcg_synchronize": (C.c_int, [vp]),
         "rcg_dev_alloc": (C.c_int, [vp, u64, C.POINTER(vp)]),
         "rcg_dev_free": (C.c_int, [vp, vp]),

@@ -191,6 +191,7 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->dc = dim_critic(cfg->critic_struct, ds, du);
   h->esz = cfg->dtype == RCG_F64 ? 8 : 4;
   h->stream = nullptr;
+  h->own_stream = nullptr;
   h->d_summary = nullptr;
   h->d_const = nullptr;
   h->prof_mask = 0;
@@ -310,6 +311,7 @@ int rcg_destroy(rcg_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   for (int i = 0; i < RCG_FIELD_COUNT_; ++i)
     if (h->f[i]) (void)hipFree(h->f[i]);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   if (h->d_summary) (void)hipFree(h->d_summary);
   if (h->d_const) (void)hipFree(h->d_const);
   for (auto& p : h->ev_pending) {
@@ -331,6 +333,13 @@ int rcg_set_stream(rcg_handle* h, void* hip_stream) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->stream = (hipStream_t)hip_stream;
   return RCG_OK;
+}
+
+int rcg_use_own_stream(rcg_handle* h) {
+  DeviceGuard dev_guard(h);
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  return rcg_set_stream(h, (void*)h->own_stream);
 }
 
 int rcg_synchronize(rcg_handle* h) {

@@ -17,6 +17,7 @@ struct rcg_handle {
   int ds, du, np, dc, nchi;
   size_t esz;  // sizeof(real)
   hipStream_t stream;
+  hipStream_t own_stream;  // created by rcg_use_own_stream, destroyed with the handle (nullptr: none)
   void* f[RCG_FIELD_COUNT_];
   size_t fbytes[RCG_FIELD_COUNT_];
   double* d_summary;

@@ -221,6 +221,10 @@ class Engine:
     def set_stream(self, stream_ptr: Optional[int]):
         N.check(N.lib().rcg_set_stream(self._h, C.c_void_p(stream_ptr or 0)), self._h)
 
+    def use_own_stream(self):
+        """A non-blocking HIP stream owned by the handle (rcg_use_own_stream)."""
+        N.check(N.lib().rcg_use_own_stream(self._h), self._h)
+
     def synchronize(self):
         N.check(N.lib().rcg_synchronize(self._h), self._h)
 

@@ -4,8 +4,9 @@
 Environments never interact, and a wave must not mix system types (the dynamics are compile-time
 policies of the kernels), so the pool sorts its envs by type into homogeneous *segments*, one
 :class:`~rcognita_amd.engine.Engine` per segment.  A pool tick issues one ``rcg_control_tick`` per
-segment; the segments run on separate HIP streams when the caller provides them, since nothing orders
-them.  Episode statistics are merged exactly as across GPUs (:func:`rcognita_amd.parallel.merge_summaries`).
+segment; nothing orders the segments, so each handle runs on a non-blocking HIP stream of its own
+(``rcg_use_own_stream``; measured on the configs[4] shard: 6.7e8 -> 8.0e8 env.control-steps/s) unless the caller
+installs streams (``set_streams``) or passes ``own_streams=False``.  Episode statistics are merged exactly as across GPUs (:func:`rcognita_amd.parallel.merge_summaries`).
 Across ranks the pool is sharded *within each type* (:func:`rcognita_amd.parallel.shard_by_type`) so every
 rank sees the same mix.
 """
@@ -58,7 +59,7 @@ class MixedPool:
     shard ``shard_by_type(counts, rank, world)`` of every type."""
 
     def __init__(self, counts: Dict[str, int], rank: int = 0, world: int = 1, device: int = 0, dtype: str = "f32",
-                 Nactor: int = 15, mode: str = "MPC", **over):
+                 Nactor: int = 15, mode: str = "MPC", own_streams: bool = True, **over):
         self.counts = dict(counts)
         self.segments: List[Segment] = []
         spans = shard_by_type(counts, rank, world)
@@ -69,6 +70,8 @@ class MixedPool:
                 continue
             eng = Engine(preset_engine_config(name, hi - lo, device=device, dtype=dtype, Nactor=Nactor, mode=mode,
                                               buffer_size=buffer_size, **over))
+            if own_streams:  # nothing orders the segments: their (short) launches overlap on streams of their own
+                eng.use_own_stream()
             self.segments.append(Segment(name, eng, lo, hi))
 
     @property

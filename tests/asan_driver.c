@@ -140,6 +140,7 @@ static void abi_host_side(void) {
   EXPECT(rcg_destroy(NULL) == RCG_OK);
   EXPECT(rcg_set_stream(NULL, NULL) < 0);
   EXPECT(rcg_synchronize(NULL) < 0);
+  EXPECT(rcg_use_own_stream(NULL) < 0);
   EXPECT(rcg_dev_alloc(NULL, 16, &p) < 0);
   EXPECT(rcg_dev_free(NULL, NULL) < 0);
   EXPECT(rcg_memcpy_h2d(NULL, x, x, 8) < 0);
