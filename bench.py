@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6.29e12 measured copy)
 VALU_PEAK = 7.9e13  # f32 lane-instructions/s: 256 CUs x 4 SIMDs x 32 lanes/clk... = 157.3 TFLOP/s FMA / 2
 PRESPIN_S = 0.35    # untimed clock pre-spin: the first launches after the GPU wakes run 10-25 % slower
+PRESPIN_MAX_S = 3.0
 C4_TOTAL_ENVS = 524288
 
 
@@ -438,17 +439,23 @@ def main(argv=None):
     # ago, and the warm-up and the timed region follow without a gap.
     prespin = 0
     t_spin = time.perf_counter()
-    evs = []
+    evs, chunk_ms = [], []
     while True:
         for _ in range(32):
             tick()
         prespin += 32
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         evs.append(ev)
-        if len(evs) >= 3:
-            evs[-3].synchronize()
-            if time.perf_counter() - t_spin >= PRESPIN_S:
+        if len(evs) >= 4:
+            evs[-3].synchronize()  # two chunks stay queued behind it: the GPU never runs dry
+            chunk_ms.append(evs[-4].elapsed_time(evs[-3]))
+            spun = time.perf_counter() - t_spin
+            # steady = the last four chunks within 1.5 % of each other (a box that has just been handed over can need
+            # longer than a warm one); never less than PRESPIN_S, never more than PRESPIN_MAX_S
+            last = chunk_ms[-4:]
+            steady = len(last) == 4 and (max(last) - min(last)) <= 0.015 * min(last)
+            if (spun >= PRESPIN_S and steady) or spun >= PRESPIN_MAX_S:
                 break
     for _ in range(args.warmup):
         tick()
@@ -481,8 +488,8 @@ def main(argv=None):
     if args.profile_stride > 0:
         if args.steps // args.profile_stride < 3:
             args.profile_stride = max(1, args.steps // 3)
-        for e in engines:
-            e.profile((N.KERNEL_ACTOR,), stride=args.profile_stride)
+        for e in engines:  # (the first launch after the barrier starts on an idle GPU: sampling starts mid-stride)
+            e.profile((N.KERNEL_ACTOR,), stride=args.profile_stride, skip=args.profile_stride // 2)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -573,7 +580,8 @@ def main(argv=None):
         "data": "synthetic",
         "config": {"workload": workload, "config": args.config, "envs_total": total_envs, "envs_rank0": B,
                    "candidates": K, "nactor": Nh, "regime": args.regime, "parallelism": f"env-shard x{world}",
-                   "actor_cost_evals_per_s": value * K, "prespin_ticks_untimed": prespin},
+                   "actor_cost_evals_per_s": value * K, "prespin_ticks_untimed": prespin,
+                   "prespin_last_chunks_ms_per_tick": [round(c / 32, 5) for c in chunk_ms[-4:]]},
         "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
         "dist_backend": (args.dist_backend if dist is not None else None),
         "launcher": launcher,

@@ -287,8 +287,9 @@ int rcg_set_tick_count(rcg_handle* h, int64_t ticks);
 /* ---- measurement ---------------------------------------------------------------------------- */
 typedef enum rcg_kernel { RCG_KERNEL_ACTOR = 0, RCG_KERNEL_SIM = 1, RCG_KERNEL_CRITIC = 2, RCG_KERNEL_COUNT_ = 3 } rcg_kernel;
 /* kernel_mask bits 0..7: bit k set = bracket launches of rcg_kernel k with HIP events recorded on the
- * handle's own stream (1 = the actor kernel only, 7 = all); bits 8..: sampling stride n (0/1 = every
- * launch, n = every n-th launch of each kernel).  A non-zero mask also resets the totals; 0 stops. */
+ * handle's own stream (1 = the actor kernel only, 7 = all); bits 8..19: sampling stride n (0/1 = every
+ * launch, n = every n-th launch of each kernel); bits 20..: launches to let pass before the first sample
+ * (< n).  A non-zero mask also resets the totals; 0 stops. */
 int rcg_profile(rcg_handle* h, int32_t kernel_mask);
 /* Synchronise, then return the summed device time (ms) and number of launches of one kernel since
  * the last rcg_profile(h, 1). */

@@ -28,6 +28,7 @@ int rcg_fail(rcg_handle* h, int code, const char* fmt, ...) {
 }
 
 static void prof_drain(rcg_handle* h) {
+  if (h->ev_pending.empty()) return;  // nothing recorded: do not stall the stream (rcg_profile just before a timed region)
   (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->ev_pending) {
     float ms = 0.f;
@@ -712,8 +713,12 @@ int rcg_profile(rcg_handle* h, int32_t enable) {
   if (!h) return RCG_ERR_BAD_ARG;
   prof_drain(h);
   h->prof_mask = (unsigned)enable & 0xffu;
-  h->prof_stride = ((unsigned)enable >> 8) ? ((unsigned)enable >> 8) : 1u;
-  memset(h->prof_seen, 0, sizeof h->prof_seen);
+  h->prof_stride = (((unsigned)enable >> 8) & 0xfffu) ? (((unsigned)enable >> 8) & 0xfffu) : 1u;
+  // bits 20..: launches of each kernel to let pass before the first sample (the first launch after a synchronisation
+  // starts on an idle GPU and is not representative of the stream)
+  const unsigned skip = (unsigned)enable >> 20;
+  for (int k = 0; k < RCG_KERNEL_COUNT_; ++k)
+    h->prof_seen[k] = skip ? (uint64_t)h->prof_stride - (uint64_t)(skip % h->prof_stride) : 0;
   if (enable) {
     memset(h->prof_ms, 0, sizeof h->prof_ms);
     memset(h->prof_n, 0, sizeof h->prof_n);

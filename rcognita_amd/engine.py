@@ -559,9 +559,9 @@ class Engine:
             self.load_state_dict({k: z[k] for k in z.files})
 
     # ------------------------------------------------------------------ measurement
-    def profile(self, kernels=(N.KERNEL_ACTOR, N.KERNEL_SIM, N.KERNEL_CRITIC), stride=1):
+    def profile(self, kernels=(N.KERNEL_ACTOR, N.KERNEL_SIM, N.KERNEL_CRITIC), stride=1, skip=0):
         """Bracket every ``stride``-th launch of the given kernels with HIP events on the engine's own
-        stream (rcg_profile); ``False`` / empty stops recording."""
+        stream (rcg_profile), the first one after ``skip`` (< stride) launches; ``False`` / empty stops recording."""
         mask = 0
         if kernels is True:
             mask = 7
@@ -569,7 +569,9 @@ class Engine:
             for k in kernels:
                 mask |= 1 << int(k)
         if mask:
-            mask |= max(int(stride), 1) << 8
+            stride = min(max(int(stride), 1), 0xfff)
+            mask |= stride << 8
+            mask |= (int(skip) % stride) << 20
         N.check(N.lib().rcg_profile(self._h, mask), self._h)
 
     def profile_read(self, kernel=N.KERNEL_ACTOR):
