@@ -369,8 +369,12 @@ def main(argv=None):
     if args.single_device:
         local_rank = 0
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} device(s) "
-                         "are visible (use --single-device --dist-backend gloo to exercise the N>1 path on one GPU)")
+        if torch.cuda.device_count() == 1 and world > 1:
+            local_rank = 0  # the launcher masked the devices per rank (HIP_VISIBLE_DEVICES): each rank sees its own GPU as 0
+        else:
+            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} "
+                             "device(s) are visible (use --single-device --dist-backend gloo to exercise the N>1 path "
+                             "on one GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
     coll_dev = torch.device("cuda", local_rank)  # where collective payloads live
