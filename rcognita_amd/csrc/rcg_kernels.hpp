@@ -774,6 +774,80 @@ __global__ __launch_bounds__(256) void k_sim(const SimArgs<real> A, const KParam
   if (P.accum_every_substep) A.accum[b] = accum;
 }
 
+// k_sim with 16 bytes per lane and component: a lane owns VEC = 16 / sizeof(real) CONSECUTIVE envs (the struct-of-arrays
+// layout makes their values of one component contiguous), so every load and store is a dwordx4 (1 KiB per wave
+// instruction instead of 256 B).  The env step moves 72 B per env for ~400 flop: bandwidth-bound once the batch is large
+// (2^24 envs: 5.75 TB/s with 4-byte accesses).  Needs B % VEC == 0; a lane with a frozen env or one that has just gone
+// non-finite falls back to per-env stores (k_sim's semantics exactly: that env's state is left as it was).
+template <typename Sys, typename real, bool TGT>
+__global__ __launch_bounds__(256) void k_sim_v(const SimArgs<real> A, const KParams<real> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NP = Sys::NP, VEC = 16 / (int)sizeof(real);
+  typedef real vreal __attribute__((ext_vector_type(VEC)));
+  typedef uint32_t vu32 __attribute__((ext_vector_type(VEC)));
+  const long B = P.B;
+  const long b0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (b0 >= B) return;
+  vreal xv[DS], uv[DU], pv[NP > 0 ? NP : 1], av;
+#pragma unroll
+  for (int c = 0; c < DS; ++c) xv[c] = *reinterpret_cast<const vreal*>(A.state + (long)c * B + b0);
+#pragma unroll
+  for (int c = 0; c < DU; ++c) uv[c] = *reinterpret_cast<const vreal*>(A.action + (long)c * B + b0);
+  const vu32 stv = *reinterpret_cast<const vu32*>(A.status + b0);
+  if (A.pars_env) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pv[i] = *reinterpret_cast<const vreal*>(A.pars_env + (long)i * B + b0);
+  }
+  if (P.accum_every_substep) av = *reinterpret_cast<const vreal*>(A.accum + b0);
+  vreal xo[DS], xpo[DS], ao;
+  uint32_t sto[VEC];
+  bool all_ok = true;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    real x[DS], xp[DS], u[DU], pe[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) xp[c] = x[c] = xv[c][e];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) u[c] = uv[c][e];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pe[i] = A.pars_env ? pv[i][e] : P.pars[i];
+    const auto pre = Sys::template prepare<real>(pe);
+    uint32_t st = stv[e];
+    real accum = P.accum_every_substep ? av[e] : (real)0;
+    const bool ok = env_substeps<Sys, real, TGT>(P, pre, A.n_sub, x, xp, u, st, accum);
+    all_ok = all_ok && ok;
+    sto[e] = ok ? 0xffffffffu : st;  // marker: stepped; otherwise the status to keep / write
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+      xo[c][e] = x[c];
+      xpo[c][e] = xp[c];
+    }
+    ao[e] = accum;
+  }
+  if (all_ok) {
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+      *reinterpret_cast<vreal*>(A.state + (long)c * B + b0) = xo[c];
+      *reinterpret_cast<vreal*>(A.state_prev + (long)c * B + b0) = xpo[c];
+    }
+    if (P.accum_every_substep) *reinterpret_cast<vreal*>(A.accum + b0) = ao;
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {  // rare: per-env writes, exactly what k_sim does for each of them
+    const long b = b0 + e;
+    if (sto[e] == 0xffffffffu) {
+#pragma unroll
+      for (int c = 0; c < DS; ++c) {
+        A.state[(long)c * B + b] = xo[c][e];
+        A.state_prev[(long)c * B + b] = xpo[c][e];
+      }
+      if (P.accum_every_substep) A.accum[b] = ao[e];
+    } else if (!(stv[e] & 1u)) {
+      A.status[b] = sto[e];  // became non-finite in this step: frozen at its last finite state
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_ticks: T control ticks in ONE launch, generated candidates (rcg_control_ticks)
 // ---------------------------------------------------------------------------------------------

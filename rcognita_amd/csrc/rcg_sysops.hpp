@@ -125,7 +125,14 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
       HIPCHK(h, hipGetLastError());
       return (int)RCG_OK;
     }
-    if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
+    constexpr long VEC = 16 / (long)sizeof(real);
+    if (h->cfg.batch % VEC == 0 && h->cfg.batch >= (1 << 18)) {  // 16 B per lane and component (k_sim_v): pays once
+      const dim3 gridv(blocks_for(h->cfg.batch / VEC));          // the launch is bandwidth- rather than latency-bound
+      if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
+        hipLaunchKernelGGL((k_sim_v<Sys, real, true>), gridv, dim3(256), 0, h->stream, A, params<real>(h));
+      else
+        hipLaunchKernelGGL((k_sim_v<Sys, real, false>), gridv, dim3(256), 0, h->stream, A, params<real>(h));
+    } else if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
       hipLaunchKernelGGL((k_sim<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, A,
                          params<real>(h));
     else

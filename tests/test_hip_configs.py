@@ -232,3 +232,46 @@ def test_one_million_envs():
     np.testing.assert_array_equal(eng.get_field(N.FIELD_RETURNS), returns)
     eng.control_tick(None, K=K)
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.ones(B, np.int32))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["3wrobot", "2tank"])
+def test_vectorised_env_step_equals_the_scalar_kernel(name, dtype):
+    """From 2^18 envs the env step runs on k_sim_v (16 bytes per lane and component, VEC consecutive envs per lane);
+    below on k_sim.  Same arithmetic: the first 4096 envs of a 2^18 batch must equal a 4096-env handle bit for bit,
+    including an env that overflows in this step (frozen, flagged), an already frozen env, per-env parameters and several
+    substeps; a sample follows the oracle."""
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import preset_engine_config
+
+    rng = np.random.default_rng(18)
+    B, Bs, S = 1 << 18, 4096, 3
+    per_env = name == "3wrobot"
+    big = Engine(preset_engine_config(name, B, Nactor=3, dtype=dtype, substeps_per_tick=S, per_env_pars=per_env))
+    small = Engine(preset_engine_config(name, Bs, Nactor=3, dtype=dtype, substeps_per_tick=S, per_env_pars=per_env))
+    x0 = rand_states(rng, name, B).astype(big.real)
+    x0[5, -1] = 1e30 if dtype == "f32" else 1e300  # goes non-finite inside the step (lane 1 of its vector)
+    u0 = (rng.uniform(-1, 1, (B, big.du)) * (100 if name == "3wrobot" else 1)).astype(big.real)
+    st = np.zeros(B, np.uint32)
+    st[10] = 1  # frozen before the step
+    for e, n in ((big, B), (small, Bs)):
+        e.set_state(x0[:n])
+        e.set_field(N.FIELD_ACTION, u0[:n])
+        e.set_field(N.FIELD_STATUS, st[:n])
+        if per_env:
+            e.set_field(N.FIELD_PARS, np.stack([np.linspace(5, 20, B)[:n], np.linspace(0.5, 2, B)[:n]], axis=-1))
+    for _ in range(2):
+        big.sim_step(S)
+        small.sim_step(S)
+    for f in (N.FIELD_STATE, N.FIELD_STATE_PREV, N.FIELD_STATUS):
+        np.testing.assert_array_equal(big.get_field(f)[:Bs], small.get_field(f), err_msg=str(f))
+    s1 = big.get_field(N.FIELD_STATUS)
+    assert s1[5] == 1 and s1[10] == 1 and s1.sum() == 2
+    np.testing.assert_array_equal(big.get_state()[[5, 10]], x0[[5, 10]])  # frozen at their last finite state
+    if not per_env:
+        sel = np.sort(rng.choice(np.arange(64, B), 64, replace=False))
+        cfg = oracle_cfg(name, n_actor=3, substeps_per_tick=S)
+        env = O.new_batch(cfg, x0[sel].astype(np.float64), action0=u0[sel].astype(np.float64))
+        for _ in range(2):
+            O.sim_substeps(cfg, env, S)
+        assert rel_err_norm(big.get_state()[sel], env.state) < (1e-5 if dtype == "f32" else 1e-11)
