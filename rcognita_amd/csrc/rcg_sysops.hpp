@@ -126,8 +126,11 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
       return (int)RCG_OK;
     }
     constexpr long VEC = 16 / (long)sizeof(real);
-    if (h->cfg.batch % VEC == 0 && h->cfg.batch >= (1 << 18)) {  // 16 B per lane and component (k_sim_v): pays once
-      const dim3 gridv(blocks_for(h->cfg.batch / VEC));          // the launch is bandwidth- rather than latency-bound
+    // 16 B per lane and component (k_sim_v) pays once the launch is bandwidth- rather than latency-bound, and only for
+    // the light dynamics: 2tank at 2^24 envs 4.7 -> 5.6 TB/s; the robots' RK4 (four accurate sin/cos per substep) with
+    // VEC envs per lane needs 112 VGPRs instead of 70 and got SLOWER (5.76 -> 5.2 TB/s), so they stay on k_sim
+    if (Sys::DS <= 2 && h->cfg.batch % VEC == 0 && h->cfg.batch >= (1 << 18)) {
+      const dim3 gridv(blocks_for(h->cfg.batch / VEC));
       if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
         hipLaunchKernelGGL((k_sim_v<Sys, real, true>), gridv, dim3(256), 0, h->stream, A, params<real>(h));
       else

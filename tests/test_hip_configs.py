@@ -237,8 +237,8 @@ def test_one_million_envs():
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["3wrobot", "2tank"])
 def test_vectorised_env_step_equals_the_scalar_kernel(name, dtype):
-    """From 2^18 envs the env step runs on k_sim_v (16 bytes per lane and component, VEC consecutive envs per lane);
-    below on k_sim.  Same arithmetic: the first 4096 envs of a 2^18 batch must equal a 4096-env handle bit for bit,
+    """From 2^18 envs the 2tank env step runs on k_sim_v (16 bytes per lane and component, VEC consecutive envs per lane);
+    below, and for the robots, on k_sim.  Same arithmetic: the first 4096 envs of a 2^18 batch must equal a 4096-env handle bit for bit,
     including an env that overflows in this step (frozen, flagged), an already frozen env, per-env parameters and several
     substeps; a sample follows the oracle."""
     from rcognita_amd import Engine, _native as N
@@ -250,7 +250,11 @@ def test_vectorised_env_step_equals_the_scalar_kernel(name, dtype):
     big = Engine(preset_engine_config(name, B, Nactor=3, dtype=dtype, substeps_per_tick=S, per_env_pars=per_env))
     small = Engine(preset_engine_config(name, Bs, Nactor=3, dtype=dtype, substeps_per_tick=S, per_env_pars=per_env))
     x0 = rand_states(rng, name, B).astype(big.real)
-    x0[5, -1] = 1e30 if dtype == "f32" else 1e300  # goes non-finite inside the step (lane 1 of its vector)
+    big_v = 3e38 if dtype == "f32" else 1.7e308  # goes non-finite inside the step (lane 1 of its vector)
+    if name == "3wrobot":
+        x0[5, 2], x0[5, 3] = 0.0, big_v  # k1 + 2 k2 + 2 k3 + k4 of x overflows
+    else:
+        x0[5, 1] = 1e30 if dtype == "f32" else 1e200  # K3 h2^2 overflows
     u0 = (rng.uniform(-1, 1, (B, big.du)) * (100 if name == "3wrobot" else 1)).astype(big.real)
     st = np.zeros(B, np.uint32)
     st[10] = 1  # frozen before the step
