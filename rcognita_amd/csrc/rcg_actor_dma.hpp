@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
       if ((nbytes & 1023) == 0) {
         const unsigned char* const src = reinterpret_cast<const unsigned char*>(jstage);
         unsigned char* const dst = reinterpret_cast<unsigned char*>(Jout);
-        for (int i = lane * 16; i < nbytes; i += 1024)
-          *reinterpret_cast<v4f*>(dst + i) = *reinterpret_cast<const v4f*>(src + i);
+        for (int i = lane * 16; i < nbytes; i += 1024)  // written once, never re-read by this launch: non-temporal
+          __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(src + i), reinterpret_cast<v4f*>(dst + i));
       } else {
         for (int i = lane; i < n; i += 64) Jout[i] = jstage[i];
       }
