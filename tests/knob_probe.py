@@ -40,6 +40,20 @@ def main():
         for f in (N.FIELD_STATE, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_BEST_IDX, N.FIELD_BEST_J):
             h.update(np.ascontiguousarray(e3.get_field(f)).tobytes())
         e3.close()
+    # RQL / SQL closed loops past the point where the buffers have filled (env step + push + critic fit in one launch,
+    # generated candidates), a ragged last block
+    for name, cs, mode, Bc in (("2tank", "quadratic", "RQL", 2000), ("2tank", "quad-mix", "SQL", 700),
+                               ("2tank", "quad-nomix", "RQL", 300), ("2tank", "quad-lin", "RQL", 300),
+                               ("3wrobot", "quad-nomix", "RQL", 900), ("3wrobotNI", "quad-nomix", "SQL", 333)):
+        ec = Engine(preset_engine_config(name, Bc, Nactor=6, mode=mode, critic_struct=cs, Ncritic=4, buffer_size=6))
+        ds = {"2tank": 2, "3wrobot": 5, "3wrobotNI": 3}[name]
+        ec.set_state(rng.uniform(0.1, 2.0, (Bc, ds)).astype(np.float32))
+        for _ in range(14):
+            ec.control_tick(None, K=64)
+        for f in (N.FIELD_STATE, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_BEST_IDX, N.FIELD_W_CRITIC, N.FIELD_W_PREV,
+                  N.FIELD_OBS_BUF, N.FIELD_ACT_BUF):
+            h.update(np.ascontiguousarray(ec.get_field(f)).tobytes())
+        ec.close()
     print("HASH", h.hexdigest())
 
 

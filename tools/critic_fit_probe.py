@@ -14,7 +14,7 @@ from rcognita_amd.pool import preset_engine_config  # noqa: E402
 
 rng = np.random.default_rng(1234)
 B, K = 131072, 256
-for cs in ("quadratic", "quad-lin", "quad-nomix", "quad-mix"):
+for cs in (sys.argv[1:] or ("quadratic", "quad-lin", "quad-nomix", "quad-mix")):
     eng = Engine(preset_engine_config("2tank", B, Nactor=20, mode="RQL", critic_struct=cs, Ncritic=4, buffer_size=10))
     eng.set_state(np.stack([rng.uniform(0, 2, B), rng.uniform(-2, 2, B)], axis=-1))
     for _ in range(25):
