@@ -557,7 +557,7 @@ def main(argv=None):
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "                           "stored; not re-measured in this run)"
         except Exception:
             traffic = None
-    dma = streamed and K % 64 == 0 and args.config != "C5" and Nh * 2 <= (32 if args.dtype == "f32" else 20)
+    dma = streamed and K % 64 == 0 and args.config != "C5" and Nh * 2 <= (40 if args.dtype == "f32" else 20)
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
               "candidates (BASELINE configs[1])",

@@ -4,7 +4,7 @@
 TEST INFRASTRUCTURE ONLY; runs in the build container (imports /root/reference through oracle/gen_fixtures.py).
 F4 has ``state_sys != obs`` and one sequence per call, so on the GPU it reaches the generic kernel only.  Here, per
 case, 2 envs x 64 candidate sequences with ``state_sys == obs`` (the control tick without ref_lag) - what k_actor_dma
-serves: f32, K a multiple of 64, rows of N*du <= 32 reals, MPC (gamma = 1: the per-component instance; gamma = 0.95:
+serves: f32, K a multiple of 64, rows of N*du <= 40 reals, MPC (gamma = 1: the per-component instance; gamma = 0.95:
 the discounted one) and RQL (critic instances, all four structures).  States and sequences are float32-exact values
 stored as float32 (the reference evaluates them in float64), so the f32 kernel reads bit-identical inputs.
 
@@ -17,7 +17,7 @@ import gen_fixtures as G
 
 def main():
     systems, simulator, controllers = G.import_reference()
-    rng = np.random.default_rng(20261004)
+    rng_main = np.random.default_rng(20261004)
     for name in G.PRESETS:
         p = G.PRESETS[name]
         sys_obj = G.make_sys(systems, name)
@@ -26,8 +26,16 @@ def main():
         cases = [(N, "MPC", "quad-nomix", g) for N in (3, 5, 10, 16) for g in (1.0, 0.95)]
         cases += [(N, "RQL", cs, 0.95) for N in (5, 16) for cs in ("quad-lin", "quadratic", "quad-nomix", "quad-mix")]
         if p["du"] == 1:
-            cases += [(32, "MPC", "quad-nomix", 1.0)]  # the longest row k_actor_dma takes for du = 1
-        for N, mode, cs, gamma in cases:
+            cases += [(32, "MPC", "quad-nomix", 1.0)]  # (round-2 fixture: the longest row at the time)
+        # rows up to 160 bytes = 40 floats: the robots' Nactor = 20 (a generator of their own, so that the cases above
+        # keep the draws the committed fixture was made with)
+        Nmax = 40 // p["du"]
+        n_old = len(cases)
+        cases += [(Nmax, "MPC", "quad-nomix", 1.0), (Nmax, "MPC", "quad-nomix", 0.95), (Nmax - 1, "RQL", "quad-mix", 0.95),
+                  (Nmax, "SQL", "quad-nomix", 1.0)]
+        rng_long = np.random.default_rng([20261005, p["ds"], p["du"]])
+        for ci, (N, mode, cs, gamma) in enumerate(cases):
+            rng = rng_main if ci < n_old else rng_long
             x = G.rand_states(rng, name, n_env).astype(np.float32)
             aseq = G.rand_actions(rng, name, (n_env, K, N)).astype(np.float32)
             c = G.make_ctrl(controllers, sys_obj, name, mode=mode, Nactor=N, gamma=gamma, critic_struct=cs)

@@ -303,7 +303,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
 
   // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K a multiple of 64, diagonal quadratic
-  // stage cost, the preset's observation target; f32: rows of <= 32 reals, MPC / RQL / SQL; f64: rows of <= 20 reals, MPC.
+  // stage cost, the preset's observation target; f32: rows of <= 40 reals, MPC / RQL / SQL; f64: rows of <= 20 reals, MPC.
   const DevKnobs& knobs = dev_knobs();
   A.dbg = knobs.dbg;
   constexpr bool is_f32 = std::is_same<real, float>::value;

@@ -120,7 +120,7 @@ def test_F4_actor_cost_golden(name, dtype):
 @pytest.mark.parametrize("name", SYSTEMS)
 def test_F4b_reference_actor_cost_through_the_production_kernel(name, dtype):
     """Numbers the REFERENCE produced (fixture F4b: its _actor_cost, controllers.py:1273-1328, state_sys == obs, 64
-    sequences per env) through the streamed production kernel: f32 K = 64, rows of N*du <= 32 reals, diagonal R1 ->
+    sequences per env) through the streamed production kernel: f32 K = 64, rows of N*du <= 40 reals, diagonal R1 ->
     k_actor_dma - the gamma == 1 per-component instance (G1), the discounted instance, and the critic instances (RQL,
     four structures).  Both the operator (J of every sequence, staged in LDS) and the argmin.  Inputs are stored as
     float32, so the kernel reads exactly what the reference evaluated."""
@@ -203,7 +203,8 @@ def test_F6_hip_rk4_vs_reference_rk45(name):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name,N", [("3wrobot", 10), ("3wrobot", 7), ("3wrobotNI", 15), ("2tank", 20), ("2tank", 5),
                                     ("3wrobot", 5), ("3wrobotNI", 3), ("3wrobot", 16), ("2tank", 32), ("2tank", 1),
-                                    ("3wrobot", 20)])  # preset defaults, the largest DMA rows, and one beyond them
+                                    ("3wrobot", 20), ("2tank", 40), ("3wrobotNI", 21)])  # preset defaults, the largest DMA
+#                                                                   rows (160 bytes: 40 floats / 20 doubles), one beyond them
 @pytest.mark.parametrize("K", [1, 3, 16, 33, 64, 100, 256])
 def test_actor_cost_and_argmin_vs_oracle(name, N, K, dtype):
     """Streamed candidates: J vs oracle; argmin bit-exact vs numpy on the SAME J; winner's first action."""
