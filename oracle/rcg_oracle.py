@@ -729,7 +729,9 @@ def critic_fit_single(A, b, w0, lo, hi, stats=None, w_start=None):
                         acc += A[r, i] * A[q, i]
                 M[r, q] = M[q, r] = acc + (mu if r == q else 0.0)
         lam = _chol_solve(M, rhs, floor=mu * 1e-6)
-        alpha, jmin = 2.0, -1
+        # ratio test: the step to the bound z_i crosses is a_i = n_i / d_i, n_i = |bound_i - w_i| <= d_i = |z_i - w_i|; the
+        # smallest one (first index on ties) is found by cross-multiplication, alpha is the ONE division (as the kernel)
+        nb, db, jmin = 2.0, 1.0, -1
         for i in range(dc):
             if not free[i]:
                 continue
@@ -737,14 +739,13 @@ def critic_fit_single(A, b, w0, lo, hi, stats=None, w_start=None):
             for r in range(m):
                 c += A[r, i] * lam[r]
             z[i] = w0[i] + c
-            a = 2.0
-            if z[i] < lo[i]:
-                a = (lo[i] - w[i]) / (z[i] - w[i])
-            elif z[i] > hi[i]:
-                a = (hi[i] - w[i]) / (z[i] - w[i])
-            if a < alpha:
-                alpha, jmin = a, i
+            if z[i] < lo[i] or z[i] > hi[i]:
+                ni = abs((lo[i] if z[i] < lo[i] else hi[i]) - w[i])
+                di = abs(z[i] - w[i])
+                if ni * db < nb * di:
+                    nb, db, jmin = ni, di, i
         if jmin >= 0:  # move towards z until the first bound, fix that variable
+            alpha = nb / db
             if not alpha > 0.0:
                 alpha = 0.0
             for i in range(dc):

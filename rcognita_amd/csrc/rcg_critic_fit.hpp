@@ -93,10 +93,32 @@ struct FitArgs {
 template <typename Sys, typename real, int CS, int MAXM>
 __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, DC = CriticDim<CS, DS, DU>::value;
+  // rows of the shifted buffers that stay in registers for the TD stack: new row r = old row r + 1, r = 0 .. KEEP - 1
+  constexpr int KEEP = MAXM + 1 <= 4 ? MAXM + 1 : 4;
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long B = P.B;
   if (b >= B) return;
   const int m = P.n_critic - 1;  // rows of the TD stack, 1 <= m <= MAXM (checked on the host)
+  const int bs = Pr.buffer_size;
+
+  // ---- every load the prologue needs is requested here, before any arithmetic: the env step, the shift of the two
+  // buffers and the TD stack used to be three dependent round trips to memory (and the row-by-row shift one per row:
+  // the compiler cannot prove that the store to row r leaves row r + 2 alone) ----------------------------------------
+  real wpr[DC];
+  if (F.do_fit) {
+#pragma unroll
+    for (int i = 0; i < DC; ++i) wpr[i] = F.w_prev[(long)i * B + b];
+  }
+  real ko[KEEP][DS], ka[KEEP][DU];  // do_push: old rows 1 .. KEEP (= new rows 0 .. KEEP - 1); else rows 0 .. KEEP - 1
+  const int koff = F.do_push ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < KEEP; ++k)
+    if (k + koff < bs) {
+#pragma unroll
+      for (int c = 0; c < DS; ++c) ko[k][c] = F.obs_buf[((long)(k + koff) * DS + c) * B + b];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) ka[k][c] = F.act_buf[((long)(k + koff) * DU + c) * B + b];
+    }
 
   if (F.do_sim || F.do_push) {
     real xs[DS], xp[DS], ua[DU];
@@ -125,17 +147,47 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
       }
     }
     if (F.do_push) {  // push_vec on both buffers: drop row 0, append (obs, action_curr) at the bottom (utilities.py:78-79)
-      const int bs = Pr.buffer_size;
-      for (int r = 0; r < bs - 1; ++r) {
 #pragma unroll
-        for (int c = 0; c < DS; ++c) F.obs_buf[((long)r * DS + c) * B + b] = F.obs_buf[((long)(r + 1) * DS + c) * B + b];
+      for (int k = 0; k < KEEP; ++k)
+        if (k + 1 < bs) {
 #pragma unroll
-        for (int c = 0; c < DU; ++c) F.act_buf[((long)r * DU + c) * B + b] = F.act_buf[((long)(r + 1) * DU + c) * B + b];
+          for (int c = 0; c < DS; ++c) F.obs_buf[((long)k * DS + c) * B + b] = ko[k][c];
+#pragma unroll
+          for (int c = 0; c < DU; ++c) F.act_buf[((long)k * DU + c) * B + b] = ka[k][c];
+        }
+      // the rest of the shift four rows at a time, all loads of a pass before its stores
+      constexpr int CH = 4;
+      for (int r0 = KEEP; r0 < bs - 1; r0 += CH) {
+        real ro[CH][DS], ra[CH][DU];
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+          if (r0 + k < bs - 1) {
+#pragma unroll
+            for (int c = 0; c < DS; ++c) ro[k][c] = F.obs_buf[((long)(r0 + k + 1) * DS + c) * B + b];
+#pragma unroll
+            for (int c = 0; c < DU; ++c) ra[k][c] = F.act_buf[((long)(r0 + k + 1) * DU + c) * B + b];
+          }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+          if (r0 + k < bs - 1) {
+#pragma unroll
+            for (int c = 0; c < DS; ++c) F.obs_buf[((long)(r0 + k) * DS + c) * B + b] = ro[k][c];
+#pragma unroll
+            for (int c = 0; c < DU; ++c) F.act_buf[((long)(r0 + k) * DU + c) * B + b] = ra[k][c];
+          }
       }
 #pragma unroll
       for (int c = 0; c < DS; ++c) F.obs_buf[((long)(bs - 1) * DS + c) * B + b] = xs[c];
 #pragma unroll
       for (int c = 0; c < DU; ++c) F.act_buf[((long)(bs - 1) * DU + c) * B + b] = ua[c];
+#pragma unroll
+      for (int k = 0; k < KEEP; ++k)
+        if (k == bs - 1) {  // (buffer_size <= KEEP: the row just pushed is one of the kept rows)
+#pragma unroll
+          for (int c = 0; c < DS; ++c) ko[k][c] = xs[c];
+#pragma unroll
+          for (int c = 0; c < DU; ++c) ka[k][c] = ua[c];
+        }
     }
     if (!F.do_fit) return;
   }
@@ -143,7 +195,7 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
   double A[MAXM][DC], bv[MAXM], wp[DC], w0[DC], lo[DC], hi[DC];
 #pragma unroll
   for (int i = 0; i < DC; ++i) {
-    wp[i] = (double)F.w_prev[(long)i * B + b];
+    wp[i] = (double)wpr[i];
     w0[i] = F.wcfg[i];
     lo[i] = F.wcfg[40 + i];
     hi[i] = F.wcfg[80 + i];
@@ -159,10 +211,17 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
   for (int r = 0; r <= MAXM; ++r) {
     if (r <= m) {
       double y[DS], u[DU], chi[NCHI], phi[DC];
+      if (r < KEEP) {
 #pragma unroll
-      for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)r * DS + c) * B + b];
+        for (int c = 0; c < DS; ++c) y[c] = (double)ko[r][c];
 #pragma unroll
-      for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)r * DU + c) * B + b];
+        for (int c = 0; c < DU; ++c) u[c] = (double)ka[r][c];
+      } else {  // m > 3: beyond the kept rows (written above by this lane: same-address order, served by L2)
+#pragma unroll
+        for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)r * DS + c) * B + b];
+#pragma unroll
+        for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)r * DU + c) * B + b];
+      }
       if (P.has_target)
         make_chi<DS, DU, true, double>(P, y, u, chi);
       else
@@ -203,6 +262,13 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
   }
   int last_freed = -1;
 
+  // Cost model, measured at B = 131072 (2tank, quadratic critic, steady state of an RQL loop, tools/critic_fit_probe.py
+  // with the walk capped at c iterations): 14 us + 3.6 us x c up to c = 8, 66 us uncapped (the longest walk of the batch):
+  // with B / 64 = 2 waves per SIMD the kernel lasts as long as its slowest wave, and a wave runs as many iterations as
+  // its slowest lane.  Per-variable work is straight-line code on selects and the ratio test divides once; one
+  // iteration is ~680 VALU instructions of which 250 are float64 arithmetic and 160 are the halves of 64-bit selects.
+  // Re-packing unfinished walks into dense waves between levels of iterations (LDS hand-over, blocks of 256 envs) was
+  // built and measured in round 2: 34 % fewer instructions per wave, bit-identical weights, the same duration - dropped.
   for (int it = 0; it < fit_max_iters(DC); ++it) {
     // rhs = b - A_B w_B - A_F w0_F,  M = A_F A_F^T + mu I  (rows >= m: M = mu I, rhs = 0 -> lam = 0)
     double L[MAXM][MAXM], lam[MAXM];
@@ -266,41 +332,41 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
       for (int k = i + 1; k < MAXM; ++k) s -= L[k][i] * lam[k];
       lam[i] = s;
     }
-    // z_F = w0_F + A_F^T lam and the ratio test towards it
-    double alpha = 2.0;
+    // z_F = w0_F + A_F^T lam and the ratio test towards it: the step to the bound z_i crosses is a_i = n_i / d_i with
+    // n_i = |bound_i - w_i| <= d_i = |z_i - w_i|; the smallest a_i (first index on ties) is found by comparing
+    // n_i d_best with n_best d_i - no division - and alpha = n_best / d_best is the one division of the iteration
+    double nb = 2.0, db = 1.0;
     int jmin = -1;
 #pragma unroll
     for (int i = 0; i < DC; ++i) {
-      if ((fm >> i) & 1ull) {
-        double c = 0.0;
+      const bool fr = (fm >> i) & 1ull;
+      double c = 0.0;
 #pragma unroll
-        for (int r = 0; r < MAXM; ++r) c = fma_r(A[r][i], lam[r], c);
-        z[i] = w0[i] + c;
-        double a = 2.0;
-        if (z[i] < lo[i])
-          a = (lo[i] - w[i]) / (z[i] - w[i]);
-        else if (z[i] > hi[i])
-          a = (hi[i] - w[i]) / (z[i] - w[i]);
-        if (a < alpha) {
-          alpha = a;
-          jmin = i;
-        }
+      for (int r = 0; r < MAXM; ++r) c = fma_r(A[r][i], lam[r], c);
+      const double zi = w0[i] + c;
+      z[i] = fr ? zi : z[i];
+      const bool vlo = zi < lo[i], vhi = zi > hi[i];
+      const double ni = fabs((vlo ? lo[i] : hi[i]) - w[i]), di = fabs(zi - w[i]);
+      if (fr && (vlo || vhi) && ni * db < nb * di) {
+        nb = ni;
+        db = di;
+        jmin = i;
       }
     }
     if (jmin >= 0) {  // move towards z until the first bound, fix that variable
+      double alpha = nb / db;
       if (!(alpha > 0.0)) alpha = 0.0;
 #pragma unroll
       for (int i = 0; i < DC; ++i) {
-        if ((fm >> i) & 1ull) {
-          double v = w[i] + alpha * (z[i] - w[i]);
-          v = v < lo[i] ? lo[i] : (v > hi[i] ? hi[i] : v);
-          if (i == jmin) {
-            const bool up = z[i] > hi[i];
-            v = up ? hi[i] : lo[i];
-            at_hi = up ? (at_hi | (1ull << i)) : (at_hi & ~(1ull << i));
-          }
-          w[i] = v;
+        const bool fr = (fm >> i) & 1ull;
+        double v = w[i] + alpha * (z[i] - w[i]);
+        v = v < lo[i] ? lo[i] : (v > hi[i] ? hi[i] : v);
+        const bool up = z[i] > hi[i];
+        if (i == jmin) {
+          v = up ? hi[i] : lo[i];
+          at_hi = up ? (at_hi | (1ull << i)) : (at_hi & ~(1ull << i));
         }
+        w[i] = fr ? v : w[i];
       }
       fm &= ~(1ull << jmin);
       if (alpha > 0.0)
@@ -315,7 +381,7 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
     for (int r = 0; r < MAXM; ++r) res[r] = -bv[r];
 #pragma unroll
     for (int i = 0; i < DC; ++i) {
-      if ((fm >> i) & 1ull) w[i] = z[i];
+      w[i] = ((fm >> i) & 1ull) ? z[i] : w[i];
 #pragma unroll
       for (int r = 0; r < MAXM; ++r) res[r] = fma_r(A[r][i], w[i], res[r]);
     }
@@ -323,20 +389,18 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
     double best_score = 0.0;
 #pragma unroll
     for (int i = 0; i < DC; ++i) {
-      if (!(((fm | blocked) >> i) & 1ull)) {
-        double g = mu * (w[i] - w0[i]);
-        double scale = fabs(g);
+      double g = mu * (w[i] - w0[i]);
+      double scale = fabs(g);
 #pragma unroll
-        for (int r = 0; r < MAXM; ++r) {
-          const double t = A[r][i] * res[r];
-          g += t;
-          scale += fabs(t);
-        }
-        const double score = ((at_hi >> i) & 1ull) ? g : -g;
-        if (score > FIT_KKT_TOL * scale && score > best_score) {
-          best = i;
-          best_score = score;
-        }
+      for (int r = 0; r < MAXM; ++r) {
+        const double t = A[r][i] * res[r];
+        g += t;
+        scale += fabs(t);
+      }
+      const double score = ((at_hi >> i) & 1ull) ? g : -g;
+      if (!(((fm | blocked) >> i) & 1ull) && score > FIT_KKT_TOL * scale && score > best_score) {
+        best = i;
+        best_score = score;
       }
     }
     if (best < 0) break;
