@@ -102,8 +102,16 @@ struct Sys2Tank {
     // 1/tau1 (-h1 + K1 u), 1/tau2 (-h2 + K2 h1 + K3 h2^2) (systems.py:416-417) with the multiply-adds written out: under
     // -ffp-contract=fast the compiler otherwise picks the fusions per call site, and the kernels that share this function
     // (k_sim, k_sim_v, k_ticks, the rollouts) must round identically
-    d[0] = q.inv_tau1 * fma_r(q.K1, u[0], -x[0]);
-    d[1] = q.inv_tau2 * fma_r(q.K3, x[1] * x[1], fma_r(q.K2, x[0], -x[1]));
+    // (HW marks the Euler rollouts of _actor_cost: there the expression is left to the compiler, which folds it into the
+    // step and the cost accumulation - with the fusions written out the generated-candidate kernels of configs[2] ran
+    // 18-26 % slower; a rollout never has to reproduce the simulator's bits, only its own across launches)
+    if constexpr (HW) {
+      d[0] = q.inv_tau1 * (-x[0] + q.K1 * u[0]);
+      d[1] = q.inv_tau2 * (-x[1] + q.K2 * x[0] + q.K3 * (x[1] * x[1]));
+    } else {
+      d[0] = q.inv_tau1 * fma_r(q.K1, u[0], -x[0]);
+      d[1] = q.inv_tau2 * fma_r(q.K3, x[1] * x[1], fma_r(q.K2, x[0], -x[1]));
+    }
   }
   template <typename real, bool HW = false>
   __device__ __forceinline__ static void jac_T(const Pre<real>& q, const real* x, const real*, const real* lam,
