@@ -3,7 +3,11 @@
 bench line: configs[2] (Sys2Tank B=131072, Nactor=20, RQL + quadratic critic TD fit every tick) and the
 per-GPU shard of configs[4] (mixed pool, Nactor=15, 256 generated candidates).  Prints one JSON object.
 
-    python tools/bench_configs.py [--steps 50]
+    python tools/bench_configs.py [--steps 50] [--compare profiles/r02_bench_configs.json]
+
+--compare: every rate / kernel time of this run against a stored run, on stderr; exit code 3 if anything is more than
+10 % worse (a regression guard for changes to shared device code: in round 2 a rounding fix in Sys2Tank::rhs slowed the
+generated-candidate kernels of configs[2] by 20 % and went unnoticed until the next profile run).
 """
 import argparse
 import json
@@ -23,6 +27,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=120,
                     help="untimed ticks per case: the GPU needs ~20 ms of continuous work to reach its steady clock "
                          "(tools/clock_ramp.py) and the RQL / SQL buffers ~10 ticks to fill")
+    ap.add_argument("--compare", default=None, help="stored output of this tool to compare with")
     a = ap.parse_args()
     from rcognita_amd import Engine
     from rcognita_amd import _native as N
@@ -224,6 +229,31 @@ def main():
                                                     "ms_per_tick": dt / a.steps * 1e3, "n_failed": summ["n_failed"]}
     pool.close()
     print(json.dumps(out, indent=1))
+    if a.compare:
+        sys.exit(compare(out, json.load(open(a.compare))))
+
+
+def compare(new, old, tol=0.10):
+    """Rates (higher is better) and times (lower is better) of `new` against `old`; 3 if any is > tol worse."""
+    worse = 0
+    for k, e in new.items():
+        o = old.get(k)
+        if not isinstance(e, dict) or not isinstance(o, dict):
+            continue
+        for f, v in e.items():
+            ov = o.get(f)
+            if not isinstance(v, (int, float)) or not isinstance(ov, (int, float)) or not v or not ov:
+                continue
+            if f.endswith("_per_s") or f.endswith("GBps") or f.endswith("GBps_moved"):
+                r = v / ov
+            elif f.endswith("_ms"):
+                r = ov / v
+            else:
+                continue
+            flag = "  <-- WORSE" if r < 1 - tol else ""
+            worse += bool(flag)
+            print(f"{k:62s} {f:26s} {ov:12.5g} -> {v:12.5g}  x{r:.3f}{flag}", file=sys.stderr)
+    return 3 if worse else 0
 
 
 if __name__ == "__main__":
