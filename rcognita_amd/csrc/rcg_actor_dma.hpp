@@ -4,8 +4,8 @@
 // Shape it serves: diagonal quadratic stage cost (every reference preset), K a multiple of 64, the observation target as
 // the system's preset has it; the rollout starts from `state_sys` with `obs` as y_0 (controllers.py:1286-1296) - the same
 // vector in the plain tick, the state before the last substep with RCG_FLAG_REF_LAG (the reference's loop order);
-// f32: candidate rows of R = N*du <= 40 reals, modes MPC, RQL and SQL; f64 (the reference's own arithmetic width): rows
-// of <= 20 reals, MPC.  Everything else goes to k_actor (rcg_kernels.hpp).
+// candidate rows of R = N*du <= 40 reals; f32: modes MPC, RQL and SQL; f64 (the reference's own arithmetic width):
+// MPC.  Everything else goes to k_actor (rcg_kernels.hpp).
 //
 //   per tile of 64 candidate rows (64*R*sizeof(real) bytes, contiguous in HBM):
 //     1. direct-to-LDS loads: global_load_lds_dwordx4 (64 lanes x 16 B = 1 KiB each) plus global_load_lds_dword (256 B
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   constexpr int CS = SQL ? V - DMA_SQL_0 : -1;  // compile-time critic structure (SQL), -1: P.critic_struct (RQL)
   constexpr int DCMAX = SQL ? dma_dc(CS, DS, DU) : (RQL ? dma_dc(RCG_CRITIC_QUAD_LIN, DS, DU) : 1);
   constexpr int ESZ = (int)sizeof(real);
-  static_assert(R % DU == 0 && R >= DU && R * ESZ <= 160, "row = N*du reals, at most 160 bytes");
+  static_assert(R % DU == 0 && R >= DU && R <= 40, "row = N*du reals, at most 40 (f32: 160 bytes, f64: 320)");
   constexpr int N = R / DU;
   constexpr int TILE = 64 * R * ESZ;                               // bytes of one tile of 64 rows
   constexpr int NFULL = TILE / 1024, NREM = (TILE % 1024) / 256;  // 1-KiB and 256-B direct-to-LDS loads per tile
@@ -351,10 +351,11 @@ template <typename Sys, typename real, int GROUP>
 bool launch_dma(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
                 const KParams<real>& P);
 
-// longest row with an instance, in reals: 160 bytes (f32: 40 reals = the robots' Nactor = 20, f64: 20 reals)
+// longest row with an instance, in reals: 40 = the robots' Nactor = 20 (f32: 160 bytes; f64: 320 bytes, a block's four
+// tiles are then 80 KB of LDS - beyond the default dynamic limit, launch_dma raises it for those instances)
 template <typename real>
 constexpr int dma_max_row() {
-  return sizeof(real) == 4 ? 40 : 20;
+  return 40;
 }
 
 }  // namespace rcg

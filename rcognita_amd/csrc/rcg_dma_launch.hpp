@@ -19,9 +19,15 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
     if constexpr (R % Sys::DU != 0) {
       return false;
     } else {
-#define RCG_DMA_CASE(V)                                                                            \
-  case V: hipLaunchKernelGGL((k_actor_dma<Sys, real, R, Sys::TGT, V>), grid, block, lds, s, A, P); \
-    return true;
+#define RCG_DMA_CASE(V)                                                                                              \
+  case V: {                                                                                                          \
+    auto fn = k_actor_dma<Sys, real, R, Sys::TGT, V>;                                                                \
+    if (lds > 64 * 1024) /* f64 rows beyond 256 bytes: four 64-row tiles exceed the default dynamic-LDS limit */     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                (int)lds);                                                                           \
+    hipLaunchKernelGGL(fn, grid, block, lds, s, A, P);                                                               \
+    return true;                                                                                                     \
+  }
       if constexpr (GROUP == 0) {
         switch (variant) {
           RCG_DMA_CASE(DMA_MPC_G1)
