@@ -144,6 +144,37 @@ def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B):
     assert summ["count"] == B and summ["n_failed"] == 0
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-11)])
+@pytest.mark.parametrize("name,Nh,ref_lag", [("3wrobot", 20, False), ("3wrobotNI", 19, True), ("2tank", 40, False)])
+def test_long_rows_closed_loop_on_the_production_kernel(name, Nh, ref_lag, dtype, tol):
+    """Rows of up to 40 reals (the robots' Nactor = 20; f32 160 B, f64 320 B - four 64-row tiles of a block are then
+    80 KB of LDS) on k_actor_dma: a streamed closed loop, a ragged last block, every env and every
+    tick against the oracle (near-tied argmins followed), with and without the reference's one-step state lag."""
+    from oracle import parity as PAR
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import preset_engine_config
+
+    rng = np.random.default_rng(Nh)
+    B, K, T = 2048 + 37, 128, 3
+    eng = Engine(preset_engine_config(name, B, Nactor=Nh, dtype=dtype, ref_lag=ref_lag))
+    x0 = rand_states(rng, name, B).astype(eng.real)
+    eng.set_state(x0)
+    cfg = oracle_cfg(name, n_actor=Nh, ref_lag=ref_lag)
+    du = cfg.du
+    lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
+    cand1 = (lo + (hi - lo) * rng.random((K, Nh, du))).astype(eng.real)
+    cand = eng.to_device(np.ascontiguousarray(np.broadcast_to(cand1, (B, K, Nh, du))))
+    env = O.new_batch(cfg, x0.astype(np.float64))
+    rep = PAR.TickReport()
+    for t in range(T):
+        eng.control_tick(cand, K=K)
+        env = PAR.check_tick(cfg, env, cand1.astype(np.float64), PAR.device_fields(eng, N), tol=tol, report=rep,
+                             what=f"{name} N={Nh} {dtype} t={t}")
+    assert rep.ties <= 0.002 * B * T
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
+    eng.close()
+
+
 def test_C4_job_sharded_eight_ways_equals_the_unsharded_job():
     """configs[3] by construction on one GPU: the 524288-env Sys3WRobot job as ONE handle, and as the 8 shards
     `shard_range` gives 8 ranks (65536 envs each, run one after the other here), same global states and candidate rows.
