@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - env.control-steps/sec of the rcognita hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C4|C5] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5] [--scaling weak|strong]
 
 Workload, default (BASELINE.json configs[1], SURVEY.md 8d "C2"): Sys3WRobot, B = 65536 envs per GPU, RK4
 dt = 0.01 (one substep per control tick), CtrlOptPred MPC, Nactor = 10, K = 256 candidate action
@@ -9,6 +9,9 @@ sequences per env streamed from HBM as a [B][K][N][du] f32 tensor (the `_actor_c
 operator shape).  One "step" = one env.control-step (unit U2) for every env of the batch:
 rcg_control_tick = k_sim (closed_loop_rhs under RK4) + k_actor_dma (K rollouts + argmin + accum update).
 Inputs are synthetic and resident in HBM before the timed region.
+  --config C3   configs[2]: Sys2Tank, 131072 envs per GPU, Nactor = 20, RQL with the quadratic critic refitted every tick
+                (k_critic_fit: env step + buffer push + TD fit in one launch), K = 256 candidates streamed (k_actor_dma, RQL
+                instance) or `--regime generated`.
   --config C4   configs[3]: 524288 Sys3WRobot envs in total, sharded over the ranks (strong scaling unless
                 --scaling weak), ONE all_gather of the per-env episode returns over RCCL in the timed region.
   --config C5   configs[4]: mixed pool 3wrobot + 3wrobot_NI + 2tank, 65536 envs per GPU sharded within each type,
@@ -46,13 +49,13 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=500)
     p.add_argument("--warmup", type=int, default=100)
-    p.add_argument("--config", choices=["C2", "C4", "C5"], default="C2",
-                   help="BASELINE.json configs[1] (default, the metric's config), configs[3], configs[4]")
+    p.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C2",
+                   help="BASELINE.json configs[1] (default, the metric's config), configs[2], configs[3], configs[4]")
     p.add_argument("--scaling", choices=["weak", "strong"], default=None,
                    help="weak: --batch envs per GPU; strong: --batch envs in total (default: weak, C4: strong)")
     p.add_argument("--batch", type=int, default=None, help="envs per GPU (weak) or in total (strong)")
     p.add_argument("--candidates", type=int, default=256, help="K candidate sequences per env")
-    p.add_argument("--nactor", type=int, default=None, help="horizon (default 10; C5: 15)")
+    p.add_argument("--nactor", type=int, default=None, help="horizon (default 10; C3: 20; C5: 15)")
     p.add_argument("--regime", choices=["streamed", "generated"], default=None)
     p.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,9 +75,9 @@ def parse(argv=None):
     if a.scaling is None:
         a.scaling = "strong" if a.config == "C4" else "weak"
     if a.batch is None:
-        a.batch = C4_TOTAL_ENVS if (a.config == "C4" and a.scaling == "strong") else 65536
+        a.batch = C4_TOTAL_ENVS if (a.config == "C4" and a.scaling == "strong") else (131072 if a.config == "C3" else 65536)
     if a.nactor is None:
-        a.nactor = 15 if a.config == "C5" else 10
+        a.nactor = {"C5": 15, "C3": 20}.get(a.config, 10)
     if a.regime is None:
         a.regime = "generated" if a.config == "C5" else "streamed"
     if a.config == "C5" and a.regime != "generated":
@@ -153,11 +156,20 @@ def launch(args, argv):
 # ---------------------------------------------------------------------------------------------------------------
 # workload pieces
 # ---------------------------------------------------------------------------------------------------------------
+C3_KW = dict(mode="RQL", critic_struct="quadratic", Ncritic=4, buffer_size=10, gamma=1.0)
+
+
 def c2_engine_config(args, device, batch, dtype=None, env_id_base=0):
     import numpy as np
 
     from rcognita_amd import EngineConfig
     from rcognita_amd import _native as N
+
+    if args.config == "C3":  # Sys2Tank with its preset's constants (presets/main_2tank.py:45-48, 199-211)
+        from rcognita_amd.pool import preset_engine_config
+
+        return preset_engine_config("2tank", batch, Nactor=args.nactor, dtype=dtype or args.dtype, device=device,
+                                    env_id_base=env_id_base, **C3_KW), np.array([[0.0, 1.0]])
 
     bnds = np.array([[-300.0, 300.0], [-100.0, 100.0]])  # presets/main_3wrobot.py:207-211
     R1 = np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0])  # presets/main_3wrobot.py R1_diag default
@@ -172,19 +184,28 @@ def c2_oracle_cfg(args):
 
     from oracle import rcg_oracle as O
 
+    if args.config == "C3":
+        return O.OracleCfg(sys_id=O.SYS_2TANK, n_actor=args.nactor, pars=[18.4, 24.4, 1.3, 1.0, 0.2],
+                           ctrl_bnds=np.array([[0.0, 1.0]]), R1=np.diag([10.0, 10.0, 1.0]), target=[0.5, 0.5],
+                           mode=O.MODE_RQL, critic_struct=O.CRITIC_QUADRATIC, n_critic=4, buffer_size=10, gamma=1.0,
+                           dt_sim=0.1, sampling_time=0.1, pred_step_size=0.2)
+
     bnds = np.array([[-300.0, 300.0], [-100.0, 100.0]])
     return O.OracleCfg(sys_id=O.SYS_3WROBOT, n_actor=args.nactor, pars=[10.0, 1.0], ctrl_bnds=bnds,
                        R1=np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0]), gamma=1.0, dt_sim=0.01, sampling_time=0.01,
                        pred_step_size=0.02)
 
 
-def synth_state(seed, lo, hi):
-    """x,y ~ U(-10,10), alpha ~ U(-pi,pi), v, omega ~ U(-1,1); the job's env g always gets the same
-    state whatever the number of ranks (generated for the whole job, sliced to this rank's [lo, hi))."""
+def synth_state(seed, lo, hi, config="C2"):
+    """x,y ~ U(-10,10), alpha ~ U(-pi,pi), v, omega ~ U(-1,1) (C3: h1 ~ U(0,2), h2 ~ U(-2,2)); the job's env
+    g always gets the same state whatever the number of ranks (generated for the whole job, sliced to this rank's
+    [lo, hi))."""
     import numpy as np
 
     rng = np.random.default_rng(seed)
     n = hi
+    if config == "C3":
+        return np.stack([rng.uniform(0, 2, n), rng.uniform(-2, 2, n)], axis=-1)[lo:hi]
     x = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-np.pi, np.pi, n),
                   rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], axis=-1)
     return x[lo:hi]
@@ -292,11 +313,17 @@ def parity_check(args, device, stream_ptr, x0, cand, K, tol=1e-5, n_sample=64, t
         cand_host = O.grid_candidates(ocfg, K)
     rep = PAR.TickReport()
     tol = tol if args.dtype == "f32" else 1e-11
+    critic = args.config == "C3"
+    if critic:
+        ticks = 14  # past the point where the buffers (10 rows) have filled: the TD fits are non-trivial from tick 8 on
+    # critic weights solve a least-squares problem regularised at 1e-8 of its scale: float64 at 1e-6 per tick
+    over = {"w_critic": 1e-6, "best_J": 1e-7} if (critic and args.dtype == "f64") else None  # (as tests/test_hip_critic.py)
     try:
         for t in range(ticks):
             eng.control_tick(cand, K=K)
-            dev = {k: v[sel] for k, v in PAR.device_fields(eng, N).items()}
-            env = PAR.check_tick(ocfg, env, cand_host, dev, tol=tol, report=rep, what=f"bench parity tick {t}")
+            dev = {k: v[sel] for k, v in PAR.device_fields(eng, N, critic=critic).items()}
+            env = PAR.check_tick(ocfg, env, cand_host, dev, tol=tol, report=rep, what=f"bench parity tick {t}",
+                                 tol_over=over)
         out = {"ok": True, "tol": tol, **rep.as_dict()}
     except AssertionError as e:
         out = {"ok": False, "tol": tol, "error": str(e)[:500], **rep.as_dict()}
@@ -425,17 +452,17 @@ def main(argv=None):
         ecfg, bnds = c2_engine_config(args, local_rank, B, env_id_base=lo)
         eng = Engine(ecfg)
         eng.set_stream(stream_ptr)
-        x0 = synth_state(1234, lo, hi)
+        x0 = synth_state(1234, lo, hi, args.config)
         eng.set_state(x0)
         if streamed:
             g = torch.Generator(device="cuda")
             g.manual_seed(1234 + rank)
             blo = torch.tensor(bnds[:, 0], device="cuda", dtype=tdtype)
             bhi = torch.tensor(bnds[:, 1], device="cuda", dtype=tdtype)
-            cand = (torch.rand((B, K, Nh, 2), generator=g, device="cuda", dtype=tdtype) * (bhi - blo) + blo).contiguous()
+            cand = (torch.rand((B, K, Nh, eng.du), generator=g, device="cuda", dtype=tdtype) * (bhi - blo) + blo).contiguous()
         engines = [eng]
         tick = lambda: eng.control_tick(cand, K=K)
-    du, ds = 2, 5
+    du, ds = (1, 2) if args.config == "C3" else (2, 5)
 
     # ---- untimed: clock pre-spin (>= PRESPIN_S of the same kernels), then the W warm-up steps ------------------------
     # The GPU reaches its steady clock after ~100 ticks (20 ms) of CONTINUOUS work and falls back within 10 ms of idling
@@ -542,6 +569,8 @@ def main(argv=None):
         bytes_launch = sum(actor_bytes_per_launch(e.B, K, Nh, e.du, e.ds, esz, False) for e in engines)
     else:
         bytes_launch = actor_bytes_per_launch(B, K, Nh, du, ds, esz, streamed)
+        if args.config == "C3":
+            bytes_launch += B * engines[0].dc * esz  # the env's critic weights travel with its state
     actor_avg_s = (actor_ms / max(actor_n, 1)) * 1e-3
     if args.config == "C5":
         # one launch per segment, on streams of their own: the launches overlap, so the per-tick figure is the wall time of
@@ -557,10 +586,13 @@ def main(argv=None):
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "                           "stored; not re-measured in this run)"
         except Exception:
             traffic = None
-    dma = streamed and K % 64 == 0 and args.config != "C5" and Nh * 2 <= 40
+    dma = (streamed and K % 64 == 0 and args.config != "C5" and Nh * du <= 40 and
+           (args.dtype == "f32" or args.config != "C3"))  # (f64 critic modes run on the generic kernel)
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
               "candidates (BASELINE configs[1])",
+        "C3": f"Sys2Tank B={args.batch}/GPU RK4 dt=0.1 S=1, CtrlOptPred RQL Nactor={Nh} + quadratic critic TD fit every tick "
+              f"(Ncritic=4, buffer 10), K={K} {args.regime} candidates (BASELINE configs[2])",
         "C4": f"Sys3WRobot {total_envs} envs sharded over {world} rank(s), RK4 dt=0.01, MPC Nactor={Nh}, K={K} "
               f"{args.regime} candidates, all_gather of episode returns (BASELINE configs[3])",
         "C5": f"mixed pool 3wrobot+3wrobot_NI+2tank, {total_envs} envs over {world} rank(s) sharded within each type, "
@@ -609,13 +641,19 @@ def main(argv=None):
         for e in engines:
             name = {N.SYS_3WROBOT: "3wrobot", N.SYS_3WROBOT_NI: "3wrobotNI", N.SYS_2TANK: "2tank"}[int(e.cfg.sys_id)]
             key = (f"k_actor_generated_{name}_N{Nh}_{args.dtype}_C5" if args.config == "C5"
-                   else f"k_actor_generated_{name}_N{Nh}_{args.dtype}")
+                   else (f"k_actor_generated_{name}_N{Nh}_RQL_{args.dtype}" if args.config == "C3"
+                         else f"k_actor_generated_{name}_N{Nh}_{args.dtype}"))
             ipe = valu_instr_per_eval(key)
             if not ipe:
                 missing = True
                 break
             lane_instr += e.B * K * ipe["valu_instr_per_eval"]
         hbm = dict(out["roofline"])
+        if missing:  # no stored instruction count for this shape: say so instead of pricing a VALU-bound kernel in bytes
+            out["roofline"].update(bound="valu", achieved=None, frac=None, unit="lane-instr/s", peak=VALU_PEAK,
+                                   note="generated regime is VALU-bound; no SQ_INSTS_VALU pass is stored for this shape "
+                                        "(tools/valu_probe.py + tools/prof_summary.py --valu)",
+                                   hbm_frac_for_completeness=hbm["frac"])
         if not missing and actor_avg_s > 0:
             out["roofline"] = {"bound": "valu", "kernel": "k_actor (generated level grid)",
                                "achieved": lane_instr / actor_avg_s, "peak": VALU_PEAK, "unit": "lane-instr/s",

@@ -20,7 +20,7 @@ def _run(argv, env_extra=None, timeout=300):
 
 
 @pytest.mark.parametrize("n,extra,total", [(2, [], 2 * 65536), (3, ["--scaling", "strong", "--batch", "100"], 100),
-                                           (2, ["--config", "C4"], 524288)])
+                                           (2, ["--config", "C4"], 524288), (2, ["--config", "C3"], 2 * 131072)])
 def test_gpus_n_spawns_n_ranks_that_tile_the_job(n, extra, total):
     out = _run(["--gpus", str(n), "--dry-launch"] + extra)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -165,6 +165,21 @@ def valu_summary(a):
             t[f"k_actor_generated_{key}_N15_f32_C5"] = {
                 "valu_instr_per_eval": d["SQ_INSTS_VALU_per_launch"] * 64 / uu["evals"], "round": a.round, "kernel": k,
                 "launches": d["launches"]}
+    # configs[2] generated (2tank, N = 20): MPC on the specialised instance, RQL / SQL on the generic one - priced only from a
+    # pass in which the instance ran ONE of them (valu_probe.py c3rql / c3sql), recognised by the launch count
+    launches_each = 0
+    if a.valu_units and os.path.exists(a.valu_units):
+        for line in open(a.valu_units):
+            if line.startswith("{"):
+                launches_each = json.loads(line).get("launches_each", 0)
+    for mode, gen in (("MPC", "false"), ("RQL", "true"), ("SQL", "true")):
+        key = f"k_actor_generated_2tank_N20_{mode}_f32"
+        uu = units.get(key)
+        hh = [(k, d) for k, d in per.items() if k.startswith(f"rcg::k_actor<rcg::Sys2Tank, float, {gen}, true, false>")]
+        if uu and hh and hh[0][1]["launches"] == launches_each:
+            k, d = hh[0]
+            t[key] = {"valu_instr_per_eval": d["SQ_INSTS_VALU_per_launch"] * 64 / uu["evals"], "round": a.round, "kernel": k,
+                      "launches": d["launches"]}
     hit = [(k, d) for k, d in per.items() if k.startswith("rcg::k_actor<rcg::Sys3WRobot, float, false, false, false>")]
     u = units.get("k_actor_generated_3wrobot_N10_f32")
     if t:

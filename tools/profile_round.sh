@@ -5,6 +5,8 @@
 #   python tools/prof_summary.py --round r02 --kt gpurun_out/prof_kt --fetch gpurun_out/prof_fetch \
 #       --write gpurun_out/prof_write --key k_actor_streamed_B65536_K256_N10_f32 \
 #       --valu gpurun_out/prof_valu --valu-units gpurun_out/valu_units.json          # back in the build container
+#   python tools/prof_summary.py --round r02_pool --valu gpurun_out/prof_valu_pool --valu-units gpurun_out/valu_units_pool.json
+#   python tools/prof_summary.py --round r02_c3rql --valu gpurun_out/prof_valu_c3rql --valu-units gpurun_out/valu_units_c3rql.json
 #   python tools/prof_summary.py --round r02 --tag configs --kt gpurun_out/prof_kt_configs
 #
 # Passes (MI355X_MICROARCH.md, HBM / rocprofv3 section): the kernel trace of the SAME command the bench line comes from,
@@ -28,6 +30,8 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu -
   python3 tools/valu_probe.py main > gpurun_out/valu_units.json 2> gpurun_out/prof_valu.log
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu_pool -o v -- \
   python3 tools/valu_probe.py pool > gpurun_out/valu_units_pool.json 2> gpurun_out/prof_valu_pool.log
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu_c3rql -o v -- \
+  python3 tools/valu_probe.py c3rql > gpurun_out/valu_units_c3rql.json 2> gpurun_out/prof_valu_c3rql.log
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_configs -o kt -- \
   python3 tools/bench_configs.py > "gpurun_out/bench_configs_${ROUND}_profiled.json" 2> gpurun_out/prof_kt_configs.log
 python tools/bench_configs.py > "gpurun_out/bench_configs_${ROUND}.json" 2> gpurun_out/bench_configs.err

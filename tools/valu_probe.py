@@ -38,7 +38,7 @@ def main():
 
     rng = np.random.default_rng(1234)
     n = int(os.environ.get("VALU_PROBE_LAUNCHES", "6"))
-    part = sys.argv[1] if len(sys.argv) > 1 else "main"  # "pool": configs[4] alone (it re-uses kernel instances of "main")
+    part = sys.argv[1] if len(sys.argv) > 1 else "main"  # "pool": configs[4] alone (it re-uses kernel instances of "main"); "c3rql" / "c3sql"
     units = {}
     if part == "pool":
         total = 65536
@@ -51,6 +51,20 @@ def main():
         for s in pool.segments:
             units[f"k_actor_generated_{s.name}_N15_f32_C5"] = {"evals": (s.hi - s.lo) * 256, "envs": s.hi - s.lo}
         pool.close()
+        print(json.dumps({"launches_each": n, "units_per_launch": units}))
+        return
+
+    if part in ("c3rql", "c3sql"):  # configs[2] generated, ONE critic mode (RQL and SQL share a kernel instance)
+        mode = part[2:].upper()
+        B3, K = 131072, 256
+        kw = dict(Nactor=20, mode=mode, critic_struct="quadratic", Ncritic=4, buffer_size=10)
+        e = Engine(preset_engine_config("2tank", B3, **kw))
+        e.set_state(states(rng, "2tank", B3))
+        for _ in range(n):
+            e.control_tick(None, K=K)
+        e.synchronize()
+        units[f"k_actor_generated_2tank_N20_{mode}_f32"] = {"evals": B3 * K, "envs": B3}
+        e.close()
         print(json.dumps({"launches_each": n, "units_per_launch": units}))
         return
 
