@@ -38,6 +38,13 @@
 #pragma once
 #include "rcg_kernels.hpp"
 
+// cache policy of the direct-to-LDS tile loads (the aux / cpol immediate of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1):
+// the candidate tensor is read once per tick -> nt.  Measured on C2 (tools/knob_sweep.py against libraries built with
+// -DRCG_DMA_AUX=...): see DESIGN.md 4.
+#ifndef RCG_DMA_AUX
+#define RCG_DMA_AUX 2
+#endif
+
 namespace rcg {
 
 // Variants of the cost accumulation, one kernel instance each (the horizon is unrolled, so each is straight-line code):
@@ -130,11 +137,11 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
 #pragma unroll
     for (int j = 0; j < NFULL; ++j)
       __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0,
-                                       2 /* nt */);
+                                       RCG_DMA_AUX);
 #pragma unroll
     for (int j = 0; j < NREM; ++j)
       __builtin_amdgcn_global_load_lds((glb_void*)(g + NFULL * 1024 + j * 256 + lane * 4),
-                                       (lds_void*)(tile + NFULL * 1024 + j * 256), 4, 0, 2 /* nt */);
+                                       (lds_void*)(tile + NFULL * 1024 + j * 256), 4, 0, RCG_DMA_AUX);
   };
 
   // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
