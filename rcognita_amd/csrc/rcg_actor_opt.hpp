@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
         real d[DS];
         // f32: hardware v_sin/v_cos behind the exact reduction, as in every f32 rollout of the build (the 64 trial
         // rollouts of the line search are where this kernel spends its instructions)
-        Sys::template rhs<real, std::is_same<real, float>::value>(pre, x, up, d);
+        Sys::template rhs<real, true>(pre, x, up, d);
 #pragma unroll
         for (int c = 0; c < DS; ++c) {
           x[c] = fma_r(h, d[c], x[c]);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
         for (int c = 0; c < DU; ++c) u[c] = ue[(k - 1) * DU + c];
         // f32: the hardware-trig rollout every cost evaluation of this kernel uses, so that the gradient is the gradient
         // of the function the line search evaluates (and a third of phase 1's instructions go away)
-        Sys::template rhs<real, std::is_same<real, float>::value>(pre_e, x, u, d);
+        Sys::template rhs<real, true>(pre_e, x, u, d);
 #pragma unroll
         for (int c = 0; c < DS; ++c) {
           x[c] = fma_r(h, d[c], x[c]);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
         real lamk[DS];
         if (k < N - 1) {
           real ax[DS], bu[DU];
-          Sys::template jac_T<real, std::is_same<real, float>::value>(pre_e, xk, u, lam, ax, bu);
+          Sys::template jac_T<real, true>(pre_e, xk, u, lam, ax, bu);
 #pragma unroll
           for (int c = 0; c < DU; ++c) g[c] = fma_r(h, bu[c], g[c]);
 #pragma unroll

@@ -351,7 +351,7 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
       real d[DS];
       // unclipped, as sys_rhs([], state, u[k-1]); f32: hardware v_sin/v_cos behind the exact reduction, as in
       // k_actor_dma (3.7e-7 max abs error, 7 VALU ops instead of ~25: the generated-candidate regime is VALU-bound)
-      Sys::template rhs<real, std::is_same<real, float>::value>(pre, x, up, d);
+      Sys::template rhs<real, true>(pre, x, up, d);
 #pragma unroll
       for (int c = 0; c < DS; ++c) {
         x[c] = fma_r(h, d[c], x[c]);
@@ -491,7 +491,7 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         real d[DS];
-        Sys::template rhs<real, std::is_same<real, float>::value>(pre, x[c], u[c], d);  // unclipped (controllers.py:1294)
+        Sys::template rhs<real, true>(pre, x[c], u[c], d);  // unclipped (controllers.py:1294)
 #pragma unroll
         for (int i = 0; i < DS; ++i) {
           x[c][i] = fma_r(h, d[i], x[c][i]);

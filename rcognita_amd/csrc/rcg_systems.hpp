@@ -3,9 +3,9 @@
 // Each policy gives the dimensions and the open-loop right-hand side `Sys*._state_dyn` of the
 // reference (disturbance-free branch; is_disturb = 0 in every preset).
 // `Pre` holds per-env values derived once from the parameter vector (e.g. 1/m), so the rollout's
-// inner loop does no divisions.  `rhs<real, HW>`: HW = true selects the hardware sin/cos form
-// (rcg_math.hpp, f32 only) used by the streamed rollout fast path; everything else - the simulator's
-// RK4 in particular - uses the accurate polynomial form.
+// inner loop does no divisions.  `rhs<real, HW>`: HW = true selects the rollouts' trig (rcg_math.hpp: f32 hardware
+// v_sin / v_cos behind an exact reduction, f64 Cody-Waite + minimax polynomials, 2.3e-16) - every Euler rollout of
+// _actor_cost, streamed, generated or inside the optimiser; the simulator's RK4 uses the accurate forms (f64: libm).
 #pragma once
 #include "rcg_math.hpp"
 
