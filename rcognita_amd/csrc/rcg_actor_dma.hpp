@@ -1,7 +1,9 @@
 // rcg_actor_dma.hpp - k_actor_dma: the production kernel of the streamed rollout
 // (CtrlOptPred._actor_cost for K candidates per env + argmin + tick epilogue; controllers.py:1273-1427).
 //
-// Shape it serves: diagonal quadratic stage cost (every reference preset), K a multiple of 64, the observation target as
+// Shape it serves: diagonal quadratic stage cost (every reference preset), K >= 64 and a multiple of 4 (an env's last
+// tile may be ragged: its direct-to-LDS loads are masked per lane, so not a byte beyond the env's rows is read, and the lanes
+// without a row sit out the argmin), the observation target as
 // the system's preset has it; the rollout starts from `state_sys` with `obs` as y_0 (controllers.py:1286-1296) - the same
 // vector in the plain tick, the state before the last substep with RCG_FLAG_REF_LAG (the reference's loop order);
 // candidate rows of R = N*du <= 40 reals; f32: modes MPC, RQL and SQL; f64 (the reference's own arithmetic width):
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
   const long B = P.B;
   const int K = A.K;
-  const int T = K >> 6;  // tiles per env
+  const int T = (K + 63) >> 6;   // tiles per env
+  const int rem_rows = K & 63;   // rows of an env's LAST tile (0: it is full); K % 4 == 0, so whole 16-byte pieces
   const long env0 = wave * A.gpw;
   if (env0 >= B) return;
   const long env1 = env0 + A.gpw < B ? env0 + A.gpw : B;
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   const int n_tiles = (int)(env1 - env0) * T;
 
   unsigned char* const tile = smem_raw + (size_t)wave_in_wg * TILE;  // this wave's LDS tile
-  const unsigned char* gb = reinterpret_cast<const unsigned char*>(A.cand) + (size_t)env0 * K * (R * ESZ);
+  const size_t env_stride = (size_t)K * (R * ESZ);                    // bytes of one env's rows
+  const unsigned char* envb = reinterpret_cast<const unsigned char*>(A.cand) + (size_t)env0 * env_stride;  // env b's rows
   // operator mode (rcg_actor_cost): the J of one env is staged in LDS ([K] reals per wave, behind the tiles of all
   // four waves) and written out at the env's end in 1-KiB bursts; a 256-B store after every tile, interleaved with
   // the read stream, made the operator 35 % slower than the tick for 5 % more bytes
@@ -133,16 +137,34 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   const int jspan = A.jwave ? A.gpw * K : K;  // reals of staging per wave
   real* const jstage = reinterpret_cast<real*>(smem_raw + (size_t)4 * TILE) + (size_t)wave_in_wg * jspan;
 
-  auto issue_tile = [&](const unsigned char* g) {
+  // `rows` (wave-uniform): 64, or rem_rows for an env's ragged last tile - then every lane loads only pieces that lie
+  // inside the env's rows (rows * R * ESZ bytes, a multiple of 16), the rest of the LDS tile keeps stale rows that no
+  // valid candidate index points at
+  auto issue_tile = [&](const unsigned char* g, int rows) {
+    if (rows == 64) {
 #pragma unroll
-    for (int j = 0; j < NFULL; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0,
-                                       RCG_DMA_AUX);
+      for (int j = 0; j < NFULL; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0,
+                                         RCG_DMA_AUX);
 #pragma unroll
-    for (int j = 0; j < NREM; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void*)(g + NFULL * 1024 + j * 256 + lane * 4),
-                                       (lds_void*)(tile + NFULL * 1024 + j * 256), 4, 0, RCG_DMA_AUX);
+      for (int j = 0; j < NREM; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)(g + NFULL * 1024 + j * 256 + lane * 4),
+                                         (lds_void*)(tile + NFULL * 1024 + j * 256), 4, 0, RCG_DMA_AUX);
+    } else {
+      const int vb = rows * (R * ESZ);  // valid bytes of the tile
+#pragma unroll
+      for (int j = 0; j < NFULL; ++j)
+        if (j * 1024 + lane * 16 < vb)
+          __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0,
+                                           RCG_DMA_AUX);
+#pragma unroll
+      for (int j = 0; j < NREM; ++j)
+        if (NFULL * 1024 + j * 256 + lane * 4 < vb)
+          __builtin_amdgcn_global_load_lds((glb_void*)(g + NFULL * 1024 + j * 256 + lane * 4),
+                                           (lds_void*)(tile + NFULL * 1024 + j * 256), 4, 0, RCG_DMA_AUX);
+    }
   };
+  auto rows_of = [&](int tt) -> int { return (tt == T - 1 && rem_rows) ? rem_rows : 64; };
 
   // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
   // "pointer ? load : default" selects (a default written into a register with a load in flight would force a
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   };
 
   fetch_env(env0);
-  issue_tile(gb);  // after the env request: retiring the env state must not drain the first tile
+  issue_tile(envb, rows_of(0));  // after the env request: retiring the env state must not drain the first tile
 
   const real h = P.h_pred;
   long b = env0;
@@ -221,10 +243,14 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane's row is out of LDS (in-order per wave)
     __builtin_amdgcn_wave_barrier();
     // 3. the LDS tile is free: request tile g + 1 into it, an env-state request first if it opens an env
-    gb += TILE;
     if (g + 1 < n_tiles) {
-      if (t == T - 1) fetch_env(b + 1);
-      issue_tile(gb);
+      if (t == T - 1) {
+        fetch_env(b + 1);
+        envb += env_stride;
+        issue_tile(envb, rows_of(0));
+      } else {
+        issue_tile(envb + (size_t)(t + 1) * TILE, rows_of(t + 1));
+      }
     }
 
     // 4. _actor_cost of this lane's row (controllers.py:1284-1326), registers only
@@ -277,9 +303,10 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
     }
 
     const int k = t * 64 + lane;
-    if (A.J) jstage[(A.jwave ? (int)(b - env0) * K : 0) + k] = J;
+    const bool has_row = k < K;  // false only in a ragged last tile
+    if (A.J && has_row) jstage[(A.jwave ? (int)(b - env0) * K : 0) + k] = J;
     const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
-    if (Jc < bestJ || bestI == 0x7fffffff) {
+    if (has_row && (Jc < bestJ || bestI == 0x7fffffff)) {
       bestJ = Jc;
       bestI = k;
 #pragma unroll

@@ -108,8 +108,8 @@ def test_mixed_pool_C5_shard(world, rank):
     pool.close()
 
 
-@pytest.mark.parametrize("B", [32773, 65536 + 9])
-def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B):
+@pytest.mark.parametrize("B,K", [(32773, 64), (65536 + 9, 64), (32773, 100)])
+def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B, K):
     """Production kernel geometry: for B >= 16384 a wave owns several consecutive envs and writes their results once,
     coalesced; B is chosen so that the LAST wave owns fewer envs than the others.  Every env of the batch against the
     float64 oracle (streamed candidates shared by all envs), integer fields exact."""
@@ -117,7 +117,7 @@ def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B):
     from rcognita_amd.pool import preset_engine_config
 
     rng = np.random.default_rng(B)
-    K, Nh, T = 64, 5, 2
+    Nh, T = 5, 2  # (K = 100: every env's second tile is ragged, 36 rows - masked loads, env rows no longer tile-aligned)
     eng = Engine(preset_engine_config("3wrobot", B, Nactor=Nh))
     x0 = rand_states(rng, "3wrobot", B).astype(np.float32)
     eng.set_state(x0)

@@ -228,10 +228,12 @@ def test_actor_cost_and_argmin_vs_oracle(name, N, K, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("K", [130, 128, 256])
+@pytest.mark.parametrize("K", [130, 128, 256, 132, 196])
 def test_argmin_ties_and_nan(dtype, K):
     """Lower index wins ties; NaN costs count as +inf; an all-NaN env returns index 0.  K = 130: the generic kernel
-    (ragged last tile); K = 128, 256: the production kernel's DPP (f32) / shuffle (f64) wave argmin."""
+    (ragged last tile, K not a multiple of 4); K = 128, 256: the production kernel's DPP (f32) / shuffle (f64) wave
+    argmin; K = 132, 196: the production kernel with a ragged last tile (4 rows: masked direct-to-LDS loads, 60 lanes
+    without a row sit out the argmin - including the LAST env of the tensor, whose tile ends at the allocation's end)."""
     name, N, B = "3wrobot", 5, 4
     rng = np.random.default_rng(5)
     eng, cfg = both(name, B, dtype, n_actor=N)
@@ -251,6 +253,14 @@ def test_argmin_ties_and_nan(dtype, K):
     assert np.isnan(J[1, 5]) and bi[1] != 5
     assert bi[2] == 0 and np.isinf(bj[2])
     assert J[0, 3] == J[0, 77] == J[0, 100]
+    # the last env of the tensor (its ragged tile must not read past the rows): a unique winner in its LAST row
+    cand2 = cand.copy()
+    cand2[2] = cand[3]
+    cand2[3, K - 1] = 0.0
+    act, bj, bi = eng.actor_argmin(cand2)
+    J2 = eng.actor_cost(cand2)
+    np.testing.assert_array_equal(bi, np.argmin(np.where(np.isnan(J2), np.inf, J2), axis=1).astype(np.int32))
+    np.testing.assert_array_equal(bj, J2[np.arange(B), bi])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
