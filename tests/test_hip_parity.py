@@ -228,6 +228,30 @@ def test_actor_cost_and_argmin_vs_oracle(name, N, K, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode,cs", [("MPC", "quad-nomix"), ("RQL", "quad-mix"), ("SQL", "quadratic")])
+def test_tank_without_a_target_on_the_production_kernel(mode, cs, dtype):
+    """Sys2Tank's production instances subtract the observation target; a handle WITHOUT one (the reference's
+    observation_target == []) runs on them with a target of zeros - y - 0 = y exactly - and must equal the oracle with
+    no target (the critic's quad-mix features use the raw observation either way, controllers.py:1212)."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(77)
+    B, K, Nh = 6, 128, 9
+    eng, cfg = both("2tank", B, dtype, n_actor=Nh, target=None, mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs],
+                    gamma=0.97, buffer_size=4)
+    assert cfg.target is None
+    x = rand_states(rng, "2tank", B)
+    cand = rand_actions(rng, "2tank", (B, K, Nh))
+    w = rng.uniform(0.1, 2.0, (B, cfg.dc))
+    eng.set_state(x)
+    if mode != "MPC":
+        eng.set_field(N.FIELD_W_CRITIC, w)
+    J = eng.actor_cost(eng.to_device(cand.astype(eng.real)))
+    J_or = O.actor_cost(cand, x[:, None, :], x[:, None, :], cfg, w_critic=w[:, None, :] if mode != "MPC" else None)
+    _close(J, J_or, dtype, msg=f"no-target tank {mode}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K", [130, 128, 256, 132, 196])
 def test_argmin_ties_and_nan(dtype, K):
     """Lower index wins ties; NaN costs count as +inf; an all-NaN env returns index 0.  K = 130: the generic kernel
