@@ -144,15 +144,38 @@ def critic_bounds(critic_struct: str):
 
 
 class DeviceArray:
-    """A raw HBM allocation made through the C ABI (no torch needed)."""
+    """A raw HBM allocation made through the C ABI (no torch needed).
 
-    def __init__(self, engine: "Engine", shape, dtype):
+    ``scratch=True`` marks the engine's own temporaries (uploaded inputs and output buffers of one call): small ones are
+    returned to a per-engine free list instead of hipFree'd - at B = 1 the drop-in classes made 12 allocations per
+    simulation step, a fifth of the step's wall time.  Safe because a scratch array is only ever touched on its engine's
+    stream (rcg_memcpy_* are stream-ordered), so a reused buffer is written after the kernel that last read it."""
+
+    POOL_MAX_ARRAY = 1 << 20   # larger temporaries go back to the driver at once
+    POOL_MAX_TOTAL = 16 << 20  # per engine
+
+    def __init__(self, engine: "Engine", shape, dtype, scratch=False):
         self.engine = engine
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
-        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        n = 1
+        for v in self.shape:
+            n *= v
+        self.nbytes = n * self.dtype.itemsize
+        self.scratch = bool(scratch)
+        self._cap = 0
+        if self.scratch and self.nbytes <= self.POOL_MAX_ARRAY:
+            cap = 256
+            while cap < self.nbytes:
+                cap <<= 1
+            self._cap = cap
+            free = engine._pool.get(cap)
+            if free:
+                self.ptr = free.pop()
+                engine._pool_bytes -= cap
+                return
         p = C.c_void_p()
-        N.check(N.lib().rcg_dev_alloc(engine._h, max(self.nbytes, 16), C.byref(p)), engine._h)
+        N.check(N.lib().rcg_dev_alloc(engine._h, max(self._cap, self.nbytes, 16), C.byref(p)), engine._h)
         self.ptr = p.value
 
     def upload(self, arr):
@@ -169,8 +192,13 @@ class DeviceArray:
         return out
 
     def free(self):
-        if self.ptr and self.engine._h:
-            N.lib().rcg_dev_free(self.engine._h, self.ptr)
+        e = self.engine
+        if self.ptr and e._h:
+            if self._cap and e._pool_bytes + self._cap <= self.POOL_MAX_TOTAL:
+                e._pool.setdefault(self._cap, []).append(self.ptr)
+                e._pool_bytes += self._cap
+            else:
+                N.lib().rcg_dev_free(e._h, self.ptr)
         self.ptr = None
 
     def __del__(self):
@@ -190,6 +218,7 @@ class Engine:
     def __init__(self, cfg: EngineConfig):
         self.cfg = cfg
         self._h = None
+        self._pool, self._pool_bytes = {}, 0  # free list of small scratch allocations, by capacity (DeviceArray)
         L = N.lib()
         self.ds, self.du, self.npar = N.SYS_DIMS[cfg.sys_id]
         self.dd = N.DIM_DISTURB[int(cfg.sys_id)]
@@ -209,6 +238,10 @@ class Engine:
     # ------------------------------------------------------------------ life cycle
     def close(self):
         if self._h:
+            for ptrs in self._pool.values():
+                for p in ptrs:
+                    N.lib().rcg_dev_free(self._h, p)
+            self._pool, self._pool_bytes = {}, 0
             N.lib().rcg_destroy(self._h)
             self._h = None
 
@@ -231,6 +264,10 @@ class Engine:
     # ------------------------------------------------------------------ device memory
     def empty(self, shape, dtype=None) -> DeviceArray:
         return DeviceArray(self, shape, self.real if dtype is None else dtype)
+
+    def _tmp(self, shape, dtype=None) -> DeviceArray:
+        """Output buffer of ONE call of this engine (pooled, see DeviceArray)."""
+        return DeviceArray(self, shape, self.real if dtype is None else dtype, scratch=True)
 
     def to_device(self, arr, dtype=None) -> DeviceArray:
         a = np.ascontiguousarray(arr, dtype=self.real if dtype is None else dtype)
@@ -278,7 +315,8 @@ class Engine:
         a = np.asarray(x, dtype=self.real)
         if soa_from is not None:
             a = soa_from(a)
-        d = self.to_device(a)
+        a = np.ascontiguousarray(a, dtype=self.real)
+        d = DeviceArray(self, a.shape, a.dtype, scratch=True).upload(a)
         keep.append(d)
         return C.c_void_p(d.ptr)
 
@@ -352,7 +390,7 @@ class Engine:
         keep = []
         ps = self._in(state, keep, lambda a: a.T)
         pa = self._in(action, keep, lambda a: a.T)
-        d, ca = self.empty((self.ds, n)), self.empty((self.du, n))
+        d, ca = self._tmp((self.ds, n)), self._tmp((self.du, n))
         N.check(N.lib().rcg_rhs(self._h, ps, pa, C.c_void_p(d.ptr), C.c_void_p(ca.ptr), n, 1 if clip else 0), self._h)
         return d.to_host().T.copy(), ca.to_host().T.copy()
 
@@ -366,14 +404,14 @@ class Engine:
         n = state.shape[0]
         keep = []
         ptrs = [self._in(a, keep, lambda v: v.T) for a in (state, disturb, action, xi)]
-        d, dq, ca = self.empty((self.ds, n)), self.empty((self.dd, n)), self.empty((self.du, n))
+        d, dq, ca = self._tmp((self.ds, n)), self._tmp((self.dd, n)), self._tmp((self.du, n))
         N.check(N.lib().rcg_rhs_full(self._h, *ptrs, C.c_void_p(d.ptr), C.c_void_p(dq.ptr), C.c_void_p(ca.ptr), n,
                                      1 if clip else 0), self._h)
         return d.to_host().T.copy(), dq.to_host().T.copy(), ca.to_host().T.copy()
 
     def disturb_noise(self):
         """What the next ``sim_step`` substep will draw: ``(bits [B, 4] uint32, xi [B, 2])`` (rcg_disturb_noise)."""
-        bits, xi = self.empty((4, self.B), np.uint32), self.empty((2, self.B))
+        bits, xi = self._tmp((4, self.B), np.uint32), self._tmp((2, self.B))
         N.check(N.lib().rcg_disturb_noise(self._h, C.c_void_p(bits.ptr), C.c_void_p(xi.ptr)), self._h)
         return bits.to_host().T.copy(), xi.to_host().T.copy()
 
@@ -382,7 +420,7 @@ class Engine:
         act = np.asarray(act, dtype=self.real).reshape(-1, self.du)
         n = obs.shape[0]
         keep = []
-        out = self.empty((n,))
+        out = self._tmp((n,))
         N.check(N.lib().rcg_stage_obj(self._h, self._in(obs, keep, lambda a: a.T), self._in(act, keep, lambda a: a.T),
                                       C.c_void_p(out.ptr), n), self._h)
         return out.to_host()
@@ -393,7 +431,7 @@ class Engine:
         w = np.asarray(w, dtype=self.real).reshape(-1, self.dc)
         n = obs.shape[0]
         keep = []
-        out = self.empty((n,))
+        out = self._tmp((n,))
         N.check(N.lib().rcg_critic(self._h, self._in(obs, keep, lambda a: a.T), self._in(act, keep, lambda a: a.T),
                                    self._in(w, keep, lambda a: a.T), C.c_void_p(out.ptr), n), self._h)
         return out.to_host()
@@ -423,7 +461,7 @@ class Engine:
         """``_actor_cost`` of every candidate: ``cand [B, K, N, du]`` -> ``J [B, K]``."""
         keep = []
         pc, K = self._cand(cand, keep)
-        J = self.empty((self.B, K))
+        J = self._tmp((self.B, K))
         N.check(N.lib().rcg_actor_cost(self._h, pc, K, self._in_soa(obs, keep, self.dy, "obs"),
                                        self._in_soa(state_sys, keep, self.ds, "state_sys"),
                                        self._in_soa(w, keep, self.dc, "w"), C.c_void_p(J.ptr)), self._h)
@@ -431,7 +469,7 @@ class Engine:
 
     def critic_cost(self, w=None):
         keep = []
-        Jc = self.empty((self.B,))
+        Jc = self._tmp((self.B,))
         N.check(N.lib().rcg_critic_cost(self._h, self._in_soa(w, keep, self.dc, "w"), C.c_void_p(Jc.ptr)), self._h)
         return Jc.to_host()
 
@@ -445,7 +483,7 @@ class Engine:
         pc, K = self._cand(cand, keep, K)
         if K is None:
             raise ValueError("actor_argmin: K is required with generated candidates (cand=None)")
-        act, bj, bi = self.empty((self.du, self.B)), self.empty((self.B,)), self.empty((self.B,), np.int32)
+        act, bj, bi = self._tmp((self.du, self.B)), self._tmp((self.B,)), self._tmp((self.B,), np.int32)
         N.check(N.lib().rcg_actor_argmin(self._h, pc, K, self._in_soa(obs, keep, self.dy, "obs"),
                                          self._in_soa(state_sys, keep, self.ds, "state_sys"),
                                          C.c_void_p(act.ptr), C.c_void_p(bj.ptr), C.c_void_p(bi.ptr)), self._h)
@@ -473,8 +511,8 @@ class Engine:
         keep = []
         pu = self._in(None if u_init is None else np.broadcast_to(
             np.asarray(u_init, dtype=self.real).reshape(-1, self.N, self.du), (self.B, self.N, self.du)), keep)
-        uo, act = self.empty((self.B, self.N, self.du)), self.empty((self.du, self.B))
-        bj, ni = self.empty((self.B,)), self.empty((self.B,), np.int32)
+        uo, act = self._tmp((self.B, self.N, self.du)), self._tmp((self.du, self.B))
+        bj, ni = self._tmp((self.B,)), self._tmp((self.B,), np.int32)
         N.check(N.lib().rcg_actor_optimize(self._h, int(iters), self._in_soa(obs, keep, self.dy, "obs"),
                                            self._in_soa(state_sys, keep, self.ds, "state_sys"), pu,
                                            C.c_void_p(uo.ptr), C.c_void_p(act.ptr), C.c_void_p(bj.ptr),
@@ -498,8 +536,8 @@ class Engine:
         obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)
         n = obs.shape[0]
         keep = []
-        act = self.empty((self.du, n))
-        lyap = self.empty((n,)) if want_lyap else None
+        act = self._tmp((self.du, n))
+        lyap = self._tmp((n,)) if want_lyap else None
         N.check(N.lib().rcg_nominal_action(self._h, self._in(obs, keep, lambda a: a.T), C.c_void_p(act.ptr),
                                            C.c_void_p(lyap.ptr) if want_lyap else None, n, float(ctrl_gain),
                                            self._ctrl_pars(ctrl_pars), 1 if clip else 0), self._h)
