@@ -320,9 +320,73 @@ class Engine:
         keep.append(d)
         return C.c_void_p(d.ptr)
 
+    def _soa_item(self, x, d, what):
+        """:meth:`_in_many` item for a per-env input ``[B, d]`` on the host / ``[d, B]`` on the device."""
+        return (x, lambda a: a.reshape(self.B, d).T, (d, self.B), what)
+
     def _in_soa(self, x, keep, d, what):
         """Per-env input ``[B, d]`` on the host, or ``[d, B]`` already on the device."""
         return self._in(x, keep, lambda a: a.reshape(self.B, d).T, dev_shape=(d, self.B), what=what)
+
+    # One host <-> device copy per direction and call: at B = 1 a synchronous copy costs 15-30 us whatever its size, and
+    # the reference's loop makes a dozen of them per simulation step through these methods.
+    def _in_many(self, items, keep):
+        """``items``: list of ``(x, soa_from, dev_shape, what)`` as for :meth:`_in`; host arrays travel in ONE upload."""
+        ptrs, host, total = [None] * len(items), [], 0
+        for i, (x, soa_from, dev_shape, what) in enumerate(items):
+            if x is None:
+                continue
+            if isinstance(x, DeviceArray) or _is_torch(x):
+                ptrs[i] = self._in(x, keep, soa_from, dev_shape, what)
+                continue
+            a = np.asarray(x, dtype=self.real)
+            if soa_from is not None:
+                a = soa_from(a)
+            a = np.ascontiguousarray(a)
+            host.append((i, total, a))
+            total += (a.nbytes + 255) & ~255
+        if host:
+            if len(host) == 1:
+                i, _, a = host[0]
+                d = DeviceArray(self, a.shape, a.dtype, scratch=True).upload(a)
+                ptrs[i] = C.c_void_p(d.ptr)
+            else:
+                blob = np.zeros(total, dtype=np.uint8)
+                for i, o, a in host:
+                    blob[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+                d = DeviceArray(self, (total,), np.uint8, scratch=True).upload(blob)
+                for i, o, a in host:
+                    ptrs[i] = C.c_void_p(d.ptr + o)
+            keep.append(d)
+        return ptrs
+
+    def _out_many(self, specs):
+        """``specs``: list of ``(shape, dtype)`` (None entries: output not wanted) -> (pointers, fetch): device buffers
+        carved from ONE scratch allocation; ``fetch()`` brings them back in ONE copy as host arrays."""
+        offs, total = [], 0
+        for sp in specs:
+            if sp is None:
+                offs.append(None)
+                continue
+            shape, dt = sp
+            n = int(np.prod(shape, dtype=np.int64)) * np.dtype(self.real if dt is None else dt).itemsize
+            offs.append((total, n))
+            total += (n + 255) & ~255
+        blob = DeviceArray(self, (max(total, 16),), np.uint8, scratch=True)
+        ptrs = [None if o is None else C.c_void_p(blob.ptr + o[0]) for o in offs]
+
+        def fetch():
+            h = blob.to_host()
+            out = []
+            for sp, o in zip(specs, offs):
+                if sp is None:
+                    out.append(None)
+                    continue
+                shape, dt = sp
+                out.append(h[o[0]:o[0] + o[1]].view(self.real if dt is None else dt).reshape(shape).copy())
+            return out
+
+        return ptrs, fetch
 
     # ------------------------------------------------------------------ per-env tensors
     _FIELD_DIMS = {
@@ -420,10 +484,10 @@ class Engine:
         act = np.asarray(act, dtype=self.real).reshape(-1, self.du)
         n = obs.shape[0]
         keep = []
-        out = self._tmp((n,))
-        N.check(N.lib().rcg_stage_obj(self._h, self._in(obs, keep, lambda a: a.T), self._in(act, keep, lambda a: a.T),
-                                      C.c_void_p(out.ptr), n), self._h)
-        return out.to_host()
+        po, pa = self._in_many([(obs, lambda a: a.T, None, "obs"), (act, lambda a: a.T, None, "act")], keep)
+        (pout,), fetch = self._out_many([((n,), None)])
+        N.check(N.lib().rcg_stage_obj(self._h, po, pa, pout, n), self._h)
+        return fetch()[0]
 
     def critic(self, obs, act, w):
         obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)
@@ -431,10 +495,11 @@ class Engine:
         w = np.asarray(w, dtype=self.real).reshape(-1, self.dc)
         n = obs.shape[0]
         keep = []
-        out = self._tmp((n,))
-        N.check(N.lib().rcg_critic(self._h, self._in(obs, keep, lambda a: a.T), self._in(act, keep, lambda a: a.T),
-                                   self._in(w, keep, lambda a: a.T), C.c_void_p(out.ptr), n), self._h)
-        return out.to_host()
+        po, pa, pw = self._in_many([(obs, lambda a: a.T, None, "obs"), (act, lambda a: a.T, None, "act"),
+                                    (w, lambda a: a.T, None, "w")], keep)
+        (pout,), fetch = self._out_many([((n,), None)])
+        N.check(N.lib().rcg_critic(self._h, po, pa, pw, pout, n), self._h)
+        return fetch()[0]
 
     def _cand(self, cand, keep, K=None):
         """Candidates ``[B, K, N, du]`` (numpy / device).  Returns (pointer, K).  An explicit ``K`` must agree with the
@@ -483,11 +548,11 @@ class Engine:
         pc, K = self._cand(cand, keep, K)
         if K is None:
             raise ValueError("actor_argmin: K is required with generated candidates (cand=None)")
-        act, bj, bi = self._tmp((self.du, self.B)), self._tmp((self.B,)), self._tmp((self.B,), np.int32)
-        N.check(N.lib().rcg_actor_argmin(self._h, pc, K, self._in_soa(obs, keep, self.dy, "obs"),
-                                         self._in_soa(state_sys, keep, self.ds, "state_sys"),
-                                         C.c_void_p(act.ptr), C.c_void_p(bj.ptr), C.c_void_p(bi.ptr)), self._h)
-        return act.to_host().T.copy(), bj.to_host(), bi.to_host()
+        pobs, pxs = self._in_many([self._soa_item(obs, self.dy, "obs"), self._soa_item(state_sys, self.ds, "state_sys")], keep)
+        (pact, pbj, pbi), fetch = self._out_many([((self.du, self.B), None), ((self.B,), None), ((self.B,), np.int32)])
+        N.check(N.lib().rcg_actor_argmin(self._h, pc, K, pobs, pxs, pact, pbj, pbi), self._h)
+        act, bj, bi = fetch()
+        return act.T.copy(), bj, bi
 
     def control_tick(self, cand=None, K=None):
         """One env.control-step for all envs.  ``cand`` on device for the timed path."""
@@ -509,15 +574,15 @@ class Engine:
         ``u_init [B, N, du]`` (None: the reference's ``action_sqn_init``).  Returns
         ``(action [B, du], u_opt [B, N, du], best_J [B], n_iter [B] int32)``."""
         keep = []
-        pu = self._in(None if u_init is None else np.broadcast_to(
-            np.asarray(u_init, dtype=self.real).reshape(-1, self.N, self.du), (self.B, self.N, self.du)), keep)
-        uo, act = self._tmp((self.B, self.N, self.du)), self._tmp((self.du, self.B))
-        bj, ni = self._tmp((self.B,)), self._tmp((self.B,), np.int32)
-        N.check(N.lib().rcg_actor_optimize(self._h, int(iters), self._in_soa(obs, keep, self.dy, "obs"),
-                                           self._in_soa(state_sys, keep, self.ds, "state_sys"), pu,
-                                           C.c_void_p(uo.ptr), C.c_void_p(act.ptr), C.c_void_p(bj.ptr),
-                                           C.c_void_p(ni.ptr)), self._h)
-        return act.to_host().T.copy(), uo.to_host(), bj.to_host(), ni.to_host()
+        u0 = None if u_init is None else np.broadcast_to(
+            np.asarray(u_init, dtype=self.real).reshape(-1, self.N, self.du), (self.B, self.N, self.du))
+        pobs, pxs, pu = self._in_many([self._soa_item(obs, self.dy, "obs"), self._soa_item(state_sys, self.ds, "state_sys"),
+                                       (u0, None, None, "u_init")], keep)
+        (puo, pact, pbj, pni), fetch = self._out_many([((self.B, self.N, self.du), None), ((self.du, self.B), None),
+                                                       ((self.B,), None), ((self.B,), np.int32)])
+        N.check(N.lib().rcg_actor_optimize(self._h, int(iters), pobs, pxs, pu, puo, pact, pbj, pni), self._h)
+        uo, act, bj, ni = fetch()
+        return act.T.copy(), uo, bj, ni
 
     def control_tick_opt(self, iters=10, warm_start=False):
         """One env.control-step with the on-device optimiser as the decision (rcg_control_tick_opt)."""
@@ -536,13 +601,12 @@ class Engine:
         obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)
         n = obs.shape[0]
         keep = []
-        act = self._tmp((self.du, n))
-        lyap = self._tmp((n,)) if want_lyap else None
-        N.check(N.lib().rcg_nominal_action(self._h, self._in(obs, keep, lambda a: a.T), C.c_void_p(act.ptr),
-                                           C.c_void_p(lyap.ptr) if want_lyap else None, n, float(ctrl_gain),
+        (pact, plyap), fetch = self._out_many([((self.du, n), None), ((n,), None) if want_lyap else None])
+        N.check(N.lib().rcg_nominal_action(self._h, self._in(obs, keep, lambda a: a.T), pact, plyap, n, float(ctrl_gain),
                                            self._ctrl_pars(ctrl_pars), 1 if clip else 0), self._h)
-        a = act.to_host().T.copy()
-        return (a, lyap.to_host()) if want_lyap else a
+        act, lyap = fetch()
+        a = act.T.copy()
+        return (a, lyap) if want_lyap else a
 
     def control_tick_nominal(self, ctrl_gain, ctrl_pars=None):
         """One env.control-step with the nominal controller as the decision (rcg_control_tick_nominal)."""
