@@ -155,9 +155,16 @@ class CtrlOptPred:
         self.state_sys = state
 
     def stage_obj(self, observation, action):
-        """rcognita/controllers.py:1063-1084 (rcg_stage_obj)."""
-        out = self._eng.stage_obj(self._b(observation, self.dim_output), self._b(action, self.dim_input)).astype(float)
-        return out if self._batched else float(out[0])
+        """rcognita/controllers.py:1063-1084 (rcg_stage_obj).  The reference's loop evaluates it twice per step on the
+        same arguments (upd_accum_obj, then the logger: presets/main_3wrobot.py:429-441): the last result is kept."""
+        y, a = self._b(observation, self.dim_output), self._b(action, self.dim_input)
+        last = getattr(self, "_stage_last", None)
+        if last is not None and last[0].shape == y.shape and np.array_equal(last[0], y) and np.array_equal(last[1], a):
+            out = last[2]
+        else:
+            out = self._eng.stage_obj(y, a).astype(float)
+            self._stage_last = (np.array(y, copy=True), np.array(a, copy=True), out)
+        return out.copy() if self._batched else float(out[0])
 
     def upd_accum_obj(self, observation, action):
         """rcognita/controllers.py:1086-1093."""
