@@ -192,12 +192,13 @@ class CtrlOptPred:
     def _critic_optimizer(self):
         """Replacement of rcognita/controllers.py:1248-1271: native bounded least squares on the TD stack
         of the CURRENT buffers (no push)."""
-        self._sync_critic_state()
-        # rcg_critic_update pushes before it fits: pre-shift the rows so the push restores them
-        ob = self._eng.get_field(N.FIELD_OBS_BUF)
-        ab = self._eng.get_field(N.FIELD_ACT_BUF)
+        # rcg_critic_update pushes (ACTION, STATE) before it fits: upload the rows pre-shifted so that the push restores
+        # them (the values travel through the handle's element type exactly as set_field + get_field would round them)
+        ob = np.broadcast_to(self.observation_buffer, (self.B,) + self.observation_buffer.shape[-2:]).astype(self._eng.real)
+        ab = np.broadcast_to(self.action_buffer, (self.B,) + self.action_buffer.shape[-2:]).astype(self._eng.real)
         self._eng.set_field(N.FIELD_OBS_BUF, np.concatenate([ob[:, :1] * 0, ob[:, :-1]], axis=1))
         self._eng.set_field(N.FIELD_ACT_BUF, np.concatenate([ab[:, :1] * 0, ab[:, :-1]], axis=1))
+        self._eng.set_field(N.FIELD_W_PREV, self._b(self.w_critic_prev, self.dim_critic))
         self._eng.set_field(N.FIELD_STATE, ob[:, -1])
         self._eng.set_field(N.FIELD_ACTION, ab[:, -1])
         self._eng.critic_update(do_fit=True)
