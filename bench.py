@@ -677,12 +677,23 @@ def main(argv=None):
             out["cpu_baseline"]["reference_algorithm"] = cpu_reference_algorithm(args, min(args.cpu_seconds, 8.0))
         except ImportError as e:  # SciPy missing on the box: the port above is the baseline
             out["cpu_baseline"]["reference_algorithm"] = {"error": str(e)}
-    print(json.dumps(out))
+    print(json.dumps(strict_json(out)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if "parity" in out and not out["parity"]["ok"]:
         sys.exit("bench.py: the parity check of this run FAILED - the numbers above are not valid")
+
+
+def strict_json(x):
+    """inf / nan (e.g. the returns of envs whose model blew up and were frozen: `n_failed` > 0) are not JSON: -> None."""
+    if isinstance(x, dict):
+        return {k: strict_json(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [strict_json(v) for v in x]
+    if isinstance(x, float) and (x != x or x in (float("inf"), float("-inf"))):
+        return None
+    return x
 
 
 def valu_instr_per_eval(key):
