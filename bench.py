@@ -586,8 +586,7 @@ def main(argv=None):
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "                           "stored; not re-measured in this run)"
         except Exception:
             traffic = None
-    dma = (streamed and K >= 64 and K % 4 == 0 and args.config != "C5" and Nh * du <= 40 and
-           (args.dtype == "f32" or args.config != "C3"))  # (f64 critic modes run on the generic kernel)
+    dma = streamed and K >= 64 and K % 4 == 0 and args.config != "C5" and Nh * du <= 40  # (C3: tank RQL, f32 and f64)
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
               "candidates (BASELINE configs[1])",

@@ -32,12 +32,11 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
         switch (variant) {
           RCG_DMA_CASE(DMA_MPC_G1)
           RCG_DMA_CASE(DMA_MPC)
-          case DMA_RQL:
-            if constexpr (std::is_same<real, float>::value) {
-              hipLaunchKernelGGL((k_actor_dma<Sys, real, R, Sys::TGT, DMA_RQL>), grid, block, lds, s, A, P);
-              return true;
-            }
-            return false;
+        }
+        // RQL: f32 for every system; f64 (the reference's width) for the tank, whose critic weights are <= 9 doubles
+        // (the robots' RQL instance keeps 2 x 35 weights in registers: 140 VGPRs in f64 on top of an 80-register row)
+        if constexpr (std::is_same<real, float>::value || Sys::DS <= 2) {
+          switch (variant) { RCG_DMA_CASE(DMA_RQL) }
         }
       } else if constexpr (std::is_same<real, float>::value) {
         switch (variant) {

@@ -304,13 +304,14 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
 
   // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K >= 64 and a multiple of 4, diagonal quadratic
   // stage cost, the preset's observation target (an instance that subtracts a target also serves a handle without one: its
-  // target is all zeros, y - 0 = y exactly); rows of <= 40 reals; f32: MPC / RQL / SQL; f64: MPC.
+  // target is all zeros, y - 0 = y exactly); rows of <= 40 reals; f32: MPC / RQL / SQL; f64: MPC, and RQL for the tank.
   const DevKnobs& knobs = dev_knobs();
   A.dbg = knobs.dbg;
   constexpr bool is_f32 = std::is_same<real, float>::value;
   constexpr size_t esz = sizeof(real);
   const size_t tile = (size_t)64 * R * esz;  // one wave's LDS tile
-  const bool mode_ok = c.mode == RCG_MODE_MPC || (is_f32 && !knobs.mpc_only);
+  const bool mode_ok = c.mode == RCG_MODE_MPC || (is_f32 && !knobs.mpc_only) ||
+                       (c.mode == RCG_MODE_RQL && Sys::DS <= 2 && !knobs.mpc_only);  // f64 RQL: the tank (rcg_dma_launch.hpp)
   const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 4) == 0 && R <= dma_max_row<real>() &&
                       P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
                       !(A.J && 4 * tile + 4 * esz * K > (size_t)160 * 1024);  // J staging must fit next to the tiles (one block per CU then)
