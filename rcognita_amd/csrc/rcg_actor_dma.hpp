@@ -96,6 +96,14 @@ __device__ __forceinline__ void wave_argmin(double& bestJ, int& bestI) {
   }
 }
 
+// Rows per lane and tile.  A tile is one round trip to HBM per wave whatever its size, so very short rows move few
+// bytes per trip: rows of <= 24 bytes (the robots' Nactor <= 3 in f32) are taken four per lane (tiles of 256 rows), rows
+// of <= 32 bytes two per lane.  One instance per row length: a K that is not a multiple of the tile is a ragged last tile
+// like any other.  Measured (B = 65536, K = 256, several interleaved pairs against the one-row-per-lane build, every output
+// bit-identical): f32 Nactor = 2 / 3 / 4: 4.75 -> 5.65 / 5.6 -> 5.8-5.95 / 5.75 -> 5.90 TB/s, f64 Nactor = 2: 5.16 -> 5.60;
+// rows of 40 and 48 bytes (Nactor = 5, 6) gained nothing and stay at one row per lane.
+__host__ __device__ constexpr int dma_rpl(int r, int esz) { return r * esz <= 24 ? 4 : (r * esz <= 32 ? 2 : 1); }
+
 template <typename Sys, typename real, int R, bool TGT, int V>
 __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   constexpr int ESZ = (int)sizeof(real);
   static_assert(R % DU == 0 && R >= DU && R <= 40, "row = N*du reals, at most 40 (f32: 160 bytes, f64: 320)");
   constexpr int N = R / DU;
-  constexpr int TILE = 64 * R * ESZ;                               // bytes of one tile of 64 rows
+  constexpr int RPL = dma_rpl(R, ESZ), TROWS = 64 * RPL;           // rows per lane, rows per tile
+  constexpr int TILE = TROWS * R * ESZ;                            // bytes of one tile
   constexpr int NFULL = TILE / 1024, NREM = (TILE % 1024) / 256;  // 1-KiB and 256-B direct-to-LDS loads per tile
   static_assert(NFULL * 1024 + NREM * 256 == TILE, "a tile is a whole number of 256-B segments");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -118,8 +127,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
   const long B = P.B;
   const int K = A.K;
-  const int T = (K + 63) >> 6;   // tiles per env
-  const int rem_rows = K & 63;   // rows of an env's LAST tile (0: it is full); K % 4 == 0, so whole 16-byte pieces
+  const int T = (K + TROWS - 1) / TROWS;  // tiles per env
+  const int rem_rows = K % TROWS;         // rows of an env's LAST tile (0: it is full); K % 4 == 0: whole 16-byte pieces
   const long env0 = wave * A.gpw;
   if (env0 >= B) return;
   const long env1 = env0 + A.gpw < B ? env0 + A.gpw : B;
@@ -137,11 +146,11 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   const int jspan = A.jwave ? A.gpw * K : K;  // reals of staging per wave
   real* const jstage = reinterpret_cast<real*>(smem_raw + (size_t)4 * TILE) + (size_t)wave_in_wg * jspan;
 
-  // `rows` (wave-uniform): 64, or rem_rows for an env's ragged last tile - then every lane loads only pieces that lie
+  // `rows` (wave-uniform): TROWS, or rem_rows for an env's ragged last tile - then every lane loads only pieces that lie
   // inside the env's rows (rows * R * ESZ bytes, a multiple of 16), the rest of the LDS tile keeps stale rows that no
   // valid candidate index points at
   auto issue_tile = [&](const unsigned char* g, int rows) {
-    if (rows == 64) {
+    if (rows == TROWS) {
 #pragma unroll
       for (int j = 0; j < NFULL; ++j)
         __builtin_amdgcn_global_load_lds((glb_void*)(g + j * 1024 + lane * 16), (lds_void*)(tile + j * 1024), 16, 0,
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
                                            (lds_void*)(tile + NFULL * 1024 + j * 256), 4, 0, RCG_DMA_AUX);
     }
   };
-  auto rows_of = [&](int tt) -> int { return (tt == T - 1 && rem_rows) ? rem_rows : 64; };
+  auto rows_of = [&](int tt) -> int { return (tt == T - 1 && rem_rows) ? rem_rows : TROWS; };
 
   // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
   // "pointer ? load : default" selects (a default written into a register with a load in flight would force a
@@ -236,10 +245,13 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
     }
     // 2. tile g has landed -> my row into registers (vmcnt retires in issue order: everything requested so far)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const real* const myrow = reinterpret_cast<const real*>(tile) + lane * R;
-    real cur[R];
+    real rows[RPL][R];  // the lane's rows: lane, lane + 64, ... of the tile
 #pragma unroll
-    for (int i = 0; i < R; ++i) cur[i] = myrow[i];
+    for (int j = 0; j < RPL; ++j) {
+      const real* const myrow = reinterpret_cast<const real*>(tile) + (j * 64 + lane) * R;
+#pragma unroll
+      for (int i = 0; i < R; ++i) rows[j][i] = myrow[i];
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane's row is out of LDS (in-order per wave)
     __builtin_amdgcn_wave_barrier();
     // 3. the LDS tile is free: request tile g + 1 into it, an env-state request first if it opens an env
@@ -253,64 +265,68 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
       }
     }
 
-    // 4. _actor_cost of this lane's row (controllers.py:1284-1326), registers only
-    real x[DS], y[DS];
+    // 4. _actor_cost of this lane's rows (controllers.py:1284-1326), registers only, in candidate order
 #pragma unroll
-    for (int c = 0; c < DS; ++c) {
-      x[c] = x0[c];  // state_sys
-      y[c] = y0[c];  // observation_sqn[0] = observation
-    }
-    real J = 0, gk = 1;
-    real S[NCHI];
+    for (int j = 0; j < RPL; ++j) {
+      const real* const cur = rows[j];
+      real x[DS], y[DS];
 #pragma unroll
-    for (int i = 0; i < NCHI; ++i) S[i] = 0;
-    if (RCG_DBG(A, 1)) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
+      for (int c = 0; c < DS; ++c) {
+        x[c] = x0[c];  // state_sys
+        y[c] = y0[c];  // observation_sqn[0] = observation
+      }
+      real J = 0, gk = 1;
+      real S[NCHI];
 #pragma unroll
-      for (int i = 0; i < R; ++i) J += cur[i];
-    } else {
+      for (int i = 0; i < NCHI; ++i) S[i] = 0;
+      if (RCG_DBG(A, 1)) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
 #pragma unroll
-      for (int kk = 0; kk < N; ++kk) {
-        if (kk > 0) {
-          real d[DS];
-          Sys::template rhs<real, true>(pre_env, x, &cur[(kk - 1) * DU], d);  // unclipped: sys_rhs([], state, u[k-1])
+        for (int i = 0; i < R; ++i) J += cur[i];
+      } else {
 #pragma unroll
-          for (int c = 0; c < DS; ++c) {
-            x[c] = fma_r(h, d[c], x[c]);
-            y[c] = x[c];  // sys_out is the identity
+        for (int kk = 0; kk < N; ++kk) {
+          if (kk > 0) {
+            real d[DS];
+            Sys::template rhs<real, true>(pre_env, x, &cur[(kk - 1) * DU], d);  // unclipped: sys_rhs([], state, u[k-1])
+#pragma unroll
+            for (int c = 0; c < DS; ++c) {
+              x[c] = fma_r(h, d[c], x[c]);
+              y[c] = x[c];  // sys_out is the identity
+            }
+          }
+          real chi[NCHI];
+#pragma unroll
+          for (int c = 0; c < DS; ++c) chi[c] = TGT ? y[c] - P.target[c] : y[c];
+#pragma unroll
+          for (int c = 0; c < DU; ++c) chi[DS + c] = cur[kk * DU + c];
+          if (G1) {
+#pragma unroll
+            for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
+          } else if (SQL) {
+            J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], [&](int i) -> real { return wc[i]; }, CS);
+          } else if (RQL && kk == N - 1) {
+            J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], [&](int i) -> real { return wc[i]; }, P.critic_struct);
+          } else {
+            J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
+            gk *= P.gamma;
           }
         }
-        real chi[NCHI];
-#pragma unroll
-        for (int c = 0; c < DS; ++c) chi[c] = TGT ? y[c] - P.target[c] : y[c];
-#pragma unroll
-        for (int c = 0; c < DU; ++c) chi[DS + c] = cur[kk * DU + c];
         if (G1) {
 #pragma unroll
-          for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
-        } else if (SQL) {
-          J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], [&](int i) -> real { return wc[i]; }, CS);
-        } else if (RQL && kk == N - 1) {
-          J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], [&](int i) -> real { return wc[i]; }, P.critic_struct);
-        } else {
-          J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
-          gk *= P.gamma;
+          for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[i], J);
         }
       }
-      if (G1) {
-#pragma unroll
-        for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[i], J);
-      }
-    }
 
-    const int k = t * 64 + lane;
-    const bool has_row = k < K;  // false only in a ragged last tile
-    if (A.J && has_row) jstage[(A.jwave ? (int)(b - env0) * K : 0) + k] = J;
-    const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
-    if (has_row && (Jc < bestJ || bestI == 0x7fffffff)) {
-      bestJ = Jc;
-      bestI = k;
+      const int k = t * TROWS + j * 64 + lane;
+      const bool has_row = k < K;  // false only in a ragged last tile
+      if (A.J && has_row) jstage[(A.jwave ? (int)(b - env0) * K : 0) + k] = J;
+      const real Jc = (J != J) ? inf_r<real>() : J;  // NaN counts as +inf
+      if (has_row && (Jc < bestJ || bestI == 0x7fffffff)) {
+        bestJ = Jc;
+        bestI = k;
 #pragma unroll
-      for (int c = 0; c < DU; ++c) bu[c] = cur[c];  // the sequence's first action
+        for (int c = 0; c < DU; ++c) bu[c] = cur[c];  // the sequence's first action
+      }
     }
 
     // env b complete (per-env staging) or wave complete (A.jwave): the staged costs go out in one piece

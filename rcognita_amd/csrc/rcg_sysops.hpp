@@ -309,7 +309,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   A.dbg = knobs.dbg;
   constexpr bool is_f32 = std::is_same<real, float>::value;
   constexpr size_t esz = sizeof(real);
-  const size_t tile = (size_t)64 * R * esz;  // one wave's LDS tile
+  const size_t tile = (size_t)64 * dma_rpl(R, (int)esz) * R * esz;  // one wave's LDS tile (64 x rows-per-lane rows)
   const bool mode_ok = c.mode == RCG_MODE_MPC || (is_f32 && !knobs.mpc_only) ||
                        (c.mode == RCG_MODE_RQL && Sys::DS <= 2 && !knobs.mpc_only);  // f64 RQL: the tank (rcg_dma_launch.hpp)
   const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 4) == 0 && R <= dma_max_row<real>() &&
