@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 112 /* 0.1.1 + checkpoint counter, own stream */
+#define RCG_VERSION 113 /* 0.1.1 + checkpoint counter, own stream, rcg_control_tick_n */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -237,6 +237,12 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
  * single ticks (same arithmetic); BEST_J / BEST_IDX are the last tick's.  MPC without the disturbance model; other
  * handles get RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of small batches. */
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
+/* T consecutive rcg_control_tick(h, cand, K) issued by ONE call: the loop of presets/main_3wrobot.py:415-468 for T sampling
+ * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode - 2 (MPC) launches per
+ * tick as rcg_control_tick makes them, without T trips through the caller's FFI: a Python caller needs ~12 us per call, and a
+ * GPU that idles between short ticks clocks down (measured, streamed K = 64: B = 4096 102 us per tick from a Python loop, 9.6 us
+ * here; B = 1024 11.7 -> 7.3 us).  Identical to T single calls; stops at the first error. */
+int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);
 /* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398), MPC with a
  * diagonal R1: `iters` iterations of {adjoint gradient of _actor_cost w.r.t. the whole sequence, box-scaled
  * projected line search over 16 step lengths (4 box widths down to 2^-28, ratio 4)}.  obs / state_sys as

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCG_LIB") or os.path.join(_HERE, "lib", "librcg.so")
 
 # ---- enums (include/rcg.h) -------------------------------------------------------------------
-RCG_VERSION = 112
+RCG_VERSION = 113
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
 SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
 MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
@@ -45,7 +45,7 @@ SYMBOLS = [
     "rcg_synchronize", "rcg_dev_alloc", "rcg_dev_free", "rcg_memcpy_h2d", "rcg_memcpy_d2h", "rcg_set_field",
     "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
-    "rcg_critic_update", "rcg_control_ticks", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
+    "rcg_critic_update", "rcg_control_ticks", "rcg_control_tick_n", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
     "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
@@ -128,6 +128,7 @@ def lib():
         "rcg_control_tick": (C.c_int, [vp, vp, i32]),
         "rcg_critic_update": (C.c_int, [vp, i32]),
         "rcg_control_ticks": (C.c_int, [vp, i32, i32]),
+        "rcg_control_tick_n": (C.c_int, [vp, vp, i32, i32]),
         "rcg_actor_optimize": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
         "rcg_nominal_action": (C.c_int, [vp, vp, vp, vp, i32, C.c_double, C.POINTER(C.c_double), i32]),

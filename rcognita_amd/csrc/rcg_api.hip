@@ -580,6 +580,16 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
                        h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, sim_first);
 }
 
+int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T) {
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (T < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_tick_n: T must be >= 1");
+  for (int32_t t = 0; t < T; ++t) {
+    const int rc = rcg_control_tick(h, cand, K);
+    if (rc) return rc;
+  }
+  return RCG_OK;
+}
+
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K) {
   DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;

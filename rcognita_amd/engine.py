@@ -554,13 +554,19 @@ class Engine:
         act, bj, bi = fetch()
         return act.T.copy(), bj, bi
 
-    def control_tick(self, cand=None, K=None):
-        """One env.control-step for all envs.  ``cand`` on device for the timed path."""
+    def control_tick(self, cand=None, K=None, T=1):
+        """One env.control-step for all envs (``T`` > 1: T of them with the same candidates in one native call,
+        rcg_control_tick_n - at small batches the Python round trip is longer than the tick and lets the GPU idle and
+        clock down).  ``cand`` on device for
+        the timed path."""
         keep = []
         pc, K = self._cand(cand, keep, K)
         if K is None:
             raise ValueError("control_tick: K is required with generated candidates (cand=None)")
-        N.check(N.lib().rcg_control_tick(self._h, pc, K), self._h)
+        if int(T) == 1:
+            N.check(N.lib().rcg_control_tick(self._h, pc, K), self._h)
+        else:
+            N.check(N.lib().rcg_control_tick_n(self._h, pc, K, int(T)), self._h)
         if keep:  # temporaries were uploaded for this call: finish before they are freed
             self.synchronize()
 

@@ -160,6 +160,7 @@ static void abi_host_side(void) {
   EXPECT(rcg_actor_argmin(NULL, x, 1, x, x, x, x, i32) < 0);
   EXPECT(rcg_control_tick(NULL, x, 1) < 0);
   EXPECT(rcg_control_ticks(NULL, 2, 16) < 0);
+  EXPECT(rcg_control_tick_n(NULL, x, 1, 2) < 0);
   EXPECT(rcg_actor_optimize(NULL, 1, x, x, x, x, x, x, i32) < 0);
   EXPECT(rcg_control_tick_opt(NULL, 1, 0) < 0);
   EXPECT(rcg_nominal_action(NULL, x, x, x, 1, 1.0, NULL, 0) < 0);

@@ -113,3 +113,39 @@ def test_small_batch_is_no_longer_launch_bound():
     rate = 4 * T * B / (time.perf_counter() - t0)
     print(f"persistent ticks: {rate:.3e} env.control-steps/s at B={B}, K={K}")
     assert rate > 2.5e8
+
+
+@pytest.mark.parametrize("name,mode,streamed", [("3wrobot", "MPC", True), ("2tank", "RQL", True), ("2tank", "SQL", False)])
+def test_tick_n_equals_n_single_ticks(name, mode, streamed):
+    """rcg_control_tick_n: T ticks with the same candidates in one native call (any mode, streamed or generated) leave
+    every field as T calls of rcg_control_tick do, bit for bit; T < 1 is refused and changes nothing."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(11)
+    B, K, T = 300, 64, 9
+    kw = dict(n_actor=6)
+    if mode != "MPC":
+        kw.update(mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_QUADRATIC, n_critic=3, buffer_size=5)
+    a, _ = both(name, B, "f32", **kw)
+    b, cfg = both(name, B, "f32", **kw)
+    x0 = rand_states(rng, name, B)
+    a.set_state(x0)
+    b.set_state(x0)
+    ca = cb = None
+    if streamed:
+        lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
+        c = (lo + (hi - lo) * rng.random((B, K, 6, cfg.du))).astype(np.float32)
+        ca, cb = a.to_device(c), b.to_device(c)
+    for _ in range(T):
+        a.control_tick(ca, K=K)
+    b.control_tick(cb, K=K, T=T)
+    fields = [N.FIELD_STATE, N.FIELD_STATE_PREV, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_STEP_IDX, N.FIELD_BEST_IDX, N.FIELD_BEST_J]
+    if mode != "MPC":
+        fields += [N.FIELD_W_CRITIC, N.FIELD_W_PREV, N.FIELD_OBS_BUF, N.FIELD_ACT_BUF]
+    for f in fields:
+        np.testing.assert_array_equal(a.get_field(f), b.get_field(f), err_msg=f"field {f}")
+    assert N.lib().rcg_tick_count(a._h) == N.lib().rcg_tick_count(b._h) == T
+    with pytest.raises(N.NativeError) as ei:
+        b.control_tick(cb, K=K, T=0)
+    assert ei.value.code == N.ERR_BAD_ARG
+    np.testing.assert_array_equal(a.get_state(), b.get_state())
