@@ -586,7 +586,7 @@ def main(argv=None):
             traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "                           "stored; not re-measured in this run)"
         except Exception:
             traffic = None
-    dma = streamed and K >= 64 and K % 4 == 0 and args.config != "C5" and Nh * du <= 40  # (C3: tank RQL, f32 and f64)
+    dma = streamed and K >= 40 and K % 4 == 0 and args.config != "C5" and Nh * du <= 40  # (C3: tank RQL, f32 and f64)
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
               "candidates (BASELINE configs[1])",
@@ -779,7 +779,7 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
             e64.close()
             b64 = actor_bytes_per_launch(B, K, Nh, du, ds, 8, True)
             sec["f64"] = {"env_control_steps_per_s": B * n4 / d4, "ms_per_step": d4 / n4 * 1e3, "dtype": "f64",
-                          "kernel": "k_actor_dma<double>" if (Nh * du <= 40 and K >= 64 and K % 4 == 0) else "k_actor",
+                          "kernel": "k_actor_dma<double>" if (Nh * du <= 40 and K >= 40 and K % 4 == 0) else "k_actor",
                           "kernel_avg_ms": ms4 / max(c4, 1),
                           "roofline": {"bound": "hbm", "achieved": b64 / (ms4 / max(c4, 1) * 1e-3) / 1e9,
                                        "peak": HBM_PEAK / 1e9, "unit": "GB/s",

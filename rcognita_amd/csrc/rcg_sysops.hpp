@@ -302,7 +302,9 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
 
-  // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K >= 64 and a multiple of 4, diagonal quadratic
+  // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K >= 40 and a multiple of 4 (40 .. 60: one
+  // ragged tile per env - K = 48: 4.6 TB/s against 2.9 on k_actor; at K <= 32 k_actor, which packs 64 / K envs into a tile,
+  // is faster: 3.7 against 3.4 TB/s at K = 32, 3.4 against 1.75 at K = 16), diagonal quadratic
   // stage cost, the preset's observation target (an instance that subtracts a target also serves a handle without one: its
   // target is all zeros, y - 0 = y exactly); rows of <= 40 reals; f32: MPC / RQL / SQL; f64: MPC, and RQL for the tank.
   const DevKnobs& knobs = dev_knobs();
@@ -312,7 +314,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const size_t tile = (size_t)64 * dma_rpl(R, (int)esz) * R * esz;  // one wave's LDS tile (64 x rows-per-lane rows)
   const bool mode_ok = c.mode == RCG_MODE_MPC || (is_f32 && !knobs.mpc_only) ||
                        (c.mode == RCG_MODE_RQL && Sys::DS <= 2 && !knobs.mpc_only);  // f64 RQL: the tank (rcg_dma_launch.hpp)
-  const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 64 && (K % 4) == 0 && R <= dma_max_row<real>() &&
+  const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 40 && (K % 4) == 0 && R <= dma_max_row<real>() &&
                       P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
                       !(A.J && 4 * tile + 4 * esz * K > (size_t)160 * 1024);  // J staging must fit next to the tiles (one block per CU then)
   // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
