@@ -112,6 +112,10 @@ static void build_params(const rcg_handle* h, KParams<real>* P, real* rfull_host
   P->n_critic = c.n_critic;
   P->buffer_size = c.buffer_size;
   P->stage_kind = (full ? STAGE_FULL : 0) | (biq ? STAGE_BIQUAD : 0);
+  P->zero_w = 0u;
+  if (!full && !biq)
+    for (int i = 0; i < n; ++i)
+      if (c.R1[i * n + i] == 0.0) P->zero_w |= 1u << i;
   P->has_target = (c.flags & RCG_FLAG_HAS_TARGET) ? 1 : 0;
   P->clip = (c.flags & RCG_FLAG_NO_CLIP) ? 0 : 1;
   P->per_env_pars = (c.flags & RCG_FLAG_PER_ENV_PARS) ? 1 : 0;

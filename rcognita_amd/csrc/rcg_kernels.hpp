@@ -49,6 +49,7 @@ struct KParams {
   real gamma, h_pred, dt_sim, sampling_time;
   int B, n_actor, mode, critic_struct, dc, n_critic, buffer_size;
   int stage_kind, has_target, clip, per_env_pars, ref_lag, accum_every_substep;
+  unsigned zero_w;  // bit i: R1_ii == 0 (diagonal stage cost only): that component's cost term is exactly zero
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -312,7 +313,8 @@ __device__ __forceinline__ void gen_candidate(const KParams<real>& P, int g, int
 // component, S_i += chi_i^2, and weighted once at the end, J = sum_i R1_ii S_i - 7 fma per 3wrobot step instead of 14
 // ops + the discount bookkeeping, in a rollout of ~33 (the generated-candidate regime is VALU-issue-bound,
 // profiles/r02_*_valu_pmc.json; k_actor_dma has had the same variant since round 1).
-template <typename Sys, typename real, bool TGT, bool STREAM, int MODE_C, int SK_C, int CS_C, bool G1 = false, typename WGet>
+template <typename Sys, typename real, bool TGT, bool STREAM, int MODE_C, int SK_C, int CS_C, bool G1 = false, unsigned ZW = 0u,
+          typename WGet>
 __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
                                              const real* xs, const real* y0, const real* urow, const real* ugen,
                                              WGet wget, real* u0) {
@@ -362,7 +364,8 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     make_chi<DS, DU, TGT, real>(P, y, u, chi);
     if (G1 && (MODE_C == RCG_MODE_MPC || kk < N - 1)) {
 #pragma unroll
-      for (int i = 0; i < NCHI; ++i) S[G1 ? i : 0] = fma_r(chi[i], chi[i], S[G1 ? i : 0]);
+      for (int i = 0; i < NCHI; ++i)
+        if (!((ZW >> i) & 1u)) S[G1 ? i : 0] = fma_r(chi[i], chi[i], S[G1 ? i : 0]);  // (ZW: weight exactly zero)
     } else if (G1) {  // RQL, last step: Q_w(y_{N-1}, u_{N-1}) (controllers.py:1310)
       J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
     } else if (mode == RCG_MODE_MPC) {
@@ -383,7 +386,8 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
   }
   if (G1) {
 #pragma unroll
-    for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[G1 ? i : 0], J);
+    for (int i = 0; i < NCHI; ++i)
+      if (!((ZW >> i) & 1u)) J = fma_r(P.R1d[i], S[G1 ? i : 0], J);  // fma(0, S_i, J) == J for finite S_i
   }
   if (SUMF) {
 #pragma unroll
@@ -399,8 +403,14 @@ __device__ __forceinline__ real rollout_dispatch(const KParams<real>& P, const t
                                                  const real* ugen, WGet wget, real* u0) {
 #define RCG_ROLL(M, S, C) rollout_cost<Sys, real, TGT, STREAM, M, S, C>(P, pre, N, xs, y0, urow, ugen, wget, u0)
   if (!GENERIC) {  // MPC, quadratic, diagonal R1
-    if (P.gamma == (real)1)  // wave-uniform
+    if (P.gamma == (real)1) {  // wave-uniform
+      // the preset's zero stage weights (Sys::ZW_PRESET) are zero in this handle too: their terms - exact zeros - are
+      // not computed (the generated-candidate regime is bound by instruction issue; streamed rollouts hide them anyway)
+      if (!STREAM && Sys::ZW_PRESET != 0u && (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET)
+        return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, true, Sys::ZW_PRESET>(P, pre, N, xs, y0, urow, ugen,
+                                                                                             wget, u0);
       return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, true>(P, pre, N, xs, y0, urow, ugen, wget, u0);
+    }
     return RCG_ROLL(RCG_MODE_MPC, 0, -1);
   }
   if (P.mode == RCG_MODE_MPC) return RCG_ROLL(RCG_MODE_MPC, -1, -1);
@@ -463,7 +473,7 @@ __device__ __forceinline__ void segment_argmin(int seg, real& bestJ, int& bestI,
 // accumulation per lane and step instead of NC.  The generated-candidate regime is bound by VALU instruction issue
 // (profiles/r02_valu_pmc.json: > 100 % of the 4-cycle issue slots), so instructions are the currency: 3wrobot, NC = 4,
 // gamma = 1: ~13 instead of 27 per candidate-step.
-template <typename Sys, typename real, bool TGT, bool G1, int NC>
+template <typename Sys, typename real, bool TGT, bool G1, int NC, unsigned ZW = 0u>
 __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, const typename Sys::template Pre<real>& pre,
                                                       int N, const real* xs, const real* y0, const real* u0v, real u1,
                                                       real* Jout) {
@@ -513,7 +523,8 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
       make_chi<DS, DU, TGT, real>(P, y[c], u[c], chi);
       if (G1) {
 #pragma unroll
-        for (int i = 0; i < NCHI; ++i) S[c][G1 ? i : 0] = fma_r(chi[i], chi[i], S[c][G1 ? i : 0]);
+        for (int i = 0; i < NCHI; ++i)
+          if (!((ZW >> i) & 1u)) S[c][G1 ? i : 0] = fma_r(chi[i], chi[i], S[c][G1 ? i : 0]);
       } else {
         J[c] = fma_r(gk, stage_diag<NCHI, real>(P, chi), J[c]);
       }
@@ -534,7 +545,8 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
   for (int c = 0; c < NC; ++c) {
     if (G1) {
 #pragma unroll
-      for (int i = 0; i < NCHI; ++i) J[c] = fma_r(P.R1d[i], S[c][G1 ? i : 0], J[c]);
+      for (int i = 0; i < NCHI; ++i)
+        if (!((ZW >> i) & 1u)) J[c] = fma_r(P.R1d[i], S[c][G1 ? i : 0], J[c]);
     }
     Jout[c] = J[c];
   }
@@ -556,7 +568,12 @@ __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const ty
     u0v[c] = ua[c][0];
   }
   if (P.gamma == (real)1)  // wave-uniform
-    rollout_mpc_gen_multi<Sys, real, TGT, true, NC>(P, pre, N, xs, y0, u0v, ua[0][1], J);
+  {
+    if (Sys::ZW_PRESET != 0u && (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET)  // wave-uniform, see rollout_dispatch
+      rollout_mpc_gen_multi<Sys, real, TGT, true, NC, Sys::ZW_PRESET>(P, pre, N, xs, y0, u0v, ua[0][1], J);
+    else
+      rollout_mpc_gen_multi<Sys, real, TGT, true, NC>(P, pre, N, xs, y0, u0v, ua[0][1], J);
+  }
   else
     rollout_mpc_gen_multi<Sys, real, TGT, false, NC>(P, pre, N, xs, y0, u0v, ua[0][1], J);
 #pragma unroll

@@ -15,6 +15,9 @@ namespace rcg {
 struct Sys3WRobot {
   static constexpr int DS = 5, DU = 2, NP = 2;
   static constexpr bool TGT = false;  // observation_target of the preset: [] (k_actor_dma instances exist for this value)
+  // chi components whose stage weight is zero in the preset (R1 = diag[1, 10, 1, 0, 0, 0, 0], main_3wrobot.py:147): v, omega,
+  // F, M - the generated-candidate rollouts skip their (exactly zero) cost terms when the handle's R1 has them zero too
+  static constexpr unsigned ZW_PRESET = 0x78u;
   // state components whose trajectory under the model depends only on (x_0, u[1]) - heading and turn rate follow the
   // torque alone; candidates of the generated grid that share u[1] share them (rollout_mpc_gen_multi, rcg_kernels.hpp)
   static constexpr unsigned SHARED_U1 = (1u << 2) | (1u << 4);
@@ -56,6 +59,7 @@ struct Sys3WRobot {
 struct Sys3WRobotNI {
   static constexpr int DS = 3, DU = 2, NP = 0;
   static constexpr bool TGT = false;
+  static constexpr unsigned ZW_PRESET = 0x18u;  // R1 = diag[1, 10, 1, 0, 0] (main_3wrobot_NI.py): v, omega
   static constexpr unsigned SHARED_U1 = 1u << 2;  // the heading follows omega = u[1] alone
   template <typename real>
   struct Pre {};
@@ -88,6 +92,7 @@ struct Sys3WRobotNI {
 struct Sys2Tank {
   static constexpr int DS = 2, DU = 1, NP = 5;
   static constexpr bool TGT = true;  // main_2tank.py:211: observation_target = [0.5, 0.5]
+  static constexpr unsigned ZW_PRESET = 0u;  // R1 = diag[10, 10, 1]: every term counts
   static constexpr unsigned SHARED_U1 = 0;  // one input
   template <typename real>
   struct Pre {
