@@ -21,8 +21,14 @@ Multi-GPU: one process per GPU.  `python bench.py --gpus N` from a plain shell s
 never touches the GPU: it spawns N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits,
 relays rank 0's JSON line and fails if any rank fails); under torchrun (`WORLD_SIZE` already set) the process IS a rank.
 
+Timing: pre-spin (untimed, until the clock is steady) -> barrier + synchronize -> W warm-up steps -> [event] K steps
+[event] -> K more steps without per-launch sampling (cross-check) -> the episode-end exchange, timed on its own ->
+synchronize + barrier.  `ms_per_step` = the event pair's device time / K (max over ranks) + allgather_ms / 1000 (one
+exchange per 1000-tick episode); nothing synchronises the host between the warm-up and the timed steps.
+
 One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel: algorithmic bytes per launch
-/ its mean duration measured with HIP events on the engine's own stream inside the timed region.  `parity` compares
+/ its mean duration over >= 20 launches of the timed region, from start / stop events carried by the dispatches
+themselves on the engine's own stream (mean, median, min reported; `kernel` is what rcg_last_launch says ran).  `parity` compares
 outputs of the same run's kernels with the CPU oracle.  `cpu_baseline` is the C oracle (oracle/oracle.c, kind "port")
 timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -42,6 +48,7 @@ VALU_PEAK = 7.9e13  # f32 lane-instructions/s: 256 CUs x 4 SIMDs x 32 lanes/clk.
 PRESPIN_S = 0.35    # untimed clock pre-spin: the first launches after the GPU wakes run 10-25 % slower
 PRESPIN_MAX_S = 3.0
 C4_TOTAL_ENVS = 524288
+EPISODE_TICKS = 1000  # T = 1 000 control ticks per episode (10 s at the preset's t1); one exchange per episode
 
 
 def parse(argv=None):
@@ -66,8 +73,12 @@ def parse(argv=None):
                    help="nccl = RCCL over xGMI (the real thing); gloo only to exercise the N>1 code path on one GPU")
     p.add_argument("--single-device", action="store_true",
                    help="debug: every rank uses cuda:0 (with --dist-backend gloo), to test the N>1 path on a 1-GPU box")
-    p.add_argument("--profile-stride", type=int, default=8,
-                   help="bracket every n-th kernel launch of the timed region with HIP events (0 = none)")
+    p.add_argument("--profile-stride", type=int, default=-1,
+                   help="time every n-th launch of the dominant kernel in the timed region (events carried by the "
+                        "dispatch); -1 = chosen so that 20 .. 64 launches are sampled, 0 = none")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise torch.distributed (RCCL with --dist-backend nccl) even at world_size 1 and run every "
+                        "collective of the N>1 path: communicator creation, device all_gather, all_reduce, barrier")
     p.add_argument("--launch-timeout", type=float, default=3000.0, help="seconds the parent waits for its ranks")
     p.add_argument("--dry-launch", action="store_true",
                    help="ranks only rendezvous (gloo, CPU) and report their environment: tests the launcher without a GPU")
@@ -389,27 +400,28 @@ def main(argv=None):
         return dry_rank(args, rank, local_rank, world)
 
     import numpy as np
-    import torch  # device memory for the synthetic candidates, stream, torch.distributed (plumbing)
+    import torch  # device memory for the synthetic candidates, streams, events, torch.distributed (plumbing)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     if args.single_device:
+        if args.dist_backend == "nccl" and world > 1:
+            raise SystemExit("bench.py: --single-device puts every rank on cuda:0, which RCCL refuses (one communicator "
+                             "rank per GPU); use it with --dist-backend gloo")
         local_rank = 0
-    if local_rank >= torch.cuda.device_count():
-        if torch.cuda.device_count() == 1 and world > 1:
-            local_rank = 0  # the launcher masked the devices per rank (HIP_VISIBLE_DEVICES): each rank sees its own GPU as 0
-        else:
-            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} "
-                             "device(s) are visible (use --single-device --dist-backend gloo to exercise the N>1 path "
-                             "on one GPU)")
+    if local_rank >= torch.cuda.device_count():  # never alias two ranks onto one GPU silently
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} "
+                         "device(s) are visible (to exercise the N>1 path on one GPU: --single-device --dist-backend gloo)")
     torch.cuda.set_device(local_rank)
     dist = None
     coll_dev = torch.device("cuda", local_rank)  # where collective payloads live
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        if args.dist_backend == "nccl":  # RCCL: the communicator is bound to this rank's GPU at creation
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=coll_dev)
         else:
             coll_dev = torch.device("cpu")
@@ -421,7 +433,8 @@ def main(argv=None):
 
     K, Nh = args.candidates, args.nactor
     total_envs = args.batch if args.scaling == "strong" else args.batch * world
-    stream_ptr = torch.cuda.current_stream().cuda_stream
+    main_stream = torch.cuda.current_stream()
+    stream_ptr = main_stream.cuda_stream
     tdtype = torch.float32 if args.dtype == "f32" else torch.float64
     esz = 4 if args.dtype == "f32" else 8
     streamed = args.regime == "streamed"
@@ -438,11 +451,14 @@ def main(argv=None):
         from rcognita_amd.pool import MixedPool
 
         counts = {"3wrobot": total_envs // 3 + total_envs % 3, "3wrobotNI": total_envs // 3, "2tank": total_envs // 3}
-        pool = MixedPool(counts, rank=rank, world=world, device=local_rank, dtype=args.dtype, Nactor=Nh)
+        # the three homogeneous segments are independent: each handle runs on a HIP stream of its own, so the tail of one
+        # segment's kernel overlaps the head of the next (each is a short launch of ~5 500 waves).  The streams are
+        # torch's here, so that this harness can record its events ON them.
+        pool = MixedPool(counts, rank=rank, world=world, device=local_rank, dtype=args.dtype, Nactor=Nh, own_streams=False)
+        streams = [torch.cuda.Stream() for _ in pool.segments]
+        pool.set_streams([st.cuda_stream for st in streams])
         rng = np.random.default_rng(1234 + rank)
         pool.set_states({s.name: pool_states(rng, s.name, s.hi - s.lo) for s in pool.segments})
-        # (the three homogeneous segments are independent: MixedPool gives each handle a HIP stream of its own, so the
-        # tail of one segment's kernel overlaps the head of the next - each is a short launch of ~5 500 waves)
         engines = [s.engine for s in pool.segments]
         B = pool.n_envs
         tick = lambda: pool.control_tick(K)
@@ -461,35 +477,25 @@ def main(argv=None):
             bhi = torch.tensor(bnds[:, 1], device="cuda", dtype=tdtype)
             cand = (torch.rand((B, K, Nh, eng.du), generator=g, device="cuda", dtype=tdtype) * (bhi - blo) + blo).contiguous()
         engines = [eng]
+        streams = [main_stream]
         tick = lambda: eng.control_tick(cand, K=K)
     du, ds = (1, 2) if args.config == "C3" else (2, 5)
 
-    # ---- untimed: clock pre-spin (>= PRESPIN_S of the same kernels), then the W warm-up steps ------------------------
-    # The GPU reaches its steady clock after ~100 ticks (20 ms) of CONTINUOUS work and falls back within 10 ms of idling
-    # (tools/clock_ramp.py), so the spin never lets the queue run dry: the host waits on the event recorded two chunks
-    # ago, and the warm-up and the timed region follow without a gap.
-    prespin = 0
-    t_spin = time.perf_counter()
-    evs, chunk_ms = [], []
-    while True:
-        for _ in range(32):
-            tick()
-        prespin += 32
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        evs.append(ev)
-        if len(evs) >= 4:
-            evs[-3].synchronize()  # two chunks stay queued behind it: the GPU never runs dry
-            chunk_ms.append(evs[-4].elapsed_time(evs[-3]))
-            spun = time.perf_counter() - t_spin
-            # steady = the last four chunks within 1.5 % of each other (a box that has just been handed over can need
-            # longer than a warm one); never less than PRESPIN_S, never more than PRESPIN_MAX_S
-            last = chunk_ms[-4:]
-            steady = len(last) == 4 and (max(last) - min(last)) <= 0.015 * min(last)
-            if (spun >= PRESPIN_S and steady) or spun >= PRESPIN_MAX_S:
-                break
-    for _ in range(args.warmup):
-        tick()
+    def record_all():
+        """One timing event per engine stream, recorded now (in-stream, no host wait)."""
+        evs = []
+        for st in streams:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(st)
+            evs.append(ev)
+        return evs
+
+    def span_ms(starts, stops):
+        """Device time from the earliest start to the latest stop (the engines' streams run side by side)."""
+        return max(a.elapsed_time(b) for a in starts for b in stops)
+
+    # ---- everything the timed region needs exists BEFORE the clock pre-spin: no allocation, no event creation, no host
+    # synchronisation stands between the warm-up steps and the timed steps ----------------------------------------------
     Bmax = B
     if dist is not None:  # ragged shards: the all_gather payload is padded to the largest shard
         bm = torch.tensor([B], dtype=torch.int64, device=coll_dev)
@@ -497,6 +503,7 @@ def main(argv=None):
         Bmax = int(bm.item())
     returns_dev = torch.zeros(Bmax, device="cuda", dtype=tdtype)
     gathered = [torch.empty(Bmax, device=coll_dev, dtype=tdtype) for _ in range(world)] if dist is not None else None
+    torch.cuda.synchronize()  # the buffers above were filled on torch's stream; the engines may run on others
 
     def exchange_returns():
         """Episode-end exchange: ONE all_gather of the per-env running returns over RCCL."""
@@ -504,45 +511,102 @@ def main(argv=None):
         for e in engines:
             N.check(N.lib().rcg_get_field(e._h, N.FIELD_ACCUM, returns_dev[off:].data_ptr(), N.DEVICE), e._h)
             off += e.B
-        if pool is not None:  # the segments' copies ran on their own streams: finish them before the collective reads
-            pool.synchronize()
+        for st in streams:  # the copies ran on the engines' streams: the collective (torch's stream) comes after them
+            if st is not main_stream:
+                main_stream.wait_stream(st)
         dist.all_gather(gathered, returns_dev if coll_dev.type == "cuda" else returns_dev.cpu())
 
     if dist is not None:
         exchange_returns()  # untimed: RCCL builds its rings / channels on the first collective of each kind
+        torch.cuda.synchronize()
 
-    # HIP events around the kernels of the tick on the engine's own stream, inside the timed region; sampled
-    # (every n-th launch) because each event is a marker packet on the stream.
-    # Only the dominant kernel is bracketed, and sparsely: an event is a barrier packet, the bracketed kernel cannot overlap
-    # its dispatch with the tail of the previous one, and a run with every other tick bracketed measured 8 % slower as a
-    # whole (0.246 against 0.205 ms per step).  Short runs keep at least 3 samples.
-    if args.profile_stride > 0:
-        if args.steps // args.profile_stride < 3:
-            args.profile_stride = max(1, args.steps // 3)
-        for e in engines:  # (the first launch after the barrier starts on an idle GPU: sampling starts mid-stride)
-            e.profile((N.KERNEL_ACTOR,), stride=args.profile_stride, skip=args.profile_stride // 2)
+    # ---- untimed: clock pre-spin (>= PRESPIN_S of the same kernels) ----------------------------------------------------
+    # The GPU reaches its steady clock after ~100 ticks (20 ms) of CONTINUOUS work and falls back within 10 ms of idling
+    # (tools/clock_ramp.py), so the spin never lets the queue run dry: the host waits on the events recorded two chunks
+    # ago (on the engines' own streams).
+    prespin = 0
+    t_spin = time.perf_counter()
+    evs, chunk_ms = [], []
+    while True:
+        for _ in range(32):
+            tick()
+        prespin += 32
+        evs.append(record_all())
+        if len(evs) >= 4:
+            for ev in evs[-3]:
+                ev.synchronize()  # two chunks stay queued behind it: the GPU never runs dry
+            chunk_ms.append(span_ms(evs[-4], evs[-3]))
+            spun = time.perf_counter() - t_spin
+            # steady = the last four chunks within 1.5 % of each other (a box that has just been handed over can need
+            # longer than a warm one); never less than PRESPIN_S, never more than PRESPIN_MAX_S
+            last = chunk_ms[-4:]
+            steady = len(last) == 4 and (max(last) - min(last)) <= 0.015 * min(last)
+            if (spun >= PRESPIN_S and steady) or spun >= PRESPIN_MAX_S:
+                break
+
+    # ---- the contract's bracket: barrier + synchronize, W untimed warm-up steps, then EXACTLY K timed steps between two
+    # in-stream events (no host synchronisation in between: the timed steps run in the flow the warm-up steps started),
+    # then synchronize + barrier.  Per-launch durations of the dominant kernel(s) come from events carried by the
+    # dispatches themselves (rcg_profile: hipExtLaunchKernelGGL start / stop stamps), at least 20 of them.
+    prof_kernels = (N.KERNEL_ACTOR, N.KERNEL_CRITIC) if args.config == "C3" else (N.KERNEL_ACTOR,)
+    stride = 0
+    if args.profile_stride != 0:
+        stride = args.profile_stride if args.profile_stride > 0 else max(1, args.steps // 64)
+        if args.steps // stride < 20:
+            stride = max(1, args.steps // 20)
     barrier()
-    t0 = time.perf_counter()
+    t_wall0 = time.perf_counter()
+    for _ in range(args.warmup):
+        tick()
+    if stride:
+        for e in engines:
+            e.profile(prof_kernels, stride=stride)  # host-side switch only: nothing is pending, nothing is waited for
+    ev_start = record_all()
     for _ in range(args.steps):
         tick()
-    if dist is not None:
-        exchange_returns()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    actor_ms = actor_n = sim_ms = sim_n = 0
+    ev_stop = record_all()
     for e in engines:
-        a_ms, a_n = e.profile_read(N.KERNEL_ACTOR)
-        s_ms, s_n = e.profile_read(N.KERNEL_SIM)
-        actor_ms, actor_n, sim_ms, sim_n = actor_ms + a_ms, actor_n + a_n, sim_ms + s_ms, sim_n + s_n
+        e.profile_pause()
+    # the same K steps again without any per-launch event: what the sampling itself costs the stream
+    for _ in range(args.steps):
+        tick()
+    ev_stop2 = record_all()
+    # the episode-end exchange, timed on its own: the design makes ONE exchange per episode (EPISODE_TICKS control ticks),
+    # so its cost enters a step as allgather_ms / EPISODE_TICKS - not once per K steps of a short run
+    n_exch = 5 if dist is not None else 0
+    ex_a, ex_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if n_exch:
+        for st in streams:
+            if st is not main_stream:
+                main_stream.wait_stream(st)
+        ex_a.record(main_stream)
+        for _ in range(n_exch):
+            exchange_returns()
+        ex_b.record(main_stream)
+    barrier()
+    wall_s = time.perf_counter() - t_wall0
+    compute_ms = span_ms(ev_start, ev_stop)
+    unbracketed_ms = span_ms(ev_stop, ev_stop2)
+    allgather_ms = (ex_a.elapsed_time(ex_b) / n_exch) if n_exch else 0.0
+    if dist is not None:  # MAX over ranks (device times of each rank's own stream)
+        tmax = torch.tensor([compute_ms, unbracketed_ms, allgather_ms], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        compute_ms, unbracketed_ms, allgather_ms = (float(v) for v in tmax.tolist())
+    step_ms_compute = compute_ms / args.steps
+    step_ms = step_ms_compute + allgather_ms / EPISODE_TICKS
+    dt = step_ms * args.steps * 1e-3
+
+    samples = {k: np.concatenate([e.profile_samples(k) for e in engines]) for k in prof_kernels} if stride else {}
+    for e in engines:
         e.profile(False)
+    act = samples.get(N.KERNEL_ACTOR, np.zeros(0))
+    actor_n = int(act.size)
+    actor_ms = float(act.sum())
+    launch_info = [e.last_launch(N.KERNEL_ACTOR) for e in engines]
 
     summ = merge_summaries([e.episode_stats(from_accum=True)[0] for e in engines])
-    total = gather_summaries(summ, dist, device=coll_dev)  # per-shard summaries -> whole-job summary
-    ticks_done = prespin + args.warmup + args.steps
+    total = gather_summaries(summ, dist, device=coll_dev, force=args.force_dist)  # per-shard summaries -> whole job
+    ticks_done = prespin + args.warmup + 2 * args.steps
     for e in engines:
         steps_idx = e.get_field(N.FIELD_STEP_IDX)
         assert int(steps_idx.min()) == int(steps_idx.max()) == ticks_done, "step counter mismatch"
@@ -573,20 +637,29 @@ def main(argv=None):
             bytes_launch += B * engines[0].dc * esz  # the env's critic weights travel with its state
     actor_avg_s = (actor_ms / max(actor_n, 1)) * 1e-3
     if args.config == "C5":
-        # one launch per segment, on streams of their own: the launches overlap, so the per-tick figure is the wall time of
+        # one launch per segment, on streams of their own: the launches overlap, so the per-tick figure is the device time of
         # a tick where that is shorter than the sum of the three kernel times
-        actor_avg_s = min(actor_avg_s * len(engines), dt / args.steps)
+        actor_avg_s = min(actor_avg_s * len(engines), step_ms_compute * 1e-3)
     achieved = bytes_launch / actor_avg_s if actor_avg_s > 0 else 0.0
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and args.config != "C5":
         try:
-            traffic = json.load(open(pmc)).get(f"k_actor_{args.regime}_B{B}_K{K}_N{Nh}_{args.dtype}", {}).get(
-                "hbm_bytes_per_launch")
-            traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "                           "stored; not re-measured in this run)"
+            mode_tag = "_RQL" if args.config == "C3" else ""
+            sysname = "2tank" if args.config == "C3" else "3wrobot"
+            keys = [f"k_actor_{args.regime}_{sysname}{mode_tag}_B{B}_K{K}_N{Nh}_{args.dtype}"]
+            if args.config != "C3":
+                keys.append(f"k_actor_{args.regime}_B{B}_K{K}_N{Nh}_{args.dtype}")  # rounds 1-2 key of the C2 shapes
+            table = json.load(open(pmc))
+            for key in keys:
+                if key in table:
+                    traffic = table[key].get("hbm_bytes_per_launch")
+                    traffic_src = (f"profiles/pmc_traffic.json[{key}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                   "this command, stored; not re-measured in this run)")
+                    break
         except Exception:
             traffic = None
-    dma = streamed and K >= 40 and K % 4 == 0 and args.config != "C5" and Nh * du <= 40  # (C3: tank RQL, f32 and f64)
+    kinfo = launch_info[0]
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
               "candidates (BASELINE configs[1])",
@@ -607,7 +680,7 @@ def main(argv=None):
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": step_ms,
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
@@ -617,22 +690,48 @@ def main(argv=None):
                    "candidates": K, "nactor": Nh, "regime": args.regime, "parallelism": f"env-shard x{world}",
                    "actor_cost_evals_per_s": value * K, "prespin_ticks_untimed": prespin,
                    "prespin_last_chunks_ms_per_tick": [round(c / 32, 5) for c in chunk_ms[-4:]]},
+        # how `value` was timed: K steps between two in-stream events (max over ranks), no host synchronisation between
+        # the W warm-up steps and the K timed steps; the episode-end exchange enters per episode, not per K steps
+        "timing": {"clock": "HIP events recorded in-stream around the K timed steps (device time, max over ranks)",
+                   "ms_per_step_compute": step_ms_compute,
+                   "value_compute_only": total_envs / (step_ms_compute * 1e-3),
+                   "allgather_ms": allgather_ms if dist is not None else None,
+                   "episode_ticks": EPISODE_TICKS,
+                   "allgather_ms_per_step": (allgather_ms / EPISODE_TICKS) if dist is not None else None,
+                   "unbracketed_ms_per_step": unbracketed_ms / args.steps,
+                   "wall_ms_per_step_incl_warmup_and_crosscheck": wall_s * 1e3 / (args.warmup + 2 * args.steps),
+                   "note": "unbracketed = the same K steps repeated right behind the timed ones with no per-launch event "
+                           "(the sampling costs the stream ~7 us per sampled launch); wall = host clock from the barrier "
+                           "in front of the warm-up to the barrier behind everything, over all W + 2K steps (+ exchanges)"},
         "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
         "dist_backend": (args.dist_backend if dist is not None else None),
         "launcher": launcher,
         "ranks": rank_info,
-        "roofline": {"bound": "hbm", "kernel": "k_actor_dma" if dma else "k_actor",
+        "roofline": {"bound": "hbm", "kernel": kinfo["kernel"], "kernel_variant": kinfo["variant"],
+                     "envs_per_wave": kinfo["envs_per_wave"],
+                     "kernel_source": "rcg_last_launch (the library's own dispatch)",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": actor_avg_s * 1e3,
-                     "launches_timed": actor_n, "event_stride": args.profile_stride,
-                     "sim_kernel_avg_ms": (sim_ms / sim_n) if sim_n else None,
+                     "median_launch_ms": float(np.median(act)) if actor_n else None,
+                     "min_launch_ms": float(act.min()) if actor_n else None,
+                     "max_launch_ms": float(act.max()) if actor_n else None,
+                     "frac_at_median": (bytes_launch / (float(np.median(act)) * 1e-3) / HBM_PEAK) if actor_n and
+                     args.config != "C5" else None,
+                     "launches_timed": actor_n, "event_stride": stride,
+                     "event_kind": "start / stop events carried by the dispatch (hipExtLaunchKernelGGL), timed region only",
                      "note": ("streamed regime: HBM-bound" if streamed else
                               "generated regime is VALU-bound (see secondary.generated_grid.roofline_valu); the HBM "
                               "fraction is reported for completeness only")},
         "returns_summary": total,
     }
 
+    if N.KERNEL_CRITIC in samples and samples[N.KERNEL_CRITIC].size:
+        cs = samples[N.KERNEL_CRITIC]
+        out["roofline"]["critic_fit_kernel"] = {"kernel": engines[0].last_launch(N.KERNEL_CRITIC)["kernel"],
+                                                "avg_launch_ms": float(cs.mean()), "median_launch_ms": float(np.median(cs)),
+                                                "min_launch_ms": float(cs.min()), "launches_timed": int(cs.size),
+                                                "bound": "latency of the longest active-set walk (DESIGN.md 4)"}
     if not streamed:
         # the generated-candidate regime is bound by VALU instruction issue, not by HBM: price it in lane-instructions/s
         #  with the instruction counts of the stored SQ_INSTS_VALU pass
@@ -776,10 +875,11 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
             torch.cuda.synchronize()
             d4 = time.perf_counter() - t1
             ms4, c4 = e64.profile_read(N.KERNEL_ACTOR)
+            k64 = e64.last_launch(N.KERNEL_ACTOR)["kernel"]
             e64.close()
             b64 = actor_bytes_per_launch(B, K, Nh, du, ds, 8, True)
             sec["f64"] = {"env_control_steps_per_s": B * n4 / d4, "ms_per_step": d4 / n4 * 1e3, "dtype": "f64",
-                          "kernel": "k_actor_dma<double>" if (Nh * du <= 40 and K >= 40 and K % 4 == 0) else "k_actor",
+                          "kernel": k64 + "<double>",
                           "kernel_avg_ms": ms4 / max(c4, 1),
                           "roofline": {"bound": "hbm", "achieved": b64 / (ms4 / max(c4, 1) * 1e-3) / 1e9,
                                        "peak": HBM_PEAK / 1e9, "unit": "GB/s",

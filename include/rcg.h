@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 113 /* 0.1.1 + checkpoint counter, own stream, rcg_control_tick_n */
+#define RCG_VERSION 114 /* 0.1.1 + rcg_last_launch, rcg_profile_samples, rcg_wait_stream (round 3) */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -166,6 +166,11 @@ int rcg_set_stream(rcg_handle* h, void* hip_stream);
 /* Give the handle a non-blocking HIP stream of its own (created here, destroyed by rcg_destroy) and switch to it: for
  * callers without a stream library that drive several independent handles - the segments of a mixed pool - side by side. */
 int rcg_use_own_stream(rcg_handle* h);
+/* Order everything this handle launches from now on AFTER the work queued on `producer_stream` so far (an event recorded
+ * there, waited for on the handle's stream; NULL = the legacy default stream): for device-resident inputs - candidate
+ * tensors, states - written on another stream than the handle's, e.g. torch's current stream when the handle runs on a
+ * stream of its own.  No host synchronisation.  No-op when `producer_stream` is the handle's stream. */
+int rcg_wait_stream(rcg_handle* h, void* producer_stream);
 int rcg_synchronize(rcg_handle* h);
 
 /* Device-memory helpers so that a host language without a GPU array library can drive the ABI. */
@@ -295,11 +300,43 @@ typedef enum rcg_kernel { RCG_KERNEL_ACTOR = 0, RCG_KERNEL_SIM = 1, RCG_KERNEL_C
 /* kernel_mask bits 0..7: bit k set = bracket launches of rcg_kernel k with HIP events recorded on the
  * handle's own stream (1 = the actor kernel only, 7 = all); bits 8..19: sampling stride n (0/1 = every
  * launch, n = every n-th launch of each kernel); bits 20..: launches to let pass before the first sample
- * (< n).  A non-zero mask also resets the totals; 0 stops. */
+ * (< n).  A non-zero mask also resets the totals; 0 stops (and waits for the samples still in flight);
+ * RCG_PROFILE_PAUSE stops sampling without waiting for anything or resetting anything, so that a measured region can be
+ * closed from the host while its launches are still queued. */
+#define RCG_PROFILE_PAUSE 0x80
 int rcg_profile(rcg_handle* h, int32_t kernel_mask);
 /* Synchronise, then return the summed device time (ms) and number of launches of one kernel since
  * the last rcg_profile(h, 1). */
 int rcg_profile_read(rcg_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+/* Synchronise, then copy the duration (ms) of each sampled launch of one kernel since the last rcg_profile(h, mask != 0),
+ * in launch order, into ms_out[0 .. min(cap, n)) and return n in *n_out (the library keeps the first 65536 samples): the
+ * median / min that SURVEY.md 8d asks for are computed by the caller.  A sample is the dispatch's own start / end stamps
+ * (hipExtLaunchKernelGGL events, the figures a rocprofv3 kernel trace shows), not a pair of markers around it. */
+int rcg_profile_samples(rcg_handle* h, int32_t kernel, double* ms_out, int64_t cap, int64_t* n_out);
+
+/* Which kernel served the handle's last launch of a kind (rcg_kernel: the decision, the env step, the critic
+ * bookkeeping) - the dispatch rule lives in the library (rcg_sysops.hpp::launch_actor) and callers that claim "the
+ * production kernel" or label a roofline ask instead of re-deriving it. */
+typedef enum rcg_kernel_id {
+  RCG_KID_NONE = 0,       /* nothing of that kind launched yet                                                       */
+  RCG_KID_ACTOR = 1,      /* k_actor: tile kernel, streamed (VGPR -> LDS staging) or generated candidates             */
+  RCG_KID_ACTOR_DMA = 2,  /* k_actor_dma: the production streamed kernel (LDS-DMA tiles, unrolled register rollout)   */
+  RCG_KID_TICKS = 3,      /* k_ticks: T ticks per launch (rcg_control_ticks)                                          */
+  RCG_KID_ACTOR_OPT = 4,  /* k_actor_opt (rcg_actor_optimize / rcg_control_tick_opt)                                  */
+  RCG_KID_NOMINAL = 5,    /* k_nominal                                                                                */
+  RCG_KID_SIM = 6,        /* k_sim: lane = env                                                                        */
+  RCG_KID_SIM_V = 7,      /* k_sim_v: lane = 16 bytes of consecutive envs                                             */
+  RCG_KID_SIM_DIST = 8,   /* k_sim_dist: env step on the full state [state, disturb]                                  */
+  RCG_KID_CRITIC_FIT = 9, /* k_critic_fit: [env step] + push + [fit]                                                  */
+  RCG_KID_COUNT_ = 10
+} rcg_kernel_id;
+/* variant: k_actor_dma: 0 MPC gamma = 1, 1 MPC discounted, 2 RQL, 3 + critic_struct SQL; k_actor / k_ticks: bit 0 generic
+ * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates; k_critic_fit: critic_struct + 16 * (rows
+ * the instance is compiled for) + 256 * do_sim + 512 * do_fit; others 0.  envs_per_wave: envs a wave owns (k_actor_dma) or
+ * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Each out pointer may be NULL. */
+int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave);
+/* "k_actor_dma", ... ; "?" for an unknown id.  Never NULL. */
+const char* rcg_kernel_name(int32_t kernel_id);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RCG_LIB") or os.path.join(_HERE, "lib", "librcg.so")
 
 # ---- enums (include/rcg.h) -------------------------------------------------------------------
-RCG_VERSION = 113
+RCG_VERSION = 114
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
 SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
 MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
@@ -47,8 +47,13 @@ SYMBOLS = [
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
     "rcg_critic_update", "rcg_control_ticks", "rcg_control_tick_n", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
     "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
+    "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
+# rcg_kernel_id (rcg_last_launch)
+(KID_NONE, KID_ACTOR, KID_ACTOR_DMA, KID_TICKS, KID_ACTOR_OPT, KID_NOMINAL, KID_SIM, KID_SIM_V, KID_SIM_DIST,
+ KID_CRITIC_FIT) = range(10)
+DMA_MPC_G1, DMA_MPC, DMA_RQL, DMA_SQL_0 = 0, 1, 2, 3  # variant of k_actor_dma (rcg_actor_dma.hpp)
 
 
 class RcgCfg(C.Structure):
@@ -141,6 +146,10 @@ def lib():
         "rcg_set_tick_count": (C.c_int, [vp, i64]),
         "rcg_profile": (C.c_int, [vp, i32]),
         "rcg_profile_read": (C.c_int, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
+        "rcg_profile_samples": (C.c_int, [vp, i32, C.POINTER(C.c_double), i64, C.POINTER(i64)]),
+        "rcg_last_launch": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "rcg_kernel_name": (C.c_char_p, [i32]),
+        "rcg_wait_stream": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export what rcg.h declares

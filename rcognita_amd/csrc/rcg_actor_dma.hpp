@@ -38,6 +38,7 @@
 // Tried and removed: two tiles in flight per wave (1.5-3 % slower), the tick's env step fused into the
 // prologue (a wash: +3-4 % kernel time against one saved 7-us launch).
 #pragma once
+#include <hip/hip_ext.h>
 #include "rcg_kernels.hpp"
 
 // cache policy of the direct-to-LDS tile loads (the aux / cpol immediate of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1):
@@ -396,10 +397,11 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
 // ---- launchers: the instances live in their own translation units (rcg_dma_inst.hip, one object per system x
 // element type x group, so that the library builds in parallel); rcg_sysops.hpp only sees this declaration ----------
 // group 0: DMA_MPC_G1, DMA_MPC, DMA_RQL (f64: the two MPC variants); group 1: DMA_SQL_0 .. DMA_SQL_0 + 3 (f32 only).
-// Returns false when there is no instance for (row length r, variant).
+// Returns false when there is no instance for (row length r, variant).  ev_a / ev_b (both or neither): the launch carries
+// them as its start / stop events (rcg_profile, rcg_handle.hpp::ProfScope).
 template <typename Sys, typename real, int GROUP>
 bool launch_dma(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
-                const KParams<real>& P);
+                const KParams<real>& P, hipEvent_t ev_a, hipEvent_t ev_b);
 
 // longest row with an instance, in reals: 40 = the robots' Nactor = 20 (f32: 160 bytes; f64: 320 bytes, a block's four
 // tiles are then 80 KB of LDS - beyond the default dynamic limit, launch_dma raises it for those instances)

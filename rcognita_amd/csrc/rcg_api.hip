@@ -32,9 +32,12 @@ static void prof_drain(rcg_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->ev_pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+    const hipError_t er = hipEventElapsedTime(&ms, p.a, p.b);
+    if (er != hipSuccess) rcg_fail(h, RCG_ERR_HIP, "rcg_profile: hipEventElapsedTime: %s", hipGetErrorString(er));
+    if (er == hipSuccess) {
       h->prof_ms[p.kernel] += ms;
       h->prof_n[p.kernel] += 1;
+      if (h->prof_samples[p.kernel].size() < kProfMaxSamples) h->prof_samples[p.kernel].push_back(ms);
     }
     h->ev_free.push_back(p.a);
     h->ev_free.push_back(p.b);
@@ -203,6 +206,9 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->prof_stride = 1;
   memset(h->prof_seen, 0, sizeof h->prof_seen);
   h->tick_count = 0;
+  h->cur_a = h->cur_b = nullptr;
+  h->order_ev = nullptr;
+  memset(h->last, 0, sizeof h->last);
   h->sys = cfg->sys_id == RCG_SYS_3WROBOT ? &kVt3WRobot : (cfg->sys_id == RCG_SYS_3WROBOT_NI ? &kVt3WRobotNI : &kVt2Tank);
   memset(h->prof_ms, 0, sizeof h->prof_ms);
   memset(h->prof_n, 0, sizeof h->prof_n);
@@ -324,6 +330,7 @@ int rcg_destroy(rcg_handle* h) {
     (void)hipEventDestroy(p.b);
   }
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
+  if (h->order_ev) (void)hipEventDestroy(h->order_ev);
   delete h;
   return RCG_OK;
 }
@@ -345,6 +352,16 @@ int rcg_use_own_stream(rcg_handle* h) {
   if (!h) return RCG_ERR_BAD_ARG;
   if (!h->own_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   return rcg_set_stream(h, (void*)h->own_stream);
+}
+
+int rcg_wait_stream(rcg_handle* h, void* producer_stream) {
+  DeviceGuard dev_guard(h);
+  if (!h) return RCG_ERR_BAD_ARG;
+  if ((hipStream_t)producer_stream == h->stream) return RCG_OK;  // same stream: already ordered
+  if (!h->order_ev) HIPCHK(h, hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+  HIPCHK(h, hipEventRecord(h->order_ev, (hipStream_t)producer_stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, h->order_ev, 0));
+  return RCG_OK;
 }
 
 int rcg_synchronize(rcg_handle* h) {
@@ -579,9 +596,12 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
     if (rc) return rc;
     sim_first = false;
   }
-  h->tick_count += 1;
-  return h->sys->actor(h, "rcg_control_tick", cand, K, nullptr, nullptr, nullptr, nullptr, h->f[RCG_FIELD_ACTION],
-                       h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, sim_first);
+  // (every argument-dependent refusal of the decision step is in check_candidates above; what can still fail below is a
+  // HIP launch error, which leaves the handle unusable anyway.  The tick is counted once it has been issued whole.)
+  rc = h->sys->actor(h, "rcg_control_tick", cand, K, nullptr, nullptr, nullptr, nullptr, h->f[RCG_FIELD_ACTION],
+                     h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, sim_first);
+  if (rc == RCG_OK) h->tick_count += 1;
+  return rc;
 }
 
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T) {
@@ -646,9 +666,10 @@ int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_nominal: the reference defines no nominal controller for 2tank");
   int rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
   if (rc) return rc;
-  h->tick_count += 1;
-  return h->sys->nominal(h, h->f[RCG_FIELD_STATE], h->f[RCG_FIELD_ACTION], nullptr, h->cfg.batch, ctrl_gain, ctrl_pars,
-                         1, true);
+  rc = h->sys->nominal(h, h->f[RCG_FIELD_STATE], h->f[RCG_FIELD_ACTION], nullptr, h->cfg.batch, ctrl_gain, ctrl_pars, 1,
+                       true);
+  if (rc == RCG_OK) h->tick_count += 1;
+  return rc;
 }
 
 int rcg_episode_reset(rcg_handle* h) {
@@ -725,8 +746,12 @@ int rcg_set_tick_count(rcg_handle* h, int64_t ticks) {
 int rcg_profile(rcg_handle* h, int32_t enable) {
   DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
+  if (((unsigned)enable & 0xffu) == RCG_PROFILE_PAUSE) {  // stop sampling; pending samples stay, nothing is waited for
+    h->prof_mask = 0;
+    return RCG_OK;
+  }
   prof_drain(h);
-  h->prof_mask = (unsigned)enable & 0xffu;
+  h->prof_mask = (unsigned)enable & 0x7fu;
   h->prof_stride = (((unsigned)enable >> 8) & 0xfffu) ? (((unsigned)enable >> 8) & 0xfffu) : 1u;
   // bits 20..: launches of each kernel to let pass before the first sample (the first launch after a synchronisation
   // starts on an idle GPU and is not representative of the stream)
@@ -736,6 +761,7 @@ int rcg_profile(rcg_handle* h, int32_t enable) {
   if (enable) {
     memset(h->prof_ms, 0, sizeof h->prof_ms);
     memset(h->prof_n, 0, sizeof h->prof_n);
+    for (auto& v : h->prof_samples) v.clear();
   }
   return RCG_OK;
 }
@@ -748,6 +774,32 @@ int rcg_profile_read(rcg_handle* h, int32_t kernel, double* total_ms, int64_t* l
   if (total_ms) *total_ms = h->prof_ms[kernel];
   if (launches) *launches = h->prof_n[kernel];
   return RCG_OK;
+}
+
+int rcg_profile_samples(rcg_handle* h, int32_t kernel, double* ms_out, int64_t cap, int64_t* n_out) {
+  DeviceGuard dev_guard(h);
+  if (!h || kernel < 0 || kernel >= RCG_KERNEL_COUNT_ || cap < 0 || (cap > 0 && !ms_out))
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_profile_samples: bad argument");
+  prof_drain(h);
+  const std::vector<float>& v = h->prof_samples[kernel];
+  const int64_t n = (int64_t)v.size();
+  for (int64_t i = 0; i < n && i < cap; ++i) ms_out[i] = (double)v[(size_t)i];
+  if (n_out) *n_out = n;
+  return RCG_OK;
+}
+
+int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave) {
+  if (!h || kind < 0 || kind >= RCG_KERNEL_COUNT_) return RCG_ERR_BAD_ARG;
+  if (kernel_id) *kernel_id = h->last[kind].kernel_id;
+  if (variant) *variant = h->last[kind].variant;
+  if (envs_per_wave) *envs_per_wave = h->last[kind].envs_per_wave;
+  return RCG_OK;
+}
+
+const char* rcg_kernel_name(int32_t kernel_id) {
+  static const char* const names[RCG_KID_COUNT_] = {"none",        "k_actor",   "k_actor_dma", "k_ticks",    "k_actor_opt",
+                                                    "k_nominal",   "k_sim",     "k_sim_v",     "k_sim_dist", "k_critic_fit"};
+  return (kernel_id >= 0 && kernel_id < RCG_KID_COUNT_) ? names[kernel_id] : "?";
 }
 
 }  // extern "C"

@@ -9,4 +9,5 @@
 
 template bool rcg::launch_dma<rcg::RCG_INST_SYS, RCG_INST_REAL, RCG_INST_GROUP>(int, int, dim3, dim3, size_t, hipStream_t,
                                                                             const rcg::ActorArgs<RCG_INST_REAL>&,
-                                                                            const rcg::KParams<RCG_INST_REAL>&);
+                                                                            const rcg::KParams<RCG_INST_REAL>&, hipEvent_t,
+                                                                            hipEvent_t);

@@ -11,11 +11,11 @@ namespace rcg {
 
 template <typename Sys, typename real, int GROUP, int R>
 static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
-                         const KParams<real>& P) {
+                         const KParams<real>& P, hipEvent_t ev_a, hipEvent_t ev_b) {
   if constexpr (R > dma_max_row<real>()) {
     return false;
   } else {
-    if (r != R) return launch_dma_r<Sys, real, GROUP, R + 1>(r, variant, grid, block, lds, s, A, P);
+    if (r != R) return launch_dma_r<Sys, real, GROUP, R + 1>(r, variant, grid, block, lds, s, A, P, ev_a, ev_b);
     if constexpr (R % Sys::DU != 0) {
       return false;
     } else {
@@ -25,7 +25,10 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
     if (lds > 64 * 1024) /* f64 rows beyond 256 bytes: four 64-row tiles exceed the default dynamic-LDS limit */     \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 (int)lds);                                                                           \
-    hipLaunchKernelGGL(fn, grid, block, lds, s, A, P);                                                               \
+    if (ev_a)                                                                                                        \
+      hipExtLaunchKernelGGL(fn, grid, block, (std::uint32_t)lds, s, ev_a, ev_b, 0, A, P);                            \
+    else                                                                                                             \
+      hipLaunchKernelGGL(fn, grid, block, lds, s, A, P);                                                             \
     return true;                                                                                                     \
   }
       if constexpr (GROUP == 0) {
@@ -54,8 +57,8 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
 
 template <typename Sys, typename real, int GROUP>
 bool launch_dma(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
-                const KParams<real>& P) {
-  return launch_dma_r<Sys, real, GROUP, 1>(r, variant, grid, block, lds, s, A, P);
+                const KParams<real>& P, hipEvent_t ev_a, hipEvent_t ev_b) {
+  return launch_dma_r<Sys, real, GROUP, 1>(r, variant, grid, block, lds, s, A, P, ev_a, ev_b);
 }
 
 }  // namespace rcg

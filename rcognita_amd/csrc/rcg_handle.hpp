@@ -4,6 +4,7 @@
 // system-independent kernels; rcg_sys_<system>.hip each instantiate every system-templated kernel and
 // launcher for one environment (rcg_sysops.hpp) and export them through a SysVTable.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -39,7 +40,21 @@ struct rcg_handle {
   std::vector<Pending> ev_pending;
   double prof_ms[RCG_KERNEL_COUNT_];
   int64_t prof_n[RCG_KERNEL_COUNT_];
+  std::vector<float> prof_samples[RCG_KERNEL_COUNT_];  // per-launch durations (ms), launch order, first kProfMaxSamples
+  hipEvent_t cur_a, cur_b;  // event pair of the ProfScope whose sample is due: the next RCG_LAUNCH carries it
+  hipEvent_t order_ev;      // rcg_wait_stream's event (created on first use)
+  // rcg_last_launch: which kernel served the last launch of each kind
+  struct LastLaunch {
+    int32_t kernel_id, variant, envs_per_wave;
+  } last[RCG_KERNEL_COUNT_];
 };
+static constexpr size_t kProfMaxSamples = 65536;
+
+static inline void note_launch(rcg_handle* h, int kind, int kernel_id, int variant, int envs_per_wave) {
+  h->last[kind].kernel_id = kernel_id;
+  h->last[kind].variant = variant;
+  h->last[kind].envs_per_wave = envs_per_wave;
+}
 
 // [0,392) R1|R2 as f32, [512,1296) R1|R2 as f64, [1296,2256) w_init|w_min|w_max as f64
 static constexpr size_t kConstR64 = 512, kConstW = 1296, kConstBytes = 2256;
@@ -56,7 +71,13 @@ int rcg_fail(rcg_handle* h, int code, const char* fmt, ...);
                       __LINE__);                                                                        \
   } while (0)
 
-// RAII bracket: records start/stop events around the launches made while it is alive
+// Measurement (rcg_profile).  A sampled launch carries an event pair IN its dispatch (hipExtLaunchKernelGGL): the
+// events read the dispatch packet's own start / end stamps, the figures a rocprofv3 kernel trace shows.  Rounds 1-2
+// recorded marker events before and after the launch instead; the bracket then contained the drain of the stream in
+// front of the kernel (tools/event_probe.hip on MI355X, 1.35 GB streaming kernel: markers 192.4 us, dispatch stamps
+// 190.6 us).  Either way a timed launch costs the stream ~7 us (the completion signal is written and waited for before
+// the next dispatch), so callers sample with a stride.
+// RAII: while a ProfScope whose sample is due is alive, the handle's next RCG_LAUNCH takes its events.
 struct ProfScope {
   rcg_handle* h;
   hipEvent_t a, b;
@@ -65,8 +86,6 @@ struct ProfScope {
   ProfScope(rcg_handle* h_, int kernel_)
       : h(h_), a(nullptr), b(nullptr), kernel(kernel_), on((h_->prof_mask >> kernel_) & 1u) {
     if (!on) return;
-    // sampled: only every prof_stride-th launch of this kernel is bracketed (each event is a marker packet
-    // on the stream; bracketing every launch of a ~230 us kernel costs a few percent of throughput)
     if ((h->prof_seen[kernel]++ % h->prof_stride) != 0) {
       on = false;
       return;
@@ -76,18 +95,41 @@ struct ProfScope {
         *e = h->ev_free.back();
         h->ev_free.pop_back();
       } else if (hipEventCreate(e) != hipSuccess) {
+        if (a) h->ev_free.push_back(a);
+        a = b = nullptr;
         on = false;
         return;
       }
     }
-    (void)hipEventRecord(a, h->stream);
+    h->cur_a = a;
+    h->cur_b = b;
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(b, h->stream);
-    h->ev_pending.push_back({a, b, kernel});
+    if (h->cur_a == nullptr) {  // a launch took the pair
+      h->ev_pending.push_back({a, b, kernel});
+    } else {  // no launch was made inside the scope (an argument check failed): nothing to time
+      h->cur_a = h->cur_b = nullptr;
+      h->ev_free.push_back(a);
+      h->ev_free.push_back(b);
+    }
   }
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
 };
+
+// Launch on the handle's stream; inside a due ProfScope the FIRST launch carries the scope's event pair.
+#define RCG_LAUNCH(h, kern, grid, block, lds, ...)                                                                 \
+  do {                                                                                                             \
+    rcg_handle* h__ = (h);                                                                                         \
+    if (h__->cur_a) {                                                                                              \
+      hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)(lds), h__->stream, h__->cur_a, h__->cur_b, 0,       \
+                            __VA_ARGS__);                                                                          \
+      h__->cur_a = h__->cur_b = nullptr;                                                                           \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL(kern, grid, block, lds, h__->stream, __VA_ARGS__);                                        \
+    }                                                                                                              \
+  } while (0)
 
 template <typename real>
 inline const rcg::KParams<real>& params(const rcg_handle* h);

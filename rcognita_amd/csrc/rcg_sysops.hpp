@@ -117,11 +117,12 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
       D.episode_idx = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
       D.D = disturb_pars(h);
       if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
-        hipLaunchKernelGGL((k_sim_dist<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, D,
+        RCG_LAUNCH(h, (k_sim_dist<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, D,
                            params<real>(h));
       else
-        hipLaunchKernelGGL((k_sim_dist<Sys, real, false>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, D,
+        RCG_LAUNCH(h, (k_sim_dist<Sys, real, false>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, D,
                            params<real>(h));
+      note_launch(h, RCG_KERNEL_SIM, RCG_KID_SIM_DIST, 0, 64);
       HIPCHK(h, hipGetLastError());
       return (int)RCG_OK;
     }
@@ -129,17 +130,19 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
     // 16 B per lane and component (k_sim_v) pays once the launch is bandwidth- rather than latency-bound, and only for
     // the light dynamics: 2tank at 2^24 envs 4.7 -> 5.6 TB/s; the robots' RK4 (four accurate sin/cos per substep) with
     // VEC envs per lane needs 112 VGPRs instead of 70 and got SLOWER (5.76 -> 5.2 TB/s), so they stay on k_sim
+    note_launch(h, RCG_KERNEL_SIM, RCG_KID_SIM, 0, 64);
     if (Sys::DS <= 2 && h->cfg.batch % VEC == 0 && h->cfg.batch >= (1 << 18)) {
       const dim3 gridv(blocks_for(h->cfg.batch / VEC));
       if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
-        hipLaunchKernelGGL((k_sim_v<Sys, real, true>), gridv, dim3(256), 0, h->stream, A, params<real>(h));
+        RCG_LAUNCH(h, (k_sim_v<Sys, real, true>), gridv, dim3(256), 0, A, params<real>(h));
       else
-        hipLaunchKernelGGL((k_sim_v<Sys, real, false>), gridv, dim3(256), 0, h->stream, A, params<real>(h));
+        RCG_LAUNCH(h, (k_sim_v<Sys, real, false>), gridv, dim3(256), 0, A, params<real>(h));
+      note_launch(h, RCG_KERNEL_SIM, RCG_KID_SIM_V, 0, 64 * (int)VEC);
     } else if (h->cfg.flags & RCG_FLAG_HAS_TARGET)
-      hipLaunchKernelGGL((k_sim<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, A,
+      RCG_LAUNCH(h, (k_sim<Sys, real, true>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, A,
                          params<real>(h));
     else
-      hipLaunchKernelGGL((k_sim<Sys, real, false>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, h->stream, A,
+      RCG_LAUNCH(h, (k_sim<Sys, real, false>), dim3(blocks_for(h->cfg.batch)), dim3(256), 0, A,
                          params<real>(h));
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
@@ -175,9 +178,9 @@ static int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, 
 #define RCG_FIT(CS)                                                                                                    \
   do {                                                                                                                 \
     if (m <= 3)                                                                                                        \
-      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, 3>), grid, block, 0, h->stream, F, h->p64, params<real>(h));     \
+      RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, 3>), grid, block, 0, F, h->p64, params<real>(h));     \
     else                                                                                                               \
-      hipLaunchKernelGGL((k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, h->stream, F, h->p64,             \
+      RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, F, h->p64,             \
                          params<real>(h));                                                                             \
   } while (0)
     switch (h->cfg.critic_struct) {
@@ -187,21 +190,24 @@ static int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, 
       default: RCG_FIT(RCG_CRITIC_QUAD_MIX); break;
     }
 #undef RCG_FIT
+    note_launch(h, RCG_KERNEL_CRITIC, RCG_KID_CRITIC_FIT,
+                h->cfg.critic_struct + 16 * (m <= 3 ? 3 : kFitMaxRows) + (F.do_sim ? 256 : 0) + (do_fit ? 512 : 0), 64);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
 }
 
-// Development knobs of the actor launcher, read from the environment ONCE per process (they select between variants
-// of the same computation for A/B measurements; none of them changes results beyond rounding):
+// Development knobs of the actor launcher.  They select between variants of the same computation for A/B measurements
+// (none changes results beyond rounding) and exist ONLY in -DRCG_DEV builds (`make dev`, librcg_dev.so, chosen by a tool
+// with RCG_LIB=...): the production library never reads the environment - its schedule is the one measured and shipped.
 //   RCG_ACTOR_KERNEL=plain  force k_actor instead of k_actor_dma      RCG_GPW=<n>  envs per persistent wave
-//   RCG_DBG=<bits>          -DRCG_DEV builds only (librcg_dev.so): 1 skip the rollout, 2 skip argmin + writes, 4 skip
-//                           env-state loads - timing only, wrong results; the production library ignores it
+//   RCG_DBG=<bits>          1 skip the rollout, 2 skip argmin + writes, 4 skip env-state loads - timing only, wrong results
 //   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL / SQL on k_actor
 //   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
 //   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor      RCG_NO_GEN_MULTI=1  generated tiles one at a time
-// tests/test_hip_knobs.py checks that the scheduling variants reproduce the default launch bit for bit; bench.py
-// refuses to run with any RCG_* variable set.
+//   RCG_NO_PACK=1           streamed K < 40 on k_actor instead of the packed-tile k_actor_dma instances
+// tests/test_hip_knobs.py checks (on librcg_dev.so) that the scheduling variants reproduce the default launch bit for
+// bit, and that the production library ignores every one of them; bench.py refuses to run with any RCG_* variable set.
 struct DevKnobs {
   int dbg = 0;
   bool force_plain = false, no_g1 = false;
@@ -214,13 +220,13 @@ struct DevKnobs {
   long plain_lds = 0;
   bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL and SQL go to k_actor (A/B against the critic instances)
   bool no_gen_multi = false;  // RCG_NO_GEN_MULTI=1: generated tiles one at a time (no shared sub-trajectory)
+  bool no_pack = false;
 };
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
     DevKnobs v;
 #ifdef RCG_DEV
     if (const char* e = getenv("RCG_DBG")) v.dbg = atoi(e);
-#endif
     if (const char* e = getenv("RCG_ACTOR_KERNEL")) v.force_plain = !strcmp(e, "plain");
     if (const char* e = getenv("RCG_GPW")) v.gpw = atol(e);
     if (const char* e = getenv("RCG_LDS_PAD")) v.lds_pad = atol(e);
@@ -229,6 +235,8 @@ static inline const DevKnobs& dev_knobs() {
     v.mpc_only = getenv("RCG_DMA_MPC_ONLY") != nullptr;
     v.no_gen_multi = getenv("RCG_NO_GEN_MULTI") != nullptr;
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
+    v.no_pack = getenv("RCG_NO_PACK") != nullptr;
+#endif
     return v;
   }();
   return k;
@@ -365,17 +373,21 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     else
       variant = DMA_SQL_0 + c.critic_struct;
     bool ok = false;
+    const hipEvent_t ev_a = h->cur_a, ev_b = h->cur_b;  // a due ProfScope's pair travels in the dispatch
     if (variant < DMA_SQL_0) {
-      ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, A, P);
+      ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
     } else {
-      if constexpr (is_f32) ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P);  // no f64 group 1
+      if constexpr (is_f32)  // no f64 group 1
+        ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
     }
     if (!ok) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d reals", who, R);
+    h->cur_a = h->cur_b = nullptr;
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA, variant, (int)gpw);
     HIPCHK(h, hipGetLastError());
     return RCG_OK;
   }
 #define RCG_LAUNCH_ACTOR(GEN, TGT, STR) \
-  hipLaunchKernelGGL((k_actor<Sys, real, GEN, TGT, STR>), dim3(blocks), dim3(64 * wpb), lds, h->stream, A, P)
+  RCG_LAUNCH(h, (k_actor<Sys, real, GEN, TGT, STR>), dim3(blocks), dim3(64 * wpb), lds, A, P)
 #define RCG_LAUNCH_ACTOR2(GEN, TGT)      \
   do {                                   \
     if (cand)                            \
@@ -396,6 +408,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   }
 #undef RCG_LAUNCH_ACTOR2
 #undef RCG_LAUNCH_ACTOR
+  note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR, (generic ? 1 : 0) | (tgt ? 2 : 0) | (cand ? 4 : 0), A.G);
   HIPCHK(h, hipGetLastError());
   return RCG_OK;
 }
@@ -455,9 +468,10 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
     }
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
     if (tgt)
-      hipLaunchKernelGGL((k_actor_opt<Sys, real, true>), grid, block, lds, h->stream, A, P);
+      RCG_LAUNCH(h, (k_actor_opt<Sys, real, true>), grid, block, lds, A, P);
     else
-      hipLaunchKernelGGL((k_actor_opt<Sys, real, false>), grid, block, lds, h->stream, A, P);
+      RCG_LAUNCH(h, (k_actor_opt<Sys, real, false>), grid, block, lds, A, P);
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_OPT, tgt ? 2 : 0, OPT_G);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
@@ -504,13 +518,14 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
     const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
     if (generic && tgt)
-      hipLaunchKernelGGL((k_ticks<Sys, real, true, true>), grid, block, 0, h->stream, A, P);
+      RCG_LAUNCH(h, (k_ticks<Sys, real, true, true>), grid, block, 0, A, P);
     else if (generic)
-      hipLaunchKernelGGL((k_ticks<Sys, real, true, false>), grid, block, 0, h->stream, A, P);
+      RCG_LAUNCH(h, (k_ticks<Sys, real, true, false>), grid, block, 0, A, P);
     else if (tgt)
-      hipLaunchKernelGGL((k_ticks<Sys, real, false, true>), grid, block, 0, h->stream, A, P);
+      RCG_LAUNCH(h, (k_ticks<Sys, real, false, true>), grid, block, 0, A, P);
     else
-      hipLaunchKernelGGL((k_ticks<Sys, real, false, false>), grid, block, 0, h->stream, A, P);
+      RCG_LAUNCH(h, (k_ticks<Sys, real, false, false>), grid, block, 0, A, P);
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_TICKS, (generic ? 1 : 0) | (tgt ? 2 : 0), A.G);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
@@ -538,7 +553,8 @@ static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, 
       A.I = ctrl_pars ? ctrl_pars[1] : c.pars[1];
       A.clip = clip;
       ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
-      hipLaunchKernelGGL((k_nominal<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, A, params<real>(h));
+      RCG_LAUNCH(h, (k_nominal<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, A, params<real>(h));
+      note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_NOMINAL, 0, 64);
       HIPCHK(h, hipGetLastError());
       return (int)RCG_OK;
     });

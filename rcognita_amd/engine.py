@@ -261,6 +261,12 @@ class Engine:
     def synchronize(self):
         N.check(N.lib().rcg_synchronize(self._h), self._h)
 
+    def wait_stream(self, producer_stream_ptr: Optional[int]):
+        """Order this handle's next launches after everything queued so far on another HIP stream (rcg_wait_stream):
+        needed when a device-resident input was written on a stream other than the handle's - e.g. torch's current
+        stream while the handle runs on a stream of its own.  No host synchronisation."""
+        N.check(N.lib().rcg_wait_stream(self._h, C.c_void_p(producer_stream_ptr or 0)), self._h)
+
     # ------------------------------------------------------------------ device memory
     def empty(self, shape, dtype=None) -> DeviceArray:
         return DeviceArray(self, shape, self.real if dtype is None else dtype)
@@ -682,8 +688,30 @@ class Engine:
             mask |= (int(skip) % stride) << 20
         N.check(N.lib().rcg_profile(self._h, mask), self._h)
 
+    def profile_pause(self):
+        """Stop sampling without waiting for the launches still queued (RCG_PROFILE_PAUSE); the samples stay readable."""
+        N.check(N.lib().rcg_profile(self._h, 0x80), self._h)
+
     def profile_read(self, kernel=N.KERNEL_ACTOR):
         """(total device ms, launches) of one kernel since ``profile(True)``."""
         ms, n = C.c_double(), C.c_int64()
         N.check(N.lib().rcg_profile_read(self._h, int(kernel), C.byref(ms), C.byref(n)), self._h)
         return ms.value, n.value
+
+    def profile_samples(self, kernel=N.KERNEL_ACTOR) -> np.ndarray:
+        """Duration (ms) of every sampled launch of one kernel since ``profile(...)``, in launch order
+        (rcg_profile_samples): the dispatches' own start / end stamps."""
+        n = C.c_int64()
+        N.check(N.lib().rcg_profile_samples(self._h, int(kernel), None, 0, C.byref(n)), self._h)
+        out = np.empty(max(n.value, 1), dtype=np.float64)
+        N.check(N.lib().rcg_profile_samples(self._h, int(kernel), out.ctypes.data_as(C.POINTER(C.c_double)), n.value,
+                                            C.byref(n)), self._h)
+        return out[:n.value]
+
+    def last_launch(self, kind=N.KERNEL_ACTOR):
+        """Which kernel served the last launch of a kind (rcg_last_launch):
+        ``{"kernel": "k_actor_dma", "kernel_id": 2, "variant": 0, "envs_per_wave": 8}``."""
+        kid, var, epw = C.c_int32(), C.c_int32(), C.c_int32()
+        N.check(N.lib().rcg_last_launch(self._h, int(kind), C.byref(kid), C.byref(var), C.byref(epw)), self._h)
+        return {"kernel": N.lib().rcg_kernel_name(kid.value).decode(), "kernel_id": kid.value, "variant": var.value,
+                "envs_per_wave": epw.value}

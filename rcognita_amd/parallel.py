@@ -59,9 +59,10 @@ def merge_summaries(parts) -> Dict[str, float]:
     return out
 
 
-def gather_summaries(summary: Dict[str, float], dist=None, device=None) -> Dict[str, float]:
-    """all_gather of one 6-double summary per rank (48 B per rank: latency-bound)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def gather_summaries(summary: Dict[str, float], dist=None, device=None, force: bool = False) -> Dict[str, float]:
+    """all_gather of one 6-double summary per rank (48 B per rank: latency-bound).  ``force``: run the
+    collective even in a world of one (exercises the communicator on a single-GPU box)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return merge_summaries([summary])
     import torch
 
@@ -73,11 +74,11 @@ def gather_summaries(summary: Dict[str, float], dist=None, device=None) -> Dict[
     return merge_summaries(dict(zip(SUMMARY_KEYS, p.tolist())) for p in parts)
 
 
-def gather_returns(returns, dist=None):
+def gather_returns(returns, dist=None, force: bool = False):
     """all_gather of per-env episode returns (BASELINE configs[3]).  ``returns``: 1-D torch tensor on
     the rank's device (equal length on every rank) or numpy array.  Returns the concatenation in rank
-    order, same kind as the input."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    order, same kind as the input.  ``force``: as :func:`gather_summaries`."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return returns
     import torch
 

@@ -88,11 +88,27 @@ class MixedPool:
         for s in self.segments:
             s.engine.set_state(states[s.name])
 
-    def control_tick(self, K: int, cand: Optional[Dict[str, object]] = None):
+    def control_tick(self, K: int, cand: Optional[Dict[str, object]] = None, producer_stream: Optional[int] = 0,
+                     ordered: bool = False):
         """One env.control-step for every env of the pool: generated level grid of K candidates, or per-type
-        candidate tensors ``cand[name] [n_local, K, N, du]``."""
+        candidate tensors ``cand[name] [n_local, K, N, du]``.
+
+        Stream ordering of device-resident candidates: the segments run on streams of their own, which nothing orders
+        against the stream the caller WROTE ``cand`` on.  So whenever ``cand`` holds device tensors, every segment first
+        waits (on the device, ``rcg_wait_stream``) for the work queued so far on ``producer_stream`` - a raw HIP stream
+        handle; the default 0 is the legacy default stream; with torch, pass
+        ``torch.cuda.current_stream().cuda_stream``.  ``ordered=True``: the caller has already ordered the tensors
+        (an earlier tick waited, or it synchronised) and the wait is skipped."""
+        device_cand = cand is not None and any(not isinstance(c, np.ndarray) for c in cand.values())
         for s in self.segments:
+            if device_cand and not ordered:
+                s.engine.wait_stream(producer_stream)
             s.engine.control_tick(None if cand is None else cand[s.name], K=K)
+
+    def wait_stream(self, producer_stream: Optional[int] = 0):
+        """Every segment's next launch waits for the work queued so far on ``producer_stream`` (see control_tick)."""
+        for s in self.segments:
+            s.engine.wait_stream(producer_stream)
 
     def synchronize(self):
         for s in self.segments:

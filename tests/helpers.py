@@ -96,3 +96,15 @@ def rand_actions(rng, name, shape, overshoot=1.0):
 
 
 TOL = {"f64": 1e-11, "f32": 1e-5}  # f32: the north star's stated tolerance (BASELINE.json)
+
+
+def assert_kernel(eng, kernel, variant=None, kind=None):
+    """The library's own record of which kernel served the handle's last launch of a kind (rcg_last_launch): tests that
+    claim a kernel ask the library instead of re-deriving its dispatch rule."""
+    from rcognita_amd import _native as N
+
+    ll = eng.last_launch(N.KERNEL_ACTOR if kind is None else kind)
+    assert ll["kernel"] == kernel, f"expected {kernel}, the library launched {ll}"
+    if variant is not None:
+        assert ll["variant"] == variant, f"expected variant {variant}, the library launched {ll}"
+    return ll

@@ -23,6 +23,8 @@ def main():
     cand = eng.to_device((rng.random((B, K, Nh, 2), dtype=np.float32) - 0.5) * np.array([600, 200], dtype=np.float32))
     for _ in range(5):
         eng.control_tick(cand, K=K)
+    ll = eng.last_launch(N.KERNEL_ACTOR)
+    print("LAUNCH", ll["kernel"], ll["variant"], ll["envs_per_wave"])
     h = hashlib.sha256()
     for f in (N.FIELD_STATE, N.FIELD_STATE_PREV, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_STEP_IDX, N.FIELD_BEST_IDX,
               N.FIELD_BEST_J, N.FIELD_STATUS):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import rcg_oracle as O
-from tests.helpers import PRESETS, oracle_cfg, rand_states, rel_err_norm
+from tests.helpers import PRESETS, assert_kernel, oracle_cfg, rand_states, rel_err_norm
 
 pytestmark = pytest.mark.gpu
 
@@ -128,6 +128,8 @@ def test_streamed_tick_with_several_envs_per_wave_and_a_ragged_tail(B, K):
     env = O.new_batch(cfg, x0.astype(np.float64))
     # operator mode first (rcg_actor_cost: J of every candidate, staged per wave in LDS and written in one burst)
     J = eng.actor_cost(cand)
+    ll = assert_kernel(eng, "k_actor_dma", N.DMA_MPC_G1)
+    assert ll["envs_per_wave"] > 1, ll
     J_or = O.actor_cost(cand1.astype(np.float64)[None], x0.astype(np.float64)[:, None, :], x0.astype(np.float64)[:, None, :],
                         cfg, pars=env.pars)
     assert J.shape == (B, K) and rel_err_norm(J, J_or) < 1e-5
@@ -170,6 +172,7 @@ def test_long_rows_closed_loop_on_the_production_kernel(name, Nh, ref_lag, dtype
         eng.control_tick(cand, K=K)
         env = PAR.check_tick(cfg, env, cand1.astype(np.float64), PAR.device_fields(eng, N), tol=tol, report=rep,
                              what=f"{name} N={Nh} {dtype} t={t}")
+    assert_kernel(eng, "k_actor_dma", N.DMA_MPC_G1)
     assert rep.ties <= 0.002 * B * T
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
     eng.close()

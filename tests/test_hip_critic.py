@@ -5,7 +5,7 @@ import pytest
 
 from oracle import rcg_oracle as O
 from tests.conftest import load_golden
-from tests.helpers import SYSTEMS, both, rand_actions, rand_states, rel_err_norm
+from tests.helpers import SYSTEMS, assert_kernel, both, rand_actions, rand_states, rel_err_norm
 
 pytestmark = pytest.mark.gpu
 
@@ -152,6 +152,7 @@ def test_streamed_rql_sql_on_the_production_kernel(name, mode, cs):
                         w_critic=w64[:, None, :])
     J = eng.actor_cost(cand)  # W_CRITIC of the handle
     assert J.shape == (B, K)
+    assert_kernel(eng, "k_actor_dma", N.DMA_RQL if mode == O.MODE_RQL else N.DMA_SQL_0 + cs)
     # signed critic weights make J a difference of large terms: the error is measured against the env's largest |J|
     # (what an argmin over the row is sensitive to), 1e-5 as everywhere else in f32
     scale = np.max(np.abs(J_or), axis=1, keepdims=True)

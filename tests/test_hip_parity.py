@@ -10,7 +10,7 @@ import pytest
 
 from oracle import rcg_oracle as O
 from tests.conftest import load_golden
-from tests.helpers import (PRESETS, SYSTEMS, TOL, both, rand_actions, rand_states, rel_err_norm)
+from tests.helpers import (PRESETS, SYSTEMS, TOL, assert_kernel, both, rand_actions, rand_states, rel_err_norm)
 
 pytestmark = pytest.mark.gpu
 
@@ -131,13 +131,17 @@ def test_F4b_reference_actor_cost_through_the_production_kernel(name, dtype):
         B, K = J_ref.shape
         eng, _ = both(name, B, dtype, n_actor=c["N"], mode=O.MODE_IDS[c["mode"]], gamma=c["gamma"],
                       critic_struct=O.CRITIC_IDS[c["critic_struct"]], pred_step_size=c["pred_step_size"], buffer_size=4)
-        eng.set_state(x)
         from rcognita_amd import _native as N
 
+        eng.set_state(x)
         if c["mode"] != "MPC":
             eng.set_field(N.FIELD_W_CRITIC, w)
         cand = eng.to_device(aseq.astype(eng.real))  # device-resident [B][K][N][du]: the streamed path
         J = eng.actor_cost(cand)  # obs = state_sys = the handle's STATE
+        # f64 critic modes of the robots keep 2 x 35 weights in registers and stay on the tile kernel
+        on_dma = c["mode"] == "MPC" or dtype == "f32" or (name == "2tank" and c["mode"] == "RQL")
+        variant = {"MPC": N.DMA_MPC_G1 if c["gamma"] == 1.0 else N.DMA_MPC, "RQL": N.DMA_RQL}.get(c["mode"])
+        assert_kernel(eng, "k_actor_dma" if on_dma else "k_actor", variant if on_dma else None)
         scale = np.max(np.abs(J_ref), axis=1, keepdims=True)
         err = float(np.max(np.abs(J - J_ref) / scale))
         assert err <= TOL[dtype], f"{tag}: J rel err {err:.3e}"
@@ -247,6 +251,7 @@ def test_tank_without_a_target_on_the_production_kernel(mode, cs, dtype):
     if mode != "MPC":
         eng.set_field(N.FIELD_W_CRITIC, w)
     J = eng.actor_cost(eng.to_device(cand.astype(eng.real)))
+    assert_kernel(eng, "k_actor" if (dtype == "f64" and mode == "SQL") else "k_actor_dma")
     J_or = O.actor_cost(cand, x[:, None, :], x[:, None, :], cfg, w_critic=w[:, None, :] if mode != "MPC" else None)
     _close(J, J_or, dtype, msg=f"no-target tank {mode}")
 
@@ -271,6 +276,7 @@ def test_argmin_ties_and_nan(dtype, K):
     cand[2] = np.nan  # every candidate NaN
     eng.set_state(x)
     J = eng.actor_cost(cand)
+    assert_kernel(eng, "k_actor" if K % 4 else "k_actor_dma")
     act, bj, bi = eng.actor_argmin(cand)
     Jc = np.where(np.isnan(J), np.inf, J)
     np.testing.assert_array_equal(bi, np.argmin(Jc, axis=1).astype(np.int32))
