@@ -37,6 +37,25 @@ def test_reference_loop_trace(name, mode):
 
 
 @pytest.mark.parametrize("name", ["3wrobot", "3wrobotNI", "2tank"])
+def test_reference_loop_long_trace_and_the_survey_quality_datapoint(name):
+    """Whole seconds of the reference's loop (fixture F7_long, oracle/gen_f7_long_fixture.py: 3 s of the robots, 20 s of
+    the tank - 400 to 600 simulation steps, 300 SLSQP decisions): the restated loop follows the reference's trace to the
+    same tolerance as the short ones (measured here: bit for bit), and the 3wrobot run ends on the SURVEY's section-6
+    datapoint, accum_obj 389.0."""
+    meta, z = load_golden(f"F7_long_{name}_MPC")
+    ref = z["rows"]
+    cfg = oracle_cfg(name, n_actor=meta["Nactor"], mode=O.MODE_MPC, gamma=1.0, critic_struct=O.CRITIC_QUAD_NOMIX,
+                     n_critic=4, buffer_size=10)
+    loop = RefLoop(cfg, np.array(PRESETS[name]["x0"], dtype=float), meta["t1"],
+                   action_init=[0.5] if name == "2tank" else None)
+    rows = loop.run()
+    assert rows.shape == ref.shape
+    assert np.max(np.abs(rows - ref) / np.maximum(np.abs(ref), 1.0)) < 1e-6
+    if name == "3wrobot":
+        assert abs(ref[-1, -1] - 389.0) < 0.05 and abs(rows[-1, -1] - 389.0) < 0.05
+
+
+@pytest.mark.parametrize("name", ["3wrobot", "3wrobotNI", "2tank"])
 @pytest.mark.parametrize("mode", ["MPC", "RQL", "SQL"])
 def test_ref_loop_callbacks_equal_the_oracle(name, mode):
     """The loop's reference-ordered single-env callbacks are the same functions as the batched oracle's."""
