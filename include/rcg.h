@@ -270,6 +270,11 @@ int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start);
  * Sys2Tank has no nominal controller: RCG_ERR_UNSUPPORTED. */
 int rcg_nominal_action(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double ctrl_gain,
                        const double* ctrl_pars, int32_t clip);
+/* theta* = argmin_theta Fc of CtrlNominal3WRobot._minimizer_theta (controllers.py:1618-1634; SciPy trust-constr there, the
+ * build-defined local search here) for n points: obs device [ds][n] -> theta device [n] (the handle's real), wrapped into
+ * [-pi, pi].  What rcg_nominal_action uses internally; exposed so that the search and the control law can be checked
+ * separately (the law is not Lipschitz in theta).  Sys3WRobot handles only. */
+int rcg_nominal_theta(rcg_handle* h, const void* obs, void* theta, int32_t n);
 /* One control tick under the nominal controller ('--ctrl_mode nominal', presets/main_3wrobot.py:425 through
  * ctrl_selector, controllers.py:58-59): sim_step -> ACTION := clipped nominal action of STATE -> ACCUM, STEP_IDX. */
 int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl_pars);

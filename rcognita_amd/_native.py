@@ -47,7 +47,7 @@ SYMBOLS = [
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
     "rcg_critic_update", "rcg_control_ticks", "rcg_control_tick_n", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
     "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
-    "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream",
+    "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream", "rcg_nominal_theta",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 # rcg_kernel_id (rcg_last_launch)
@@ -138,6 +138,7 @@ def lib():
         "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
         "rcg_nominal_action": (C.c_int, [vp, vp, vp, vp, i32, C.c_double, C.POINTER(C.c_double), i32]),
         "rcg_control_tick_nominal": (C.c_int, [vp, C.c_double, C.POINTER(C.c_double)]),
+        "rcg_nominal_theta": (C.c_int, [vp, vp, vp, i32]),
         "rcg_rhs_full": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32]),
         "rcg_disturb_noise": (C.c_int, [vp, vp, vp]),
         "rcg_episode_reset": (C.c_int, [vp]),

@@ -656,7 +656,15 @@ int rcg_nominal_action(rcg_handle* h, const void* obs, void* action, void* lyap,
   DeviceGuard dev_guard(h);
   if (!h || !obs || (!action && !lyap) || n < 1)
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_nominal_action: obs and one of action/lyap are required, n >= 1");
-  return h->sys->nominal(h, obs, action, lyap, n, ctrl_gain, ctrl_pars, clip, false);
+  return h->sys->nominal(h, obs, action, lyap, nullptr, n, ctrl_gain, ctrl_pars, clip, false);
+}
+
+int rcg_nominal_theta(rcg_handle* h, const void* obs, void* theta, int32_t n) {
+  DeviceGuard dev_guard(h);
+  if (!h || !obs || !theta || n < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_nominal_theta: obs, theta and n >= 1 are required");
+  if (h->cfg.sys_id != RCG_SYS_3WROBOT)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_nominal_theta: only CtrlNominal3WRobot has a theta search");
+  return h->sys->nominal(h, obs, nullptr, nullptr, theta, n, 1.0, nullptr, 0, false);
 }
 
 int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl_pars) {
@@ -666,8 +674,8 @@ int rcg_control_tick_nominal(rcg_handle* h, double ctrl_gain, const double* ctrl
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_nominal: the reference defines no nominal controller for 2tank");
   int rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
   if (rc) return rc;
-  rc = h->sys->nominal(h, h->f[RCG_FIELD_STATE], h->f[RCG_FIELD_ACTION], nullptr, h->cfg.batch, ctrl_gain, ctrl_pars, 1,
-                       true);
+  rc = h->sys->nominal(h, h->f[RCG_FIELD_STATE], h->f[RCG_FIELD_ACTION], nullptr, nullptr, h->cfg.batch, ctrl_gain,
+                       ctrl_pars, 1, true);
   if (rc == RCG_OK) h->tick_count += 1;
   return rc;
 }

@@ -157,8 +157,8 @@ struct SysVTable {
   int (*critic_update)(rcg_handle*, int32_t n_substeps /* 0: no env step */, int32_t do_push, int32_t do_fit);
   int (*optimize)(rcg_handle*, int32_t iters, const void* obs, const void* state_sys, const void* u_init, int shift,
                   void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick);
-  int (*nominal)(rcg_handle*, const void* obs, void* action, void* lyap, int32_t n, double gain, const double* ctrl_pars,
-                 int32_t clip, bool tick);
+  int (*nominal)(rcg_handle*, const void* obs, void* action, void* lyap, void* theta, int32_t n, double gain,
+                 const double* ctrl_pars, int32_t clip, bool tick);
   int (*ticks)(rcg_handle*, int32_t T, int32_t K);
   int (*rhs_full)(rcg_handle*, const void* state, const void* disturb, const void* action, const void* xi, void* dstate,
                   void* ddisturb, void* clipped, int32_t n, int32_t clip);

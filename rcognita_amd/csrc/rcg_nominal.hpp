@@ -93,7 +93,7 @@ template <typename Sys>
 struct Nominal {
   static constexpr bool supported = false;
   template <typename real>
-  __device__ static void act(const real*, real, real, real, real*, real*) {}
+  __device__ static void act(const real*, real, real, real, real*, real*, real*) {}
 };
 
 template <>
@@ -101,7 +101,8 @@ struct Nominal<Sys3WRobotNI> {
   static constexpr bool supported = true;
   // compute_action_vanila (controllers.py:1937-1947) and compute_LF (:1949-1955)
   template <typename real>
-  __device__ static void act(const real* x, real gain, real, real, real* u, real* L) {
+  __device__ static void act(const real* x, real gain, real, real, real* u, real* L, real* th_out) {
+    *th_out = (real)0;  // the closed-form controller has no theta search
     real xn[3], q;
     nom_cart2nh<real>(x[0], x[1], x[2], xn, &q);
     const real r = sqrt_r(xn[0] * xn[0] + xn[1] * xn[1]);
@@ -133,7 +134,7 @@ struct Nominal<Sys3WRobot> {
   static constexpr bool supported = true;
   // compute_action_vanila (controllers.py:1733-1748) with the build's theta search; L = Fc(theta*) (compute_LF)
   template <typename real>
-  __device__ static void act(const real* x, real gain, real m, real I, real* u, real* L) {
+  __device__ static void act(const real* x, real gain, real m, real I, real* u, real* L, real* th_out) {
     real xn[3], q, eta[2];
     nom_cart2nh<real>(x[0], x[1], x[2], xn, &q);
     eta[0] = x[4];
@@ -192,6 +193,7 @@ struct Nominal<Sys3WRobot> {
     }
     real th = (real)0.5 * (a + b);
     th = th > PI ? th - (real)2 * PI : (th < -PI ? th + (real)2 * PI : th);
+    *th_out = th;
     real st, ct, z[3], kap[2], sig;
     nom_sincos<real>(th, &st, &ct);
     nom_zeta_theta<real>(xn, sq3, a3, ct, st, z, &sig);
@@ -210,6 +212,7 @@ struct NomArgs {
   const real* obs;    // [ds][n]
   real* action;       // [du][n] out (or nullptr)
   real* lyap;         // [n] out: compute_LF (or nullptr)
+  real* theta;        // [n] out: theta* of _minimizer_theta (or nullptr; 0 for the closed-form NI controller)
   real* accum;        // tick: accum += rho(obs, action) * sampling_time (or nullptr)
   int32_t* step_idx;  // tick: += 1 (or nullptr)
   long n;
@@ -223,13 +226,13 @@ __global__ __launch_bounds__(256) void k_nominal(const NomArgs<real> A, const KP
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= A.n) return;
   real x[DS], u[DU];
-  double xd[DS], ud[DU], L;
+  double xd[DS], ud[DU], L, th;
 #pragma unroll
   for (int c = 0; c < DS; ++c) {
     x[c] = A.obs[(long)c * A.n + i];
     xd[c] = (double)x[c];
   }
-  Nominal<Sys>::template act<double>(xd, A.gain, A.m, A.I, ud, &L);
+  Nominal<Sys>::template act<double>(xd, A.gain, A.m, A.I, ud, &L, &th);
 #pragma unroll
   for (int c = 0; c < DU; ++c) {
     // compute_action clips (controllers.py:1712-1714), compute_action_vanila does not
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(256) void k_nominal(const NomArgs<real> A, const KP
     for (int c = 0; c < DU; ++c) A.action[(long)c * A.n + i] = u[c];
   }
   if (A.lyap) A.lyap[i] = (real)L;
+  if (A.theta) A.theta[i] = (real)th;
   if (A.accum) {  // upd_accum_obj (controllers.py:1086-1093)
     real chi[NCHI];
     if (P.has_target)

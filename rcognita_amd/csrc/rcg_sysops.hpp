@@ -533,7 +533,7 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
 
 // CtrlNominal3WRobot / CtrlNominal3WRobotNI for n points (tick: the handle's envs, with the tick epilogue)
 template <typename Sys>
-static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double gain,
+static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, void* theta, int32_t n, double gain,
                       const double* ctrl_pars, int32_t clip, bool tick) {
   if constexpr (!Nominal<Sys>::supported) {
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "nominal controller: the reference defines none for this system");
@@ -545,6 +545,7 @@ static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, 
       A.obs = (const real*)obs;
       A.action = (real*)action;
       A.lyap = (real*)lyap;
+      A.theta = (real*)theta;
       A.accum = (tick && !(c.flags & RCG_FLAG_ACCUM_EVERY_SUBSTEP)) ? (real*)h->f[RCG_FIELD_ACCUM] : nullptr;
       A.step_idx = tick ? (int32_t*)h->f[RCG_FIELD_STEP_IDX] : nullptr;
       A.n = n;

@@ -620,6 +620,15 @@ class Engine:
         a = act.T.copy()
         return (a, lyap) if want_lyap else a
 
+    def nominal_theta(self, obs):
+        """theta* of CtrlNominal3WRobot's search for ``obs [n, dy]`` (rcg_nominal_theta) -> ``[n]``."""
+        obs = np.asarray(obs, dtype=self.real).reshape(-1, self.dy)
+        n = obs.shape[0]
+        keep = []
+        (pth,), fetch = self._out_many([((n,), None)])
+        N.check(N.lib().rcg_nominal_theta(self._h, self._in(obs, keep, lambda a: a.T), pth, n), self._h)
+        return fetch()[0]
+
     def control_tick_nominal(self, ctrl_gain, ctrl_pars=None):
         """One env.control-step with the nominal controller as the decision (rcg_control_tick_nominal)."""
         N.check(N.lib().rcg_control_tick_nominal(self._h, float(ctrl_gain), self._ctrl_pars(ctrl_pars)), self._h)

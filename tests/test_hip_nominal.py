@@ -36,24 +36,44 @@ def test_ni_nominal_matches_reference_outputs(dtype):
     assert np.all(np.isnan(a_clip[8:12]))  # exact origin: NaN in the reference, NaN here
 
 
+def _check_search_and_law(x, th, a, L, meta, what, law_tol=1e-8):
+    """HIP against its oracle on EVERY env, the search and the law separately (the law takes cube roots of cancelling sums: it
+    is not Lipschitz in theta, so two correct searches that stop 1e-9 apart may return actions 1e-3 apart).
+    (1) the law: action and Fc evaluated by the oracle AT THE KERNEL'S theta* equal the kernel's, every env;
+    (2) the search: the kernel's theta* is a minimiser as good as the oracle's - Fc agrees to 1e-9 relative on every env -
+        and it is the SAME minimiser: |theta_hip - theta_oracle| < 1e-6 wherever Fc is not flat to rounding between them."""
+    xNI, eta = NO.cart2nh(x)
+    a_at = NO.nominal_action_endi(x, meta["ctrl_gain"], meta["m"], meta["I"], meta["bnds"], theta=th)
+    L_at = NO.lyapunov_endi(x, theta=th)
+    err_a = np.max(np.abs(a - a_at) / (np.abs(a_at) + 1.0))
+    err_L = np.max(np.abs(L - L_at) / L_at)
+    assert err_a <= law_tol, f"{what}: law at the kernel's theta, action rel err {err_a:.2e}"
+    assert err_L <= 1e-11, f"{what}: Fc at the kernel's theta, rel err {err_L:.2e}"
+    th_or = NO.theta_star(xNI, eta)
+    L_or = NO.lyapunov_endi(x, theta=th_or)
+    assert np.max(np.abs(L_at - L_or) / L_or) <= 1e-9, f"{what}: the two searches end on different values of Fc"
+    dth = np.abs(np.angle(np.exp(1j * (th - th_or))))
+    flat = np.abs(L_at - L_or) <= 4e-16 * L_or  # Fc cannot tell the two apart: rounding decides where a search stops
+    assert np.all((dth < 1e-6) | flat), f"{what}: theta* differs by {dth[~flat].max():.2e} where Fc is not flat"
+    assert np.all(dth[flat] < 1e-4), f"{what}: a flat stretch of {dth[flat].max():.2e} rad"
+    return th_or
+
+
 def test_endi_nominal_vs_oracle_and_reference_f64():
-    """(a) HIP == oracle (same theta search, same arithmetic); (b) the reference's own minimiser (trust-constr from
-    theta = 0) on > 90 % of the fixture states and Fc(theta*) not above the reference's on >= 95 %; (c) the clipped
-    actions agree with the reference's on > 90 % of ALL states."""
+    """(a) HIP == oracle on every env: the control law given theta*, and theta* itself (rcg_nominal_theta), separately;
+    (b) the reference's own minimiser (trust-constr from theta = 0) on > 90 % of the fixture states and Fc(theta*) not
+    above the reference's on >= 95 % - the build-defined search against SciPy's, statistical by nature (DESIGN.md 6);
+    (c) the clipped actions agree with the reference's on > 90 % of ALL states."""
     meta, z = load_golden("F10_nominal_3wrobot")
     x = z["state"]
     eng, _ = both("3wrobot", x.shape[0], "f64")
     pars = [meta["m"], meta["I"]]
     a, L = eng.nominal_action(x, meta["ctrl_gain"], ctrl_pars=pars, clip=True, want_lyap=True)
-    a_or = NO.nominal_action_endi(x, meta["ctrl_gain"], meta["m"], meta["I"], meta["bnds"])
-    L_or = NO.lyapunov_endi(x)
-    np.testing.assert_allclose(L, L_or, rtol=1e-9)
-    # the action is a cube root of theta-dependent terms: golden section pins theta to ~1e-9
-    bad = np.abs(a - a_or) > 1e-5 * (np.abs(a_or) + 1)
-    assert bad.mean() < 0.02, bad.mean()
+    th = eng.nominal_theta(x)
+    th_or = _check_search_and_law(x, th, a, L, meta, "F10 states, f64")
+    # (b), (c): against the reference's trust-constr
     assert np.mean(L <= z["Fc_star"] * (1 + 1e-9) + 1e-12) >= 0.95
-    xNI, eta = NO.cart2nh(x)
-    same = np.abs(np.angle(np.exp(1j * (NO.theta_star(xNI, eta) - z["theta_star"])))) < 1e-3
+    same = np.abs(np.angle(np.exp(1j * (th_or - z["theta_star"])))) < 1e-3
     close = np.all(np.abs(a - z["action"]) <= 2e-2 * (np.abs(z["action"]) + 1), axis=1)
     assert same.mean() > 0.9 and close[same].mean() > 0.95 and close.mean() > 0.9
     # handle pars are the default controller parameters
@@ -61,18 +81,20 @@ def test_endi_nominal_vs_oracle_and_reference_f64():
     np.testing.assert_array_equal(a2, a)
 
 
-def test_endi_nominal_f32_reaches_the_same_lyapunov_value():
+def test_endi_nominal_f32_is_the_f64_law_of_the_f32_states_rounded_once():
+    """An f32 handle evaluates the law in float64 on its f32 states (the law is not Lipschitz): action and Lyapunov value
+    are the f64 handle's on those states, rounded to f32 - bit for bit, every env; and those satisfy the oracle checks."""
     meta, z = load_golden("F10_nominal_3wrobot")
     x = z["state"]
-    eng, _ = both("3wrobot", x.shape[0], "f32")
+    e32, _ = both("3wrobot", x.shape[0], "f32")
+    e64, _ = both("3wrobot", x.shape[0], "f64")
     xin = x.astype(np.float32).astype(np.float64)
-    a, L = eng.nominal_action(x, meta["ctrl_gain"], clip=True, want_lyap=True)
-    L_or = NO.lyapunov_endi(xin)
-    assert np.all(np.isfinite(a))
-    assert np.max(np.abs(L - L_or) / L_or) < 1e-6  # f64 law of the f32 states, rounded once
-    a_or = NO.nominal_action_endi(xin, meta["ctrl_gain"], meta["m"], meta["I"], meta["bnds"])
-    close = np.all(np.abs(a - a_or) <= 1e-5 * (np.abs(a_or) + 1), axis=1)
-    assert close.mean() > 0.97, close.mean()
+    a32, L32 = e32.nominal_action(x, meta["ctrl_gain"], clip=True, want_lyap=True)
+    a64, L64 = e64.nominal_action(xin, meta["ctrl_gain"], clip=True, want_lyap=True)
+    assert np.all(np.isfinite(a32))
+    np.testing.assert_array_equal(a32, a64.astype(np.float32))
+    np.testing.assert_array_equal(L32, L64.astype(np.float32))
+    _check_search_and_law(xin, e64.nominal_theta(xin), a64, L64, meta, "F10 states rounded to f32")
 
 
 def test_nominal_unsupported_for_2tank():
@@ -100,15 +122,25 @@ def test_control_tick_nominal_vs_oracle(name, gain):
     eng.set_state(x0)
     env = O.new_batch(cfg, x0)
     m, I = (10.0, 1.0)
+    bnds = np.asarray(cfg.ctrl_bnds, dtype=float)
+    meta = dict(ctrl_gain=gain, m=m, I=I, bnds=bnds)
     for t in range(T):
         eng.control_tick_nominal(gain)
         NO.control_tick_nominal(cfg, env, gain, m, I)
         a = eng.get_field(N.FIELD_ACTION)
-        ok = np.all(np.abs(a - env.action) <= 1e-6 * (np.abs(env.action) + 1), axis=1)
-        assert ok.all() if name == "3wrobotNI" else ok.mean() > 0.9, t
-        env.action = a.astype(np.float64)  # keep the two loops on the same trajectory (theta ties may flip)
-        assert rel_err_norm(eng.get_state(), env.state) < 1e-9
-        env.accum = eng.get_field(N.FIELD_ACCUM).astype(np.float64) if not ok.all() else env.accum
+        assert rel_err_norm(eng.get_state(), env.state) < 1e-9  # same env step (the previous action was synchronised)
+        if name == "3wrobotNI":  # closed form: every env, every tick
+            assert np.all(np.abs(a - env.action) <= 1e-9 * (np.abs(env.action) + 1)), t
+        else:  # every env, every tick: the law at the kernel's theta*, and theta* against the oracle's search
+            x = eng.get_state().astype(np.float64)
+            L = NO.lyapunov_endi(x, theta=eng.nominal_theta(x))
+            _check_search_and_law(x, eng.nominal_theta(x), a, L, meta, f"tick {t}")
+        # continue both loops from the device's action (where Fc is flat the two searches may stop 1e-9 apart, and the law
+        # is not Lipschitz in theta): the NEXT tick is again compared from identical inputs
+        exact = np.all(np.abs(a - env.action) <= 1e-9 * (np.abs(env.action) + 1), axis=1)
+        env.action = a.astype(np.float64)
+        if not exact.all():
+            env.accum = eng.get_field(N.FIELD_ACCUM).astype(np.float64)
         assert rel_err_norm(eng.get_field(N.FIELD_ACCUM), env.accum, floor=float(np.max(np.abs(env.accum)))) < 1e-9
         np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), env.step_idx)
 
