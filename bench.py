@@ -75,7 +75,7 @@ def parse(argv=None):
                    help="debug: every rank uses cuda:0 (with --dist-backend gloo), to test the N>1 path on a 1-GPU box")
     p.add_argument("--profile-stride", type=int, default=-1,
                    help="time every n-th launch of the dominant kernel in the timed region (events carried by the "
-                        "dispatch); -1 = chosen so that 20 .. 64 launches are sampled, 0 = none")
+                        "dispatch); -1 = chosen so that 20 .. 40 launches are sampled, 0 = none")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed (RCCL with --dist-backend nccl) even at world_size 1 and run every "
                         "collective of the N>1 path: communicator creation, device all_gather, all_reduce, barrier")
@@ -551,7 +551,7 @@ def main(argv=None):
     prof_kernels = (N.KERNEL_ACTOR, N.KERNEL_CRITIC) if args.config == "C3" else (N.KERNEL_ACTOR,)
     stride = 0
     if args.profile_stride != 0:
-        stride = args.profile_stride if args.profile_stride > 0 else max(1, args.steps // 64)
+        stride = args.profile_stride if args.profile_stride > 0 else max(1, args.steps // 32)
         if args.steps // stride < 20:
             stride = max(1, args.steps // 20)
     barrier()

@@ -228,7 +228,12 @@ int rcg_sim_step(rcg_handle* h, int32_t n_substeps);
  * cand [B][K][N][du], or NULL for the generated level grid (K levels for du = 1, g*g for du = 2).
  * obs / state_sys as rcg_actor_cost.  Outputs (each may be NULL): action [du][B] = first du
  * entries of the winner (controllers.py:1427), best_J [B], best_idx [B] int32.  Does not modify
- * the handle's ACTION. */
+ * the handle's ACTION.
+ * Non-finite corner: with streamed candidates the stage cost is the full sum chi' R1 chi as numpy evaluates it, so a
+ * component that overflows under a ZERO weight makes J NaN (0 * inf) and the candidate counts as +inf, exactly as in the
+ * reference; the generated grid with the presets' R1 never computes zero-weighted terms (v, omega, F, M of the robots),
+ * so there such a candidate keeps the finite cost of its weighted components.  The two agree whenever every rolled-out
+ * component stays finite in the handle's element type (tests/test_hip_reset_and_guards.py pins both behaviours). */
 int rcg_actor_argmin(rcg_handle* h, const void* cand, int32_t K, const void* obs, const void* state_sys,
                      void* action, void* best_J, int32_t* best_idx);
 /* One env.control-step for every env (the loop body of presets/main_3wrobot.py:419-429):
@@ -239,7 +244,12 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
 /* T consecutive rcg_control_tick(h, NULL, K) - the loop of presets/main_3wrobot.py:415-468 for T sampling periods with
  * the generated candidate grid - in ONE kernel launch: each env's wave keeps state, held action, ACCUM and STEP_IDX in
  * registers and loops over {sim_step, K x _actor_cost, argmin, upd_accum_obj}.  Every field ends bit-identical to T
- * single ticks (same arithmetic); BEST_J / BEST_IDX are the last tick's.  MPC without the disturbance model; other
+ * single ticks on the library as built (same source expressions; tests/test_hip_ticks.py checks it for every system,
+ * element type and shape).  Across compilers the contract is "within rounding" for Sys2Tank: its rollout right-hand side
+ * leaves the choice of fused multiply-adds to the compiler (18-26 % faster than the written-out form), and k_ticks and
+ * k_actor inline it at different call sites; the robots' right-hand sides and every simulator step write their fusions
+ * out.  A checkpoint taken under one entry point and resumed under the other inherits the same caveat.
+ * BEST_J / BEST_IDX are the last tick's.  MPC without the disturbance model; other
  * handles get RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of small batches. */
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* T consecutive rcg_control_tick(h, cand, K) issued by ONE call: the loop of presets/main_3wrobot.py:415-468 for T sampling
@@ -335,7 +345,7 @@ typedef enum rcg_kernel_id {
   RCG_KID_CRITIC_FIT = 9, /* k_critic_fit: [env step] + push + [fit]                                                  */
   RCG_KID_COUNT_ = 10
 } rcg_kernel_id;
-/* variant: k_actor_dma: 0 MPC gamma = 1, 1 MPC discounted, 2 RQL, 3 + critic_struct SQL; k_actor / k_ticks: bit 0 generic
+/* variant: k_actor_dma: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL; k_actor / k_ticks: bit 0 generic
  * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates; k_critic_fit: critic_struct + 16 * (rows
  * the instance is compiled for) + 256 * do_sim + 512 * do_fit; others 0.  envs_per_wave: envs a wave owns (k_actor_dma) or
  * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Each out pointer may be NULL. */

@@ -6,8 +6,8 @@
 // without a row sit out the argmin), the observation target as
 // the system's preset has it; the rollout starts from `state_sys` with `obs` as y_0 (controllers.py:1286-1296) - the same
 // vector in the plain tick, the state before the last substep with RCG_FLAG_REF_LAG (the reference's loop order);
-// candidate rows of R = N*du <= 40 reals; f32: modes MPC, RQL and SQL; f64 (the reference's own arithmetic width):
-// MPC.  Everything else goes to k_actor (rcg_kernels.hpp).
+// candidate rows of R = N*du <= 40 reals; modes MPC, RQL and SQL in f32 and in f64 (the reference's own arithmetic width).
+// Everything else goes to k_actor (rcg_kernels.hpp).
 //
 //   per tile of 64 candidate rows (64*R*sizeof(real) bytes, contiguous in HBM):
 //     1. direct-to-LDS loads: global_load_lds_dwordx4 (64 lanes x 16 B = 1 KiB each) plus global_load_lds_dword (256 B
@@ -55,18 +55,42 @@ namespace rcg {
 //               squares is accumulated per component, S_i += chi_i^2 (one fma per term and step instead of mul + fma + the
 //               discount bookkeeping) and weighted once at the end, J = sum_i R1_ii S_i (measured +1.2 % on C2)
 //   DMA_MPC     MPC, discounted (controllers.py:1304-1306)
-//   DMA_RQL     the last stage cost is replaced by Q_w(y_{N-1}, u_{N-1}) (controllers.py:1307-1310); ONE use of the
-//               critic per rollout, so its structure stays a wave-uniform runtime switch
-//   DMA_SQL_*   J = sum_k Q_w(y_k, u_k), undiscounted (controllers.py:1311-1326): the critic is evaluated at every
-//               unrolled step, so its structure is a compile-time constant (with the runtime switch at each of the N
-//               steps this kernel was 18 % SLOWER than k_actor's specialised rollout)
-// The env's critic weights travel with its state (requested one tile ahead, held in registers).
-enum : int { DMA_MPC_G1 = 0, DMA_MPC = 1, DMA_RQL = 2, DMA_SQL_0 = 3 /* + rcg_critic_struct */, DMA_VARIANTS = 7 };
+//   DMA_RQL_*   the last stage cost is replaced by Q_w(y_{N-1}, u_{N-1}) (controllers.py:1307-1310)
+//   DMA_SQL_*   J = sum_k Q_w(y_k, u_k), undiscounted (controllers.py:1311-1326)
+//               The critic structure is a compile-time constant of both (+ rcg_critic_struct).  Rounds 1-2 served RQL with
+//               ONE instance and a wave-uniform runtime switch at the last step: compiled for the largest structure (35
+//               weights on Sys3WRobot) with the code of all four inline, it needed 183-256 VGPRs (occupancy 2, 1 at rows of
+//               40 floats) and lost 10-20 % of the stream whatever structure actually ran.
+// The env's critic weights travel with its state (requested one tile ahead).  They are wave-uniform - a wave rolls out one
+// env at a time.  Up to 9 of them (the tank; quad-nomix on the robots) are held in registers, 2 x dc (current env, next
+// env).  Instances compiled for more (the robots' RQL instance serves every structure: 35 / 20 weights) park them in LDS:
+// lane i requests weight i of the next env into ONE register, the wave writes the dc values into a small LDS slot of its
+// own when it adopts the env, and the rollouts read them back as broadcast ds_reads (RQL: dc reads per rollout, at the last
+// step; SQL: the regressor is summed over the horizon per feature - one fma per feature and step instead of a product and
+// an fma - and dotted with the weights once, as k_actor's SQL rollout does).  Round 2 kept 2 x 35 weights in registers:
+// the f32 RQL instance of Sys3WRobot needed 221 VGPRs + 149 spilled SGPRs (occupancy 2, 1 at rows of 40 floats) and
+// streamed at 0.68-0.75 of the HBM peak, SQL with 28 / 35 weights at 0.43-0.47; the float64 critic modes of the robots
+// were left on k_actor (0.69).
+enum : int {
+  DMA_MPC_G1 = 0,
+  DMA_MPC = 1,
+  DMA_RQL_0 = 2 /* + rcg_critic_struct */,
+  DMA_SQL_0 = 6 /* + rcg_critic_struct */,
+  DMA_VARIANTS = 10
+};
 
 __host__ __device__ constexpr int dma_dc(int cs, int ds, int du) {
   return cs == RCG_CRITIC_QUAD_LIN ? (ds + du) * (ds + du + 1) / 2 + (ds + du)
                                    : (cs == RCG_CRITIC_QUADRATIC ? (ds + du) * (ds + du + 1) / 2
                                                                  : (cs == RCG_CRITIC_QUAD_NOMIX ? ds + du : ds + ds * du + du));
+}
+
+// bytes of LDS per wave that hold the env's critic weights (0: they live in registers) - shared by the kernel (layout)
+// and the launcher (dynamic-LDS request)
+__host__ __device__ constexpr int dma_wslot(int esz, int variant, int ds, int du) {
+  const int dcmax = variant >= DMA_SQL_0 ? dma_dc(variant - DMA_SQL_0, ds, du)
+                                         : (variant >= DMA_RQL_0 ? dma_dc(variant - DMA_RQL_0, ds, du) : 0);
+  return dcmax > 9 ? ((dcmax * esz + 15) / 16) * 16 : 0;
 }
 
 // v_readlane of a real (the lane index is wave-uniform)
@@ -108,10 +132,13 @@ __host__ __device__ constexpr int dma_rpl(int r, int esz) { return r * esz <= 24
 template <typename Sys, typename real, int R, bool TGT, int V>
 __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
-  constexpr bool G1 = V == DMA_MPC_G1, RQL = V == DMA_RQL, SQL = V >= DMA_SQL_0, CRIT = RQL || SQL;
-  constexpr int CS = SQL ? V - DMA_SQL_0 : -1;  // compile-time critic structure (SQL), -1: P.critic_struct (RQL)
-  constexpr int DCMAX = SQL ? dma_dc(CS, DS, DU) : (RQL ? dma_dc(RCG_CRITIC_QUAD_LIN, DS, DU) : 1);
+  constexpr bool G1 = V == DMA_MPC_G1, SQL = V >= DMA_SQL_0, RQL = V >= DMA_RQL_0 && !SQL, CRIT = RQL || SQL;
+  constexpr int CS = SQL ? V - DMA_SQL_0 : (RQL ? V - DMA_RQL_0 : 0);  // compile-time critic structure
+  constexpr int DCMAX = CRIT ? dma_dc(CS, DS, DU) : 1;
   constexpr int ESZ = (int)sizeof(real);
+  constexpr int WSLOT = dma_wslot(ESZ, V, DS, DU);  // > 0: critic weights in LDS (instances with more than 9 of them)
+  constexpr bool WLDS = WSLOT > 0;
+  constexpr int WREG = WLDS ? 1 : DCMAX;             // register copies of the weights (current env, next env)
   static_assert(R % DU == 0 && R >= DU && R <= 40, "row = N*du reals, at most 40 (f32: 160 bytes, f64: 320)");
   constexpr int N = R / DU;
   constexpr int RPL = dma_rpl(R, ESZ), TROWS = 64 * RPL;           // rows per lane, rows per tile
@@ -145,7 +172,9 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   // the read stream, made the operator 35 % slower than the tick for 5 % more bytes
   // (A.jwave: the staging area holds all envs of the wave and is written once, when the wave is done)
   const int jspan = A.jwave ? A.gpw * K : K;  // reals of staging per wave
-  real* const jstage = reinterpret_cast<real*>(smem_raw + (size_t)4 * TILE) + (size_t)wave_in_wg * jspan;
+  real* const jstage = reinterpret_cast<real*>(smem_raw + (size_t)4 * TILE + (size_t)4 * WSLOT) + (size_t)wave_in_wg * jspan;
+  // (WLDS) this wave's critic weights: [dc] reals behind the four tiles
+  real* const wl = reinterpret_cast<real*>(smem_raw + (size_t)4 * TILE + (size_t)wave_in_wg * WSLOT);
 
   // `rows` (wave-uniform): TROWS, or rem_rows for an env's ragged last tile - then every lane loads only pieces that lie
   // inside the env's rows (rows * R * ESZ bytes, a multiple of 16), the rest of the LDS tile keeps stale rows that no
@@ -179,12 +208,14 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   // env state: `n`-suffixed = requested one tile ahead for the next env.  Loads only, no
   // "pointer ? load : default" selects (a default written into a register with a load in flight would force a
   // vmcnt(0) on the spot).
-  real y0[DS], yn[DS], x0[DS], xn[DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1], wc[DCMAX], wn[DCMAX];
+  real y0[DS], yn[DS], x0[DS], xn[DS], pv[NP > 0 ? NP : 1], pn[NP > 0 ? NP : 1], wc[WREG], wn[WREG];
+  real wnl = 0;  // (WLDS) weight `lane` of the next env
   const bool lag = A.state_sys != A.obs;  // wave-uniform: a second state vector per env (20 B more per 20 KB of rows)
 #pragma unroll
   for (int i = 0; i < NP; ++i) pn[i] = P.pars[i];
 #pragma unroll
-  for (int i = 0; i < DCMAX; ++i) wn[i] = wc[i] = 0;  // entries >= dc are never loaded and never read
+  for (int i = 0; i < WREG; ++i) wn[i] = wc[i] = 0;  // entries >= dc are never loaded and never read
+  constexpr int dc_rt = CRIT ? DCMAX : 0;  // weights the env has
   auto fetch_env = [&](long b) {
     if (RCG_DBG(A, 4)) {  // development: no env-state loads
 #pragma unroll
@@ -201,10 +232,11 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
 #pragma unroll
       for (int i = 0; i < NP; ++i) pn[i] = A.pars_env[(long)i * B + b];
     }
-    if (CRIT) {
+    if (CRIT && WLDS) {
+      if (lane < dc_rt) wnl = A.w[(long)lane * B + b];  // one weight per lane; parked in LDS when the env is adopted
+    } else if (CRIT) {
 #pragma unroll
-      for (int i = 0; i < DCMAX; ++i)
-        if (SQL || i < P.dc) wn[i] = A.w[(long)i * B + b];  // RQL: wave-uniform branch on the runtime structure
+      for (int i = 0; i < WREG; ++i) wn[i] = A.w[(long)i * B + b];
     }
   };
 
@@ -237,9 +269,13 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
 #pragma unroll
       for (int i = 0; i < NP; ++i) pv[i] = pn[i];
       pre_env = Sys::template prepare<real>(pv);
-      if (CRIT) {
+      if (CRIT && WLDS) {  // the previous env's rollouts are done (program order): its weights may be overwritten
+        if (lane < dc_rt) wl[lane] = wnl;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      } else if (CRIT) {
 #pragma unroll
-        for (int i = 0; i < DCMAX; ++i) wc[i] = wn[i];
+        for (int i = 0; i < WREG; ++i) wc[i] = wn[i];
       }
       bestJ = inf_r<real>();
       bestI = 0x7fffffff;
@@ -280,6 +316,10 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
       real S[NCHI];
 #pragma unroll
       for (int i = 0; i < NCHI; ++i) S[i] = 0;
+      real Phi[SQL ? DCMAX : 1];  // SQL: the regressor summed over the horizon (J = sum_k w . phi_k = w . sum_k phi_k)
+#pragma unroll
+      for (int i = 0; i < (SQL ? DCMAX : 1); ++i) Phi[i] = 0;
+      auto wget = [&](int i) -> real { return WLDS ? wl[i] : wc[WLDS ? 0 : i]; };
       if (RCG_DBG(A, 1)) {  // timing-only variant (RCG_DBG=1): consume the row, skip the rollout
 #pragma unroll
         for (int i = 0; i < R; ++i) J += cur[i];
@@ -304,9 +344,9 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
 #pragma unroll
             for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
           } else if (SQL) {
-            J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], [&](int i) -> real { return wc[i]; }, CS);
+            critic_phi_accum<DS, DU, real>(chi, y, &cur[kk * DU], Phi, CS);
           } else if (RQL && kk == N - 1) {
-            J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], [&](int i) -> real { return wc[i]; }, P.critic_struct);
+            J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], wget, CS);
           } else {
             J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
             gk *= P.gamma;
@@ -315,6 +355,10 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
         if (G1) {
 #pragma unroll
           for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[i], J);
+        }
+        if (SQL) {  // J = w . sum_k phi(chi_k)
+#pragma unroll
+          for (int i = 0; i < DCMAX; ++i) J = fma_r(wget(i), Phi[i], J);
         }
       }
 
@@ -396,7 +440,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
 
 // ---- launchers: the instances live in their own translation units (rcg_dma_inst.hip, one object per system x
 // element type x group, so that the library builds in parallel); rcg_sysops.hpp only sees this declaration ----------
-// group 0: DMA_MPC_G1, DMA_MPC, DMA_RQL (f64: the two MPC variants); group 1: DMA_SQL_0 .. DMA_SQL_0 + 3 (f32 only).
+// group 0: DMA_MPC_G1, DMA_MPC; group 1: DMA_SQL_0 .. + 3; group 2: DMA_RQL_0 .. + 3.
 // Returns false when there is no instance for (row length r, variant).  ev_a / ev_b (both or neither): the launch carries
 // them as its start / stop events (rcg_profile, rcg_handle.hpp::ProfScope).
 template <typename Sys, typename real, int GROUP>

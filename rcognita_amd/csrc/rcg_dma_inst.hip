@@ -1,6 +1,6 @@
 // rcg_dma_inst.hip - the k_actor_dma instances of ONE (system, element type, group), selected by the Makefile:
-//   -DRCG_INST_SYS=Sys3WRobot|Sys3WRobotNI|Sys2Tank  -DRCG_INST_REAL=float|double  -DRCG_INST_GROUP=0|1
-// (group 0: MPC gamma == 1, MPC discounted, RQL; group 1: SQL x 4 critic structures, f32 only).
+//   -DRCG_INST_SYS=Sys3WRobot|Sys3WRobotNI|Sys2Tank  -DRCG_INST_REAL=float|double  -DRCG_INST_GROUP=0|1|2
+// (group 0: MPC gamma == 1, MPC discounted; group 1: SQL x 4 critic structures; group 2: RQL x 4).
 #include "rcg_dma_launch.hpp"
 
 #if !defined(RCG_INST_SYS) || !defined(RCG_INST_REAL) || !defined(RCG_INST_GROUP)

@@ -3,7 +3,6 @@
 // rcg_dma_inst.hip, which is compiled once per (system, element type, group): the ~700 kernel instances of the library
 // are spread over nine objects that build in parallel.
 #pragma once
-#include <type_traits>
 
 #include "rcg_actor_dma.hpp"
 
@@ -36,17 +35,19 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
           RCG_DMA_CASE(DMA_MPC_G1)
           RCG_DMA_CASE(DMA_MPC)
         }
-        // RQL: f32 for every system; f64 (the reference's width) for the tank, whose critic weights are <= 9 doubles
-        // (the robots' RQL instance keeps 2 x 35 weights in registers: 140 VGPRs in f64 on top of an 80-register row)
-        if constexpr (std::is_same<real, float>::value || Sys::DS <= 2) {
-          switch (variant) { RCG_DMA_CASE(DMA_RQL) }
-        }
-      } else if constexpr (std::is_same<real, float>::value) {
+      } else if constexpr (GROUP == 1) {
         switch (variant) {
           RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUAD_LIN)
           RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUADRATIC)
           RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUAD_NOMIX)
           RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUAD_MIX)
+        }
+      } else {
+        switch (variant) {
+          RCG_DMA_CASE(DMA_RQL_0 + RCG_CRITIC_QUAD_LIN)
+          RCG_DMA_CASE(DMA_RQL_0 + RCG_CRITIC_QUADRATIC)
+          RCG_DMA_CASE(DMA_RQL_0 + RCG_CRITIC_QUAD_NOMIX)
+          RCG_DMA_CASE(DMA_RQL_0 + RCG_CRITIC_QUAD_MIX)
         }
       }
 #undef RCG_DMA_CASE

@@ -314,17 +314,24 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   // ragged tile per env - K = 48: 4.6 TB/s against 2.9 on k_actor; at K <= 32 k_actor, which packs 64 / K envs into a tile,
   // is faster: 3.7 against 3.4 TB/s at K = 32, 3.4 against 1.75 at K = 16), diagonal quadratic
   // stage cost, the preset's observation target (an instance that subtracts a target also serves a handle without one: its
-  // target is all zeros, y - 0 = y exactly); rows of <= 40 reals; f32: MPC / RQL / SQL; f64: MPC, and RQL for the tank.
+  // target is all zeros, y - 0 = y exactly); rows of <= 40 reals; MPC / RQL / SQL in f32 and f64.
   const DevKnobs& knobs = dev_knobs();
   A.dbg = knobs.dbg;
-  constexpr bool is_f32 = std::is_same<real, float>::value;
   constexpr size_t esz = sizeof(real);
   const size_t tile = (size_t)64 * dma_rpl(R, (int)esz) * R * esz;  // one wave's LDS tile (64 x rows-per-lane rows)
-  const bool mode_ok = c.mode == RCG_MODE_MPC || (is_f32 && !knobs.mpc_only) ||
-                       (c.mode == RCG_MODE_RQL && Sys::DS <= 2 && !knobs.mpc_only);  // f64 RQL: the tank (rcg_dma_launch.hpp)
+  const bool mode_ok = c.mode == RCG_MODE_MPC || !knobs.mpc_only;
+  int variant;
+  if (c.mode == RCG_MODE_MPC)
+    variant = (c.gamma == 1.0 && !knobs.no_g1) ? DMA_MPC_G1 : DMA_MPC;  // per-component accumulation when gamma == 1
+  else if (c.mode == RCG_MODE_RQL)
+    variant = DMA_RQL_0 + c.critic_struct;
+  else
+    variant = DMA_SQL_0 + c.critic_struct;
+  const size_t wslot = (size_t)4 * dma_wslot((int)esz, variant, Sys::DS, DU);  // critic weights parked in LDS (> 9 of them)
   const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 40 && (K % 4) == 0 && R <= dma_max_row<real>() &&
                       P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
-                      !(A.J && 4 * tile + 4 * esz * K > (size_t)160 * 1024);  // J staging must fit next to the tiles (one block per CU then)
+                      // J staging must fit next to the tiles (one block per CU then)
+                      !(A.J && 4 * tile + wslot + 4 * esz * K > (size_t)160 * 1024);
   // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
   if (sim_first) {
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
@@ -355,8 +362,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     const bool long_slab = (size_t)gpw * K * row_bytes >= (size_t)64 * 1024;
     const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 80 && long_slab) ? 2 : 4);
     // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
-    A.jwave = (A.J && 4 * tile + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
-    size_t lds_req = 4 * tile + (A.J ? 4 * esz * K * (A.jwave ? gpw : 1) : 0);
+    A.jwave = (A.J && 4 * tile + wslot + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
+    size_t lds_req = 4 * tile + wslot + (A.J ? 4 * esz * K * (A.jwave ? gpw : 1) : 0);
     if (knobs.lds_pad > 0) {
       lds_req += (size_t)knobs.lds_pad;
     } else if (knobs.lds_pad == 0) {  // RCG_LDS_PAD=-1: no residency cap
@@ -365,21 +372,14 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     }
     // (blocks of 4 waves = one wave per SIMD: blocks of 2 or 1 waves at the same 8 resident waves per CU measured
     // 10-13 % slower)
-    int variant;
-    if (c.mode == RCG_MODE_MPC)
-      variant = (c.gamma == 1.0 && !knobs.no_g1) ? DMA_MPC_G1 : DMA_MPC;  // per-component accumulation when gamma == 1
-    else if (c.mode == RCG_MODE_RQL)
-      variant = DMA_RQL;
-    else
-      variant = DMA_SQL_0 + c.critic_struct;
     bool ok = false;
     const hipEvent_t ev_a = h->cur_a, ev_b = h->cur_b;  // a due ProfScope's pair travels in the dispatch
-    if (variant < DMA_SQL_0) {
+    if (variant < DMA_RQL_0)
       ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
-    } else {
-      if constexpr (is_f32)  // no f64 group 1
-        ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
-    }
+    else if (variant >= DMA_SQL_0)
+      ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
+    else
+      ok = launch_dma<Sys, real, 2>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
     if (!ok) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d reals", who, R);
     h->cur_a = h->cur_b = nullptr;
     note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA, variant, (int)gpw);

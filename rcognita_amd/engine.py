@@ -255,7 +255,9 @@ class Engine:
         N.check(N.lib().rcg_set_stream(self._h, C.c_void_p(stream_ptr or 0)), self._h)
 
     def use_own_stream(self):
-        """A non-blocking HIP stream owned by the handle (rcg_use_own_stream)."""
+        """A non-blocking HIP stream owned by the handle (rcg_use_own_stream).  Nothing orders that stream against the
+        stream a device-resident input (torch tensor, DeviceArray of another engine) was WRITTEN on: call
+        :meth:`wait_stream` with the producer's stream before the first call that reads such an input."""
         N.check(N.lib().rcg_use_own_stream(self._h), self._h)
 
     def synchronize(self):

@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Some GPU tests use torch for device memory, streams and RCCL.  PyTorch-ROCm ships its own HIP runtime and must
+    bring the GPU up BEFORE librcg loads the system one (rcognita_amd/_native.py::lib: the other order leaves torch without
+    a device), and earlier tests of the session create handles - so initialise torch's side first, once."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 def load_golden(name):
     import json
 

@@ -138,10 +138,10 @@ def test_F4b_reference_actor_cost_through_the_production_kernel(name, dtype):
             eng.set_field(N.FIELD_W_CRITIC, w)
         cand = eng.to_device(aseq.astype(eng.real))  # device-resident [B][K][N][du]: the streamed path
         J = eng.actor_cost(cand)  # obs = state_sys = the handle's STATE
-        # f64 critic modes of the robots keep 2 x 35 weights in registers and stay on the tile kernel
-        on_dma = c["mode"] == "MPC" or dtype == "f32" or (name == "2tank" and c["mode"] == "RQL")
-        variant = {"MPC": N.DMA_MPC_G1 if c["gamma"] == 1.0 else N.DMA_MPC, "RQL": N.DMA_RQL}.get(c["mode"])
-        assert_kernel(eng, "k_actor_dma" if on_dma else "k_actor", variant if on_dma else None)
+        # every mode in both element types (f64 critic modes of the robots: weights parked in LDS, round 3)
+        variant = {"MPC": N.DMA_MPC_G1 if c["gamma"] == 1.0 else N.DMA_MPC, "RQL": N.DMA_RQL_0 + N.CRITIC_IDS[c["critic_struct"]],
+                   "SQL": N.DMA_SQL_0 + N.CRITIC_IDS[c["critic_struct"]]}[c["mode"]]
+        assert_kernel(eng, "k_actor_dma", variant)
         scale = np.max(np.abs(J_ref), axis=1, keepdims=True)
         err = float(np.max(np.abs(J - J_ref) / scale))
         assert err <= TOL[dtype], f"{tag}: J rel err {err:.3e}"
@@ -251,7 +251,7 @@ def test_tank_without_a_target_on_the_production_kernel(mode, cs, dtype):
     if mode != "MPC":
         eng.set_field(N.FIELD_W_CRITIC, w)
     J = eng.actor_cost(eng.to_device(cand.astype(eng.real)))
-    assert_kernel(eng, "k_actor" if (dtype == "f64" and mode == "SQL") else "k_actor_dma")
+    assert_kernel(eng, "k_actor_dma")
     J_or = O.actor_cost(cand, x[:, None, :], x[:, None, :], cfg, w_critic=w[:, None, :] if mode != "MPC" else None)
     _close(J, J_or, dtype, msg=f"no-target tank {mode}")
 

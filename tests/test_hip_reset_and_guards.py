@@ -209,3 +209,32 @@ def test_device_inputs_are_checked_before_they_reach_a_kernel():
                          timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "INPUT_CHECKS_OK" in out.stdout
+
+
+def test_zero_weighted_component_overflow_convention():
+    """A component that overflows under a ZERO stage-cost weight (Sys3WRobot's speed, R1 = diag[1, 10, 1, 0, 0, 0, 0]):
+    the streamed path evaluates the full sum like numpy - 0 * inf = NaN, the candidate counts as +inf, the reference's
+    own behaviour - while the generated grid never computes zero-weighted terms and keeps the finite cost of the weighted
+    ones (include/rcg.h, rcg_actor_argmin).  Both documented; identical whenever everything stays finite."""
+    from oracle import rcg_oracle as O
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import preset_engine_config
+    from tests.helpers import oracle_cfg
+
+    B, K, Nh = 4, 64, 4
+    eng = Engine(preset_engine_config("3wrobot", B, Nactor=Nh, dtype="f32"))
+    x = np.zeros((B, 5), dtype=np.float32)
+    x[:, 0], x[:, 1] = 1.0, 2.0
+    x[1, 3] = 3e19   # v^2 overflows float32, x + h v cos(alpha) stays finite over three Euler steps
+    x[2, 4] = -2e19  # omega^2 overflows; the heading is then ~1e17 rad: finite, any value of sin / cos
+    eng.set_state(x)
+    cfg = oracle_cfg("3wrobot", n_actor=Nh)
+    grid = O.grid_candidates(cfg, K)  # the generated level grid, as a tensor
+    cand = np.ascontiguousarray(np.broadcast_to(grid.astype(np.float32)[None], (B, K, Nh, 2)))
+    _, bj_gen, _ = eng.actor_argmin(None, K=K)
+    _, bj_str, _ = eng.actor_argmin(eng.to_device(cand), K=K)
+    assert np.all(np.isfinite(bj_gen[[0, 3]]))
+    np.testing.assert_allclose(bj_gen[[0, 3]], bj_str[[0, 3]], rtol=1e-6)  # finite envs: the same costs on both paths
+    assert np.all(np.isfinite(bj_gen[[1, 2]])), "generated grid: zero-weighted terms are not computed"
+    assert np.all(np.isinf(bj_str[[1, 2]])), "streamed rows: 0 * inf = NaN = +inf for every candidate, as numpy"
+    eng.close()

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Reproduce the evidence kept under profiles/ for one round, on a GPU box (run through gpurun from the repo root):
 #
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r02'
-#   python tools/prof_summary.py --round r02 --kt gpurun_out/prof_kt --fetch gpurun_out/prof_fetch \
-#       --write gpurun_out/prof_write --key k_actor_streamed_B65536_K256_N10_f32 \
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'
+#   python tools/prof_summary.py --round r03 --kt gpurun_out/prof_kt --fetch gpurun_out/prof_fetch \
+#       --write gpurun_out/prof_write --key k_actor_streamed_3wrobot_B65536_K256_N10_f32 \
 #       --valu gpurun_out/prof_valu --valu-units gpurun_out/valu_units.json          # back in the build container
-#   python tools/prof_summary.py --round r02_pool --valu gpurun_out/prof_valu_pool --valu-units gpurun_out/valu_units_pool.json
-#   python tools/prof_summary.py --round r02_c3rql --valu gpurun_out/prof_valu_c3rql --valu-units gpurun_out/valu_units_c3rql.json
-#   python tools/prof_summary.py --round r02 --tag configs --kt gpurun_out/prof_kt_configs
+#   python tools/prof_summary.py --round r03_pool --valu gpurun_out/prof_valu_pool --valu-units gpurun_out/valu_units_pool.json
+#   python tools/prof_summary.py --round r03_c3rql --valu gpurun_out/prof_valu_c3rql --valu-units gpurun_out/valu_units_c3rql.json
+#   python tools/prof_summary.py --round r03 --tag configs --kt gpurun_out/prof_kt_configs
+#   for t in c2_f64 c2_n20 c3_f32 c3_f64: python tools/prof_summary.py --round r03 --tag $t --fetch gpurun_out/prof_fetch_$t \
+#       --write gpurun_out/prof_write_$t --key <the key bench.py looks up for that shape>    (tools/profile_keys.sh prints them)
 #
 # Passes (MI355X_MICROARCH.md, HBM / rocprofv3 section): the kernel trace of the SAME command the bench line comes from,
 # then FETCH_SIZE and WRITE_SIZE in separate --pmc passes (never combined with other trace domains), then the SQ counters
@@ -25,6 +27,19 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof
   python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-parity > gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o w -- \
   python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-parity > gpurun_out/prof_write.log 2>&1
+# FETCH_SIZE / WRITE_SIZE of the other streamed shapes bench.py can be asked for (roofline.traffic of --dtype f64, --nactor 20,
+# --config C3 in both element types; the C3 passes also hold k_critic_fit, the big-batch sim pass k_sim_v)
+pmc_pair() {  # tag, bench arguments
+  local tag=$1; shift
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "gpurun_out/prof_fetch_${tag}" -o f -- \
+    python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-parity "$@" > "gpurun_out/prof_fetch_${tag}.log" 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "gpurun_out/prof_write_${tag}" -o w -- \
+    python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-parity "$@" > "gpurun_out/prof_write_${tag}.log" 2>&1
+}
+pmc_pair c2_f64 --dtype f64
+pmc_pair c2_n20 --nactor 20
+pmc_pair c3_f32 --config C3
+pmc_pair c3_f64 --config C3 --dtype f64
 SQ="SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU"
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu -o v -- \
   python3 tools/valu_probe.py main > gpurun_out/valu_units.json 2> gpurun_out/prof_valu.log
