@@ -343,11 +343,12 @@ typedef enum rcg_kernel_id {
   RCG_KID_SIM_V = 7,      /* k_sim_v: lane = 16 bytes of consecutive envs                                             */
   RCG_KID_SIM_DIST = 8,   /* k_sim_dist: env step on the full state [state, disturb]                                  */
   RCG_KID_CRITIC_FIT = 9, /* k_critic_fit: [env step] + push + [fit]                                                  */
-  RCG_KID_COUNT_ = 10
+  RCG_KID_ACTOR_DMA_PACKED = 10, /* k_actor_dma_packed: k_actor_dma's data path with 64 / K envs per tile (4 <= K <= 32) */
+  RCG_KID_COUNT_ = 11
 } rcg_kernel_id;
 /* variant: k_actor_dma: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL; k_actor / k_ticks: bit 0 generic
  * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates; k_critic_fit: critic_struct + 16 * (rows
- * the instance is compiled for) + 256 * do_sim + 512 * do_fit; others 0.  envs_per_wave: envs a wave owns (k_actor_dma) or
+ * the instance is compiled for) + 256 * do_sim + 512 * do_fit; others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
  * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Each out pointer may be NULL. */
 int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave);
 /* "k_actor_dma", ... ; "?" for an unknown id.  Never NULL. */

@@ -52,7 +52,7 @@ SYMBOLS = [
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 # rcg_kernel_id (rcg_last_launch)
 (KID_NONE, KID_ACTOR, KID_ACTOR_DMA, KID_TICKS, KID_ACTOR_OPT, KID_NOMINAL, KID_SIM, KID_SIM_V, KID_SIM_DIST,
- KID_CRITIC_FIT) = range(10)
+ KID_CRITIC_FIT, KID_ACTOR_DMA_PACKED) = range(11)
 DMA_MPC_G1, DMA_MPC, DMA_RQL_0, DMA_SQL_0 = 0, 1, 2, 6  # variant of k_actor_dma (+ critic_struct; rcg_actor_dma.hpp)
 
 

@@ -806,7 +806,8 @@ int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32
 
 const char* rcg_kernel_name(int32_t kernel_id) {
   static const char* const names[RCG_KID_COUNT_] = {"none",        "k_actor",   "k_actor_dma", "k_ticks",    "k_actor_opt",
-                                                    "k_nominal",   "k_sim",     "k_sim_v",     "k_sim_dist", "k_critic_fit"};
+                                                    "k_nominal",   "k_sim",     "k_sim_v",     "k_sim_dist", "k_critic_fit",
+                                                    "k_actor_dma_packed"};
   return (kernel_id >= 0 && kernel_id < RCG_KID_COUNT_) ? names[kernel_id] : "?";
 }
 

@@ -5,6 +5,7 @@
 #pragma once
 
 #include "rcg_actor_dma.hpp"
+#include "rcg_actor_dma_packed.hpp"
 
 namespace rcg {
 
@@ -60,6 +61,45 @@ template <typename Sys, typename real, int GROUP>
 bool launch_dma(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
                 const KParams<real>& P, hipEvent_t ev_a, hipEvent_t ev_b) {
   return launch_dma_r<Sys, real, GROUP, 1>(r, variant, grid, block, lds, s, A, P, ev_a, ev_b);
+}
+
+// ---- k_actor_dma_packed (group 3): the two MPC variants, every row length ------------------------------------------
+template <typename Sys, typename real, int R>
+static bool launch_dma_packed_r(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                                const ActorArgs<real>& A, const KParams<real>& P, hipEvent_t ev_a, hipEvent_t ev_b) {
+  if constexpr (R > dma_max_row<real>()) {
+    return false;
+  } else {
+    if (r != R) return launch_dma_packed_r<Sys, real, R + 1>(r, variant, grid, block, lds, s, A, P, ev_a, ev_b);
+    if constexpr (R % Sys::DU != 0) {
+      return false;
+    } else {
+#define RCG_DMAP_CASE(V)                                                                                             \
+  case V: {                                                                                                          \
+    auto fn = k_actor_dma_packed<Sys, real, R, Sys::TGT, V>;                                                         \
+    if (lds > 64 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                (int)lds);                                                                           \
+    if (ev_a)                                                                                                        \
+      hipExtLaunchKernelGGL(fn, grid, block, (std::uint32_t)lds, s, ev_a, ev_b, 0, A, P);                            \
+    else                                                                                                             \
+      hipLaunchKernelGGL(fn, grid, block, lds, s, A, P);                                                             \
+    return true;                                                                                                     \
+  }
+      switch (variant) {
+        RCG_DMAP_CASE(DMA_MPC_G1)
+        RCG_DMAP_CASE(DMA_MPC)
+      }
+#undef RCG_DMAP_CASE
+      return false;
+    }
+  }
+}
+
+template <typename Sys, typename real>
+bool launch_dma_packed(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
+                       const KParams<real>& P, hipEvent_t ev_a, hipEvent_t ev_b) {
+  return launch_dma_packed_r<Sys, real, 1>(r, variant, grid, block, lds, s, A, P, ev_a, ev_b);
 }
 
 }  // namespace rcg

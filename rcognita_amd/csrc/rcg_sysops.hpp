@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "rcg_actor_dma.hpp"
+#include "rcg_actor_dma_packed.hpp"
 #include "rcg_actor_opt.hpp"
 #include "rcg_critic_fit.hpp"
 #include "rcg_disturb.hpp"
@@ -332,12 +333,41 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
                       P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
                       // J staging must fit next to the tiles (one block per CU then)
                       !(A.J && 4 * tile + wslot + 4 * esz * K > (size_t)160 * 1024);
+  // Few candidates per env (4 <= K <= 32, K % 4 == 0), MPC -> k_actor_dma_packed (rcg_actor_dma_packed.hpp): 64 / K envs
+  // share a DMA tile.  J staging (operator mode) must fit next to the four tiles.
+  const int pack_g = (K >= 4 && K <= 32) ? 64 / K : 0;  // envs per tile
+  const bool pack_ok = cand && ((uintptr_t)cand % 16) == 0 && pack_g >= 2 && (K % 4) == 0 && R <= dma_max_row<real>() &&
+                       P.stage_kind == 0 && c.mode == RCG_MODE_MPC && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
+                       !knobs.no_pack;
   // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
   if (sim_first) {
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
     if (rc) return rc;
   }
   ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+  if (pack_ok) {
+    // a wave owns gpw = G * 2^n <= 64 consecutive envs (their results wait in its lanes); these launches are small (K = 16,
+    // B = 65536, Nactor = 10: 84 MB), so the grid is kept at >= 4096 waves and 4 blocks per CU stay resident
+    long gpw = pack_g;
+    while (gpw * 2 <= 64 && B / (gpw * 2) >= 4096) gpw *= 2;
+    if (knobs.gpw > 0 && knobs.gpw % pack_g == 0 && knobs.gpw <= 64) gpw = knobs.gpw;  // (dev build only)
+    A.G = pack_g;
+    A.gpw = (int)gpw;
+    A.jwave = 1;
+    const long pw = (B + gpw - 1) / gpw;
+    const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
+    const size_t full_tile = (size_t)64 * R * esz;
+    size_t lds_req = 4 * full_tile + (A.J ? 4 * esz * (size_t)gpw * K : 0);
+    const size_t cap = knobs.per_cu == 2 ? (size_t)56 * 1024 : (knobs.per_cu == 8 ? 0 : (size_t)36 * 1024);
+    if (lds_req < cap) lds_req = cap;  // 4 resident blocks per CU (dev build: RCG_PER_CU = 2 | 8)
+    const hipEvent_t ev_a = h->cur_a, ev_b = h->cur_b;
+    if (!launch_dma_packed<Sys, real>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b))
+      return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma_packed instance for a row of %d reals", who, R);
+    h->cur_a = h->cur_b = nullptr;
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA_PACKED, variant, (int)gpw);
+    HIPCHK(h, hipGetLastError());
+    return RCG_OK;
+  }
   if (dma_ok) {
     // Launch geometry, measured on MI355X at C2 (B = 65536, K = 256, N = 10):
     //  * residency: 2 blocks (8 waves) per CU stream faster than 8 blocks per CU - 0.204 ms against 0.213-0.218 ms.

@@ -566,3 +566,55 @@ def test_horizon_limits(name, N, dtype):
         with pytest.raises(Nn.NativeError) as ei:
             Engine(engine_cfg(name, B, dtype, n_actor=N + 1))
         assert ei.value.code == Nn.ERR_BAD_ARG and "Nactor" in str(ei.value)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K", [4, 8, 12, 16, 20, 28, 32, 36])
+@pytest.mark.parametrize("name,Nh", [("3wrobot", 10), ("3wrobotNI", 3), ("2tank", 20)])
+def test_few_candidates_per_env_on_packed_tiles(name, Nh, K, dtype):
+    """Streamed candidates with 4 <= K <= 32 (K % 4 == 0): k_actor_dma_packed - 64 / K envs share one DMA tile, the env state is
+    per-lane, the argmin segmented (rcg_actor_dma_packed.hpp).  Operator (J of every row), argmin (ties -> lower index, NaN =
+    +inf, all-NaN -> 0) and a three-tick closed loop against the oracle on a batch whose last wave and last tile are ragged;
+    gamma != 1 takes the discounted instance.  K = 36 (one env per tile would be mostly empty, no packing) stays on k_actor."""
+    from oracle import parity as PAR
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(100 * K + Nh)
+    B = 1000 + 7
+    gamma = 1.0 if K % 8 else 0.95
+    eng, cfg = both(name, B, dtype, n_actor=Nh, gamma=gamma)
+    x = rand_states(rng, name, B).astype(eng.real)
+    cand = rand_actions(rng, name, (B, K, Nh)).astype(eng.real)
+    clean = cand.copy()
+    cand[5, min(3, K - 1)] = cand[5, 0]      # an exact tie: the lower index must win if it is the minimum
+    cand[6, 1, 0, 0] = np.nan                # a NaN candidate is never selected
+    cand[7] = np.nan                         # every candidate NaN: index 0, +inf
+    eng.set_state(x)
+    dc = eng.to_device(cand)
+    J = eng.actor_cost(dc)
+    kernel = "k_actor_dma_packed" if K <= 32 else "k_actor"
+    assert_kernel(eng, kernel, (N.DMA_MPC_G1 if gamma == 1.0 else N.DMA_MPC) if K <= 32 else None)
+    x64, c64 = x.astype(np.float64), cand.astype(np.float64)
+    J_or = O.actor_cost(c64, x64[:, None, :], x64[:, None, :], cfg)
+    fin = np.isfinite(J_or)
+    assert np.array_equal(np.isnan(J), ~fin)
+    scale = np.max(np.abs(np.where(fin, J_or, 0.0)), axis=1, keepdims=True)
+    scale = np.where(scale > 0, scale, 1.0)
+    assert np.nanmax(np.abs(J - J_or)[fin] / np.broadcast_to(scale, J.shape)[fin]) <= TOL[dtype]
+    act, bj, bi = eng.actor_argmin(dc)
+    assert_kernel(eng, kernel)
+    Jc = np.where(np.isnan(J), np.inf, J)  # the kernel's own costs: its argmin must be numpy's on them, bit for bit
+    np.testing.assert_array_equal(bi, np.argmin(Jc, axis=1).astype(np.int32))
+    np.testing.assert_array_equal(bj, Jc[np.arange(B), bi])
+    assert bi[7] == 0 and np.isinf(bj[7]) and bi[6] != 1
+    np.testing.assert_array_equal(act[:5], cand[np.arange(5), bi[:5], 0, :])
+    # closed loop on the rows as drawn (no NaN): every env, every tick, as a map from the same inputs
+    dclean = eng.to_device(clean)
+    env = O.new_batch(cfg, x64)
+    rep = PAR.TickReport()
+    for t in range(3):
+        eng.control_tick(dclean, K=K)
+        env = PAR.check_tick(cfg, env, clean.astype(np.float64), PAR.device_fields(eng, N), tol=TOL[dtype], report=rep,
+                             what=f"{name} K={K} {dtype} t={t}")
+    assert_kernel(eng, kernel)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, 3, np.int32))
