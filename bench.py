@@ -76,6 +76,9 @@ def parse(argv=None):
     p.add_argument("--profile-stride", type=int, default=-1,
                    help="time every n-th launch of the dominant kernel in the timed region (events carried by the "
                         "dispatch); -1 = chosen so that 20 .. 40 launches are sampled, 0 = none")
+    p.add_argument("--parts", type=int, default=None,
+                   help="handles per GPU, each on a stream of its own (rcognita_amd.pool.MixedPool(parts=...)): the critic fit "
+                        "of one part runs under the actor kernel of another.  Default: 2 for --config C3, else 1")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed (RCCL with --dist-backend nccl) even at world_size 1 and run every "
                         "collective of the N>1 path: communicator creation, device all_gather, all_reduce, barrier")
@@ -91,6 +94,10 @@ def parse(argv=None):
         a.nactor = {"C5": 15, "C3": 20}.get(a.config, 10)
     if a.regime is None:
         a.regime = "generated" if a.config == "C5" else "streamed"
+    if a.parts is None:
+        a.parts = 2 if a.config == "C3" else 1
+    if a.parts > 1 and a.config == "C5":
+        p.error("--parts applies to the single-system configs (C5 already runs one handle per system type)")
     if a.config == "C5" and a.regime != "generated":
         p.error("--config C5 is the generated-candidate workload (BASELINE configs[4]: 256-candidate grid search)")
     return a
@@ -447,21 +454,45 @@ def main(argv=None):
 
     # ---- this rank's shard of the job -----------------------------------------------------------------------------
     cand, x0, pool = None, None, None
-    if args.config == "C5":
+    pool_cand = None
+    if args.config == "C5" or args.parts > 1:
         from rcognita_amd.pool import MixedPool
 
-        counts = {"3wrobot": total_envs // 3 + total_envs % 3, "3wrobotNI": total_envs // 3, "2tank": total_envs // 3}
-        # the three homogeneous segments are independent: each handle runs on a HIP stream of its own, so the tail of one
-        # segment's kernel overlaps the head of the next (each is a short launch of ~5 500 waves).  The streams are
-        # torch's here, so that this harness can record its events ON them.
-        pool = MixedPool(counts, rank=rank, world=world, device=local_rank, dtype=args.dtype, Nactor=Nh, own_streams=False)
+        if args.config == "C5":
+            counts = {"3wrobot": total_envs // 3 + total_envs % 3, "3wrobotNI": total_envs // 3, "2tank": total_envs // 3}
+            kw = {}
+        else:  # one system type cut into --parts handles: the job's envs [lo, hi) of this rank
+            sysname = "2tank" if args.config == "C3" else "3wrobot"
+            counts = {sysname: total_envs}
+            kw = dict(parts=args.parts, **(C3_KW if args.config == "C3" else dict(mode="MPC")))
+        # the handles are independent: each runs on a HIP stream of its own, so the tail of one kernel overlaps the head of
+        # the next and (RQL / SQL) the latency-bound critic fit of one part runs under the HBM-bound actor kernel of another.
+        # The streams are torch's here, so that this harness can record its events ON them.
+        pool = MixedPool(counts, rank=rank, world=world, device=local_rank, dtype=args.dtype, Nactor=Nh, own_streams=False,
+                         **kw)
         streams = [torch.cuda.Stream() for _ in pool.segments]
         pool.set_streams([st.cuda_stream for st in streams])
-        rng = np.random.default_rng(1234 + rank)
-        pool.set_states({s.name: pool_states(rng, s.name, s.hi - s.lo) for s in pool.segments})
         engines = [s.engine for s in pool.segments]
         B = pool.n_envs
-        tick = lambda: pool.control_tick(K)
+        if args.config == "C5":
+            rng = np.random.default_rng(1234 + rank)
+            pool.set_states({s.name: pool_states(rng, s.name, s.hi - s.lo) for s in pool.segments})
+            tick = lambda: pool.control_tick(K)
+        else:
+            lo, hi = shard_range(total_envs, rank, world)
+            x0 = synth_state(1234, lo, hi, args.config)
+            pool.set_states({sysname: x0})
+            _, bnds = c2_engine_config(args, local_rank, 1)
+            if streamed:
+                g = torch.Generator(device="cuda")
+                g.manual_seed(1234 + rank)
+                blo = torch.tensor(bnds[:, 0], device="cuda", dtype=tdtype)
+                bhi = torch.tensor(bnds[:, 1], device="cuda", dtype=tdtype)
+                cand = (torch.rand((B, K, Nh, engines[0].du), generator=g, device="cuda", dtype=tdtype) * (bhi - blo)
+                        + blo).contiguous()
+                torch.cuda.synchronize()  # written on torch's current stream, read on the handles' streams
+                pool_cand = {sysname: cand}
+            tick = lambda: pool.control_tick(K, pool_cand, ordered=True)
     else:
         lo, hi = shard_range(total_envs, rank, world)
         B = hi - lo
@@ -631,25 +662,39 @@ def main(argv=None):
     value = units / dt
     if args.config == "C5":
         bytes_launch = sum(actor_bytes_per_launch(e.B, K, Nh, e.du, e.ds, esz, False) for e in engines)
-    else:
-        bytes_launch = actor_bytes_per_launch(B, K, Nh, du, ds, esz, streamed)
+    else:  # one launch = one handle's envs (--parts handles of equal size per tick)
+        Bl = engines[0].B
+        bytes_launch = actor_bytes_per_launch(Bl, K, Nh, du, ds, esz, streamed)
         if args.config == "C3":
-            bytes_launch += B * engines[0].dc * esz  # the env's critic weights travel with its state
+            bytes_launch += Bl * engines[0].dc * esz  # the env's critic weights travel with its state
     actor_avg_s = (actor_ms / max(actor_n, 1)) * 1e-3
     if args.config == "C5":
         # one launch per segment, on streams of their own: the launches overlap, so the per-tick figure is the device time of
         # a tick where that is shorter than the sum of the three kernel times
         actor_avg_s = min(actor_avg_s * len(engines), step_ms_compute * 1e-3)
     achieved = bytes_launch / actor_avg_s if actor_avg_s > 0 else 0.0
+    per_launch = None
+    if args.config != "C5" and len(engines) > 1:
+        # --parts handles on streams of their own: their launches OVERLAP on the GPU, so a launch's own duration (what the
+        # dispatch stamps and a rocprofv3 trace show) is stretched by its neighbour and bytes / duration of ONE launch says
+        # nothing about the memory system.  The roofline is then taken at tick level: the algorithmic bytes of ALL the
+        # tick's actor launches over the device time of a tick (which also contains the env steps / critic fits).
+        per_launch = {"algorithmic_bytes": bytes_launch, "avg_launch_ms": actor_avg_s * 1e3,
+                      "frac_of_one_overlapped_launch": achieved / HBM_PEAK,
+                      "note": "launches of the handles overlap: not a statement about the memory system"}
+        bytes_launch = bytes_launch * len(engines)
+        actor_avg_s = step_ms_compute * 1e-3
+        achieved = bytes_launch / actor_avg_s
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and args.config != "C5":
         try:
             mode_tag = "_RQL" if args.config == "C3" else ""
             sysname = "2tank" if args.config == "C3" else "3wrobot"
-            keys = [f"k_actor_{args.regime}_{sysname}{mode_tag}_B{B}_K{K}_N{Nh}_{args.dtype}"]
+            Bl = engines[0].B  # envs of ONE launch
+            keys = [f"k_actor_{args.regime}_{sysname}{mode_tag}_B{Bl}_K{K}_N{Nh}_{args.dtype}"]
             if args.config != "C3":
-                keys.append(f"k_actor_{args.regime}_B{B}_K{K}_N{Nh}_{args.dtype}")  # rounds 1-2 key of the C2 shapes
+                keys.append(f"k_actor_{args.regime}_B{Bl}_K{K}_N{Nh}_{args.dtype}")  # rounds 1-2 key of the C2 shapes
             table = json.load(open(pmc))
             for key in keys:
                 if key in table:
@@ -687,6 +732,7 @@ def main(argv=None):
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": workload, "config": args.config, "envs_total": total_envs, "envs_rank0": B,
+                   "handles_per_gpu": len(engines), "envs_per_handle": [e.B for e in engines],
                    "candidates": K, "nactor": Nh, "regime": args.regime, "parallelism": f"env-shard x{world}",
                    "actor_cost_evals_per_s": value * K, "prespin_ticks_untimed": prespin,
                    "prespin_last_chunks_ms_per_tick": [round(c / 32, 5) for c in chunk_ms[-4:]]},
@@ -718,7 +764,7 @@ def main(argv=None):
                      "max_launch_ms": float(act.max()) if actor_n else None,
                      "frac_at_median": (bytes_launch / (float(np.median(act)) * 1e-3) / HBM_PEAK) if actor_n and
                      args.config != "C5" else None,
-                     "launches_timed": actor_n, "event_stride": stride,
+                     "launches_timed": actor_n, "event_stride": stride, "overlapped_handles": per_launch,
                      "event_kind": "start / stop events carried by the dispatch (hipExtLaunchKernelGGL), timed region only",
                      "note": ("streamed regime: HBM-bound" if streamed else
                               "generated regime is VALU-bound (see secondary.generated_grid.roofline_valu); the HBM "
@@ -746,6 +792,8 @@ def main(argv=None):
                 missing = True
                 break
             lane_instr += e.B * K * ipe["valu_instr_per_eval"]
+            if args.config != "C5":  # equal handles, one launch each per tick: price ONE launch
+                break
         hbm = dict(out["roofline"])
         if missing:  # no stored instruction count for this shape: say so instead of pricing a VALU-bound kernel in bytes
             out["roofline"].update(bound="valu", achieved=None, frac=None, unit="lane-instr/s", peak=VALU_PEAK,
@@ -767,6 +815,11 @@ def main(argv=None):
 
     if not args.no_secondary and world == 1 and args.config == "C2":
         out["secondary"] = secondary(args, local_rank, stream_ptr, x0, B, K, Nh, torch, Engine, N)
+        if streamed and args.parts == 1 and Nh * 2 <= 40:
+            try:
+                out["secondary"]["two_handles"] = two_handles(args, local_rank, x0, cand, B, K, Nh, torch)
+            except Exception as e:  # never let a secondary figure take the bench line down
+                out["secondary"]["two_handles"] = {"error": str(e)[:300]}
 
     if not args.no_cpu_baseline and world == 1 and args.config == "C2":
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
@@ -803,6 +856,39 @@ def valu_instr_per_eval(key):
         return json.load(open(path)).get(key)
     except Exception:
         return None
+
+
+def two_handles(args, device, x0, cand, B, K, Nh, torch):
+    """The same tick as TWO handles of B / 2 envs on streams of their own (rcognita_amd.pool.MixedPool(parts=2), `bench.py
+    --parts 2`): one part's env step and the ramp-down of its actor kernel overlap the other part's actor kernel."""
+    from rcognita_amd.pool import MixedPool
+
+    pool = MixedPool({"3wrobot": B}, device=device, dtype=args.dtype, Nactor=Nh, own_streams=False, parts=2, mode="MPC")
+    streams = [torch.cuda.Stream() for _ in pool.segments]
+    pool.set_streams([st.cuda_stream for st in streams])
+    pool.set_states({"3wrobot": x0})
+    torch.cuda.synchronize()
+    cd = {"3wrobot": cand}
+    for _ in range(300):
+        pool.control_tick(K, cd, ordered=True)
+    a = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    b = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    for ev, st in zip(a, streams):
+        ev.record(st)
+    n = max(100, args.steps)
+    for _ in range(n):
+        pool.control_tick(K, cd, ordered=True)
+    for ev, st in zip(b, streams):
+        ev.record(st)
+    torch.cuda.synchronize()
+    ms = max(x.elapsed_time(y) for x in a for y in b) / n
+    esz = 4 if args.dtype == "f32" else 8
+    byt = actor_bytes_per_launch(B, K, Nh, 2, 5, esz, True)
+    pool.close()
+    return {"env_control_steps_per_s": B / (ms * 1e-3), "ms_per_step": ms, "handles": 2,
+            "hbm_frac_at_tick_level": byt / (ms * 1e-3) / HBM_PEAK,
+            "note": "aggregate algorithmic bytes of the tick's two actor launches / device time per tick (the launches "
+                    "overlap, so a per-launch duration is not meaningful here); `python bench.py --parts 2` makes this the line"}
 
 
 def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):

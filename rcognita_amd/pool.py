@@ -52,27 +52,39 @@ class Segment:
     engine: Engine
     lo: int  # global env range of this segment within its type
     hi: int
+    off: int = 0  # first env of the segment within THIS RANK's envs of its type (several segments per type: `parts`)
 
 
 class MixedPool:
     """``counts``: {preset name: global number of envs}.  With ``rank/world`` given, this process owns the
-    shard ``shard_by_type(counts, rank, world)`` of every type."""
+    shard ``shard_by_type(counts, rank, world)`` of every type.
+
+    ``parts`` > 1 cuts every type's shard into that many handles of (nearly) equal size, each on a stream of its own.
+    For RQL / SQL this is worth doing even with ONE system type: a tick is {critic fit, actor kernel}, the fit is bound by
+    the latency of its longest active-set walk (a few waves stay busy for 50 us) and the actor kernel by HBM, so the fit of
+    one part runs under the actor kernel of another - configs[2] (131072 tank envs, RQL, streamed): 0.473 ms per tick as one
+    handle, 0.422 ms as two (2.77e8 -> 3.10e8 env.control-steps/s; four parts: 0.443 ms, tools/split_probe.py)."""
 
     def __init__(self, counts: Dict[str, int], rank: int = 0, world: int = 1, device: int = 0, dtype: str = "f32",
-                 Nactor: int = 15, mode: str = "MPC", own_streams: bool = True, **over):
+                 Nactor: int = 15, mode: str = "MPC", own_streams: bool = True, parts: int = 1, **over):
+        from .parallel import shard_range
+
         self.counts = dict(counts)
         self.segments: List[Segment] = []
         spans = shard_by_type(counts, rank, world)
         buffer_size = over.pop("buffer_size", 10) if mode != "MPC" else over.pop("buffer_size", 0)
+        base_id = int(over.pop("env_id_base", 0))
         for name in sorted(counts):  # deterministic segment order
             lo, hi = spans[name]
-            if hi <= lo:
-                continue
-            eng = Engine(preset_engine_config(name, hi - lo, device=device, dtype=dtype, Nactor=Nactor, mode=mode,
-                                              buffer_size=buffer_size, **over))
-            if own_streams:  # nothing orders the segments: their (short) launches overlap on streams of their own
-                eng.use_own_stream()
-            self.segments.append(Segment(name, eng, lo, hi))
+            for p in range(max(int(parts), 1)):
+                a, b = shard_range(hi - lo, p, max(int(parts), 1))
+                if b <= a:
+                    continue
+                eng = Engine(preset_engine_config(name, b - a, device=device, dtype=dtype, Nactor=Nactor, mode=mode,
+                                                  buffer_size=buffer_size, env_id_base=base_id + lo + a, **over))
+                if own_streams:  # nothing orders the segments: their launches overlap on streams of their own
+                    eng.use_own_stream()
+                self.segments.append(Segment(name, eng, lo + a, lo + b, off=a))
 
     @property
     def n_envs(self) -> int:
@@ -86,7 +98,7 @@ class MixedPool:
     def set_states(self, states: Dict[str, np.ndarray]):
         """``states[name]``: [n_local, ds] initial states of this rank's envs of that type."""
         for s in self.segments:
-            s.engine.set_state(states[s.name])
+            s.engine.set_state(states[s.name][s.off:s.off + (s.hi - s.lo)])
 
     def control_tick(self, K: int, cand: Optional[Dict[str, object]] = None, producer_stream: Optional[int] = 0,
                      ordered: bool = False):
@@ -103,7 +115,10 @@ class MixedPool:
         for s in self.segments:
             if device_cand and not ordered:
                 s.engine.wait_stream(producer_stream)
-            s.engine.control_tick(None if cand is None else cand[s.name], K=K)
+            c = None if cand is None else cand[s.name]
+            if c is not None and not (s.off == 0 and int(c.shape[0]) == s.hi - s.lo):
+                c = c[s.off:s.off + (s.hi - s.lo)]  # a type's tensor covers this rank's envs of that type: my rows
+            s.engine.control_tick(c, K=K)
 
     def wait_stream(self, producer_stream: Optional[int] = 0):
         """Every segment's next launch waits for the work queued so far on ``producer_stream`` (see control_tick)."""
