@@ -134,11 +134,13 @@ class MixedPool:
             s.engine.episode_reset()
 
     def episode_stats(self, from_accum=False):
-        """(whole-pool summary, {type: summary}) for this rank's shard."""
-        per = {}
+        """(whole-pool summary, {type: summary}) for this rank's shard (a type's parts merged)."""
+        per_seg, by_type = [], {}
         for s in self.segments:
-            per[s.name], _ = s.engine.episode_stats(from_accum=from_accum)
-        return merge_summaries(per.values()), per
+            summ, _ = s.engine.episode_stats(from_accum=from_accum)
+            per_seg.append(summ)
+            by_type.setdefault(s.name, []).append(summ)
+        return merge_summaries(per_seg), {k: merge_summaries(v) for k, v in by_type.items()}
 
     def close(self):
         for s in self.segments:

@@ -394,3 +394,42 @@ def test_vectorised_env_step_equals_the_scalar_kernel(name, dtype):
         for _ in range(2):
             O.sim_substeps(cfg, env, S)
         assert rel_err_norm(big.get_state()[sel], env.state) < (1e-5 if dtype == "f32" else 1e-11)
+
+
+@pytest.mark.parametrize("name,mode,parts", [("2tank", "RQL", 2), ("3wrobot", "MPC", 3), ("3wrobotNI", "SQL", 2)])
+def test_one_system_cut_into_parts_equals_the_single_handle(name, mode, parts):
+    """MixedPool(parts=...): one system type as several handles on streams of their own (the critic fit of one part runs
+    under the actor kernel of another).  Envs are independent, so every per-env field of the parts, concatenated, equals
+    the single handle's bit for bit - streamed device candidates (ordered against the producer stream), ragged split."""
+    import torch
+
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import MixedPool, preset_engine_config
+
+    rng = np.random.default_rng(parts)
+    B, K, Nh, T = 4099, 64, 6, 12
+    kw = dict(mode=mode, critic_struct="quadratic", Ncritic=4, buffer_size=6) if mode != "MPC" else dict(mode="MPC")
+    x0 = rand_states(rng, name, B).astype(np.float32)
+    du = PRESETS[name]["sys_id"] == O.SYS_2TANK and 1 or 2
+    bnds = np.array(PRESETS[name]["bnds"], dtype=np.float32)
+    cand = torch.as_tensor(rng.uniform(bnds[:, 0], bnds[:, 1], (B, K, Nh, du)).astype(np.float32), device="cuda")
+    torch.cuda.synchronize()
+    one = Engine(preset_engine_config(name, B, Nactor=Nh, **kw))
+    one.set_state(x0)
+    pool = MixedPool({name: B}, Nactor=Nh, parts=parts, **kw)
+    assert len(pool.segments) == parts and pool.n_envs == B and [s.off for s in pool.segments][0] == 0
+    pool.set_states({name: x0})
+    for _ in range(T):
+        one.control_tick(cand, K=K)
+        pool.control_tick(K, {name: cand}, producer_stream=torch.cuda.current_stream().cuda_stream)
+    pool.synchronize()
+    fields = [N.FIELD_STATE, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_BEST_IDX, N.FIELD_BEST_J, N.FIELD_STEP_IDX]
+    if mode != "MPC":
+        fields += [N.FIELD_W_CRITIC, N.FIELD_OBS_BUF, N.FIELD_ACT_BUF]
+    for f in fields:
+        np.testing.assert_array_equal(np.concatenate([s.engine.get_field(f) for s in pool.segments]), one.get_field(f))
+    tot, _ = pool.episode_stats(from_accum=True)
+    ref, _ = one.episode_stats(from_accum=True)
+    assert tot["count"] == ref["count"] == B and tot["min"] == ref["min"] and tot["max"] == ref["max"]
+    pool.close()
+    one.close()
