@@ -704,6 +704,8 @@ def main(argv=None):
                     break
         except Exception:
             traffic = None
+    if traffic is not None and per_launch is not None:
+        traffic *= len(engines)  # tick level, as `achieved`
     kinfo = launch_info[0]
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "

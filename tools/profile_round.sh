@@ -21,8 +21,10 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 python bench.py > "gpurun_out/bench_${ROUND}.json" 2> "gpurun_out/bench_${ROUND}.err"
+# (--no-secondary: the secondary regimes include the SAME kernel at half the batch - two handles on two streams - which
+# would blend two launch sizes into one average)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o kt -- \
-  python3 bench.py --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1
+  python3 bench.py --no-cpu-baseline --no-secondary > gpurun_out/prof_kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o f -- \
   python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-parity > gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o w -- \
