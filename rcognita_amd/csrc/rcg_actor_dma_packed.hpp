@@ -13,7 +13,7 @@
 //     winner's lane with ds_bpermute;
 //   * a wave owns gpw = G * 2^n <= 64 consecutive envs and parks env (env0 + i)'s results in lane i; one coalesced store
 //     per field when the wave is done.
-// Shapes: streamed candidates, 4 <= K <= 32 with K % 4 == 0 (whole 16-byte pieces), MPC (gamma == 1 per-component
+// Shapes: streamed candidates, 4 <= K <= 32 with K * R * esz % 16 == 0 (whole 16-byte pieces per env), MPC (gamma == 1 per-component
 // instance, discounted instance), diagonal quadratic stage cost, the preset's observation target, rows of <= 40 reals, f32
 // and f64.  RQL / SQL with K < 40 stay on k_actor (the critic weights would be per-lane data as well).
 // Until round 3 these shapes ran on k_actor (tile HBM -> VGPR -> LDS, row walked from LDS with a runtime horizon):
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
   real* const jstage = reinterpret_cast<real*>(smem_raw + (size_t)4 * TILE) + (size_t)wave_in_wg * (A.gpw * K);
 
   auto envs_in = [&](int j) -> int { return (j + 1) * G <= n_env ? G : n_env - j * G; };  // wave-uniform
-  // valid bytes of tile j (a multiple of 16: K % 4 == 0); lanes beyond them load nothing, the LDS keeps stale rows
+  // valid bytes of tile j (a multiple of 16: the launcher's condition); lanes beyond them load nothing, the LDS keeps stale rows
   auto issue_tile = [&](int j) {
     const unsigned char* const g = slab + (size_t)j * G * K * row_bytes;
     const int vb = envs_in(j) * K * (int)row_bytes;

@@ -311,7 +311,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
 
-  // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K >= 40 and a multiple of 4 (40 .. 60: one
+  // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K >= 40 with K * R * esz % 16 == 0 (40 .. 60: one
   // ragged tile per env - K = 48: 4.6 TB/s against 2.9 on k_actor; at K <= 32 k_actor, which packs 64 / K envs into a tile,
   // is faster: 3.7 against 3.4 TB/s at K = 32, 3.4 against 1.75 at K = 16), diagonal quadratic
   // stage cost, the preset's observation target (an instance that subtracts a target also serves a handle without one: its
@@ -329,14 +329,17 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   else
     variant = DMA_SQL_0 + c.critic_struct;
   const size_t wslot = (size_t)4 * dma_wslot((int)esz, variant, Sys::DS, DU);  // critic weights parked in LDS (> 9 of them)
-  const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 40 && (K % 4) == 0 && R <= dma_max_row<real>() &&
+  // (an env's rows must be a whole number of 16-byte pieces, K * R * esz % 16 == 0 - any K for rows of 16 n bytes such as C2's
+  // 80, every 4th K for the shortest rows: then every env starts 16-B aligned and a ragged last tile ends on a piece)
+  const bool slab16 = ((size_t)K * row_bytes) % 16 == 0;
+  const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 40 && slab16 && R <= dma_max_row<real>() &&
                       P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
                       // J staging must fit next to the tiles (one block per CU then)
                       !(A.J && 4 * tile + wslot + 4 * esz * K > (size_t)160 * 1024);
-  // Few candidates per env (4 <= K <= 32, K % 4 == 0), MPC -> k_actor_dma_packed (rcg_actor_dma_packed.hpp): 64 / K envs
+  // Few candidates per env (4 <= K <= 32, whole 16-byte pieces per env), MPC -> k_actor_dma_packed (rcg_actor_dma_packed.hpp): 64 / K envs
   // share a DMA tile.  J staging (operator mode) must fit next to the four tiles.
   const int pack_g = (K >= 4 && K <= 32) ? 64 / K : 0;  // envs per tile
-  const bool pack_ok = cand && ((uintptr_t)cand % 16) == 0 && pack_g >= 2 && (K % 4) == 0 && R <= dma_max_row<real>() &&
+  const bool pack_ok = cand && ((uintptr_t)cand % 16) == 0 && pack_g >= 2 && slab16 && R <= dma_max_row<real>() &&
                        P.stage_kind == 0 && c.mode == RCG_MODE_MPC && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
                        !knobs.no_pack;
   // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).

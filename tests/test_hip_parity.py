@@ -257,12 +257,13 @@ def test_tank_without_a_target_on_the_production_kernel(mode, cs, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("K", [130, 128, 256, 132, 196])
+@pytest.mark.parametrize("K", [131, 130, 128, 256, 132, 196])
 def test_argmin_ties_and_nan(dtype, K):
-    """Lower index wins ties; NaN costs count as +inf; an all-NaN env returns index 0.  K = 130: the generic kernel
-    (ragged last tile, K not a multiple of 4); K = 128, 256: the production kernel's DPP (f32) / shuffle (f64) wave
-    argmin; K = 132, 196: the production kernel with a ragged last tile (4 rows: masked direct-to-LDS loads, 60 lanes
-    without a row sit out the argmin - including the LAST env of the tensor, whose tile ends at the allocation's end)."""
+    """Lower index wins ties; NaN costs count as +inf; an all-NaN env returns index 0.  K = 131 in f32: the generic kernel
+    (rows of 40 bytes: 131 of them are not a whole number of 16-byte pieces); K = 128, 256: the production kernel's DPP (f32)
+    / shuffle (f64) wave argmin; K = 130, 132, 196 (and 131 in f64: 80-byte rows): the production kernel with a ragged last
+    tile (2 / 4 rows: masked direct-to-LDS loads, the lanes without a row sit out the argmin - including the LAST env of the
+    tensor, whose tile ends at the allocation's end)."""
     name, N, B = "3wrobot", 5, 4
     rng = np.random.default_rng(5)
     eng, cfg = both(name, B, dtype, n_actor=N)
@@ -276,7 +277,7 @@ def test_argmin_ties_and_nan(dtype, K):
     cand[2] = np.nan  # every candidate NaN
     eng.set_state(x)
     J = eng.actor_cost(cand)
-    assert_kernel(eng, "k_actor" if K % 4 else "k_actor_dma")
+    assert_kernel(eng, "k_actor_dma" if (K * N * 2 * eng.real().itemsize) % 16 == 0 else "k_actor")
     act, bj, bi = eng.actor_argmin(cand)
     Jc = np.where(np.isnan(J), np.inf, J)
     np.testing.assert_array_equal(bi, np.argmin(Jc, axis=1).astype(np.int32))
@@ -569,10 +570,10 @@ def test_horizon_limits(name, N, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("K", [4, 8, 12, 16, 20, 28, 32, 36])
+@pytest.mark.parametrize("K", [4, 6, 8, 12, 16, 20, 28, 32, 36])
 @pytest.mark.parametrize("name,Nh", [("3wrobot", 10), ("3wrobotNI", 3), ("2tank", 20)])
 def test_few_candidates_per_env_on_packed_tiles(name, Nh, K, dtype):
-    """Streamed candidates with 4 <= K <= 32 (K % 4 == 0): k_actor_dma_packed - 64 / K envs share one DMA tile, the env state is
+    """Streamed candidates with 4 <= K <= 32 (an env's rows a whole number of 16-byte pieces): k_actor_dma_packed - 64 / K envs share one DMA tile, the env state is
     per-lane, the argmin segmented (rcg_actor_dma_packed.hpp).  Operator (J of every row), argmin (ties -> lower index, NaN =
     +inf, all-NaN -> 0) and a three-tick closed loop against the oracle on a batch whose last wave and last tile are ragged;
     gamma != 1 takes the discounted instance.  K = 36 (one env per tile would be mostly empty, no packing) stays on k_actor."""
@@ -592,8 +593,9 @@ def test_few_candidates_per_env_on_packed_tiles(name, Nh, K, dtype):
     eng.set_state(x)
     dc = eng.to_device(cand)
     J = eng.actor_cost(dc)
-    kernel = "k_actor_dma_packed" if K <= 32 else "k_actor"
-    assert_kernel(eng, kernel, (N.DMA_MPC_G1 if gamma == 1.0 else N.DMA_MPC) if K <= 32 else None)
+    packed = K <= 32 and (K * Nh * cfg.du * eng.real().itemsize) % 16 == 0  # an env's rows = whole 16-byte pieces
+    kernel = "k_actor_dma_packed" if packed else "k_actor"
+    assert_kernel(eng, kernel, (N.DMA_MPC_G1 if gamma == 1.0 else N.DMA_MPC) if packed else None)
     x64, c64 = x.astype(np.float64), cand.astype(np.float64)
     J_or = O.actor_cost(c64, x64[:, None, :], x64[:, None, :], cfg)
     fin = np.isfinite(J_or)
