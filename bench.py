@@ -521,9 +521,25 @@ def main(argv=None):
             evs.append(ev)
         return evs
 
+    def align_streams():
+        """Several handles on streams of their own drift apart (the stream with the longest kernels carries a backlog):
+        make every stream wait, ON THE DEVICE, until all of them have arrived here, so that a timed region starts for all
+        handles at the same instant.  No host wait; a no-op for a single stream."""
+        if len(streams) < 2:
+            return
+        here = record_all()
+        for i, st in enumerate(streams):
+            for j, ev in enumerate(here):
+                if j != i:
+                    st.wait_event(ev)
+
     def span_ms(starts, stops):
-        """Device time from the earliest start to the latest stop (the engines' streams run side by side)."""
+        """Device time from the (aligned) start to the latest stop over the engines' streams."""
         return max(a.elapsed_time(b) for a in starts for b in stops)
+
+    def chunk_ms_of(starts, stops):
+        """Pre-spin chunks are not aligned: each stream's own time for the chunk, the slowest stream's counts."""
+        return max(a.elapsed_time(b) for a, b in zip(starts, stops))
 
     # ---- everything the timed region needs exists BEFORE the clock pre-spin: no allocation, no event creation, no host
     # synchronisation stands between the warm-up steps and the timed steps ----------------------------------------------
@@ -566,7 +582,7 @@ def main(argv=None):
         if len(evs) >= 4:
             for ev in evs[-3]:
                 ev.synchronize()  # two chunks stay queued behind it: the GPU never runs dry
-            chunk_ms.append(span_ms(evs[-4], evs[-3]))
+            chunk_ms.append(chunk_ms_of(evs[-4], evs[-3]))
             spun = time.perf_counter() - t_spin
             # steady = the last four chunks within 1.5 % of each other (a box that has just been handed over can need
             # longer than a warm one); never less than PRESPIN_S, never more than PRESPIN_MAX_S
@@ -592,6 +608,7 @@ def main(argv=None):
     if stride:
         for e in engines:
             e.profile(prof_kernels, stride=stride)  # host-side switch only: nothing is pending, nothing is waited for
+    align_streams()
     ev_start = record_all()
     for _ in range(args.steps):
         tick()
@@ -599,6 +616,8 @@ def main(argv=None):
     for e in engines:
         e.profile_pause()
     # the same K steps again without any per-launch event: what the sampling itself costs the stream
+    align_streams()
+    ev_start2 = record_all()
     for _ in range(args.steps):
         tick()
     ev_stop2 = record_all()
@@ -617,7 +636,7 @@ def main(argv=None):
     barrier()
     wall_s = time.perf_counter() - t_wall0
     compute_ms = span_ms(ev_start, ev_stop)
-    unbracketed_ms = span_ms(ev_stop, ev_stop2)
+    unbracketed_ms = span_ms(ev_start2, ev_stop2)
     allgather_ms = (ex_a.elapsed_time(ex_b) / n_exch) if n_exch else 0.0
     if dist is not None:  # MAX over ranks (device times of each rank's own stream)
         tmax = torch.tensor([compute_ms, unbracketed_ms, allgather_ms], device=coll_dev, dtype=torch.float64)
@@ -875,6 +894,13 @@ def two_handles(args, device, x0, cand, B, K, Nh, torch):
         pool.control_tick(K, cd, ordered=True)
     a = [torch.cuda.Event(enable_timing=True) for _ in streams]
     b = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    here = [torch.cuda.Event() for _ in streams]  # align the two streams on the device: the timed ticks start together
+    for ev, st in zip(here, streams):
+        ev.record(st)
+    for i, st in enumerate(streams):
+        for j, ev in enumerate(here):
+            if j != i:
+                st.wait_event(ev)
     for ev, st in zip(a, streams):
         ev.record(st)
     n = max(100, args.steps)

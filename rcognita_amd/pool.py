@@ -62,8 +62,8 @@ class MixedPool:
     ``parts`` > 1 cuts every type's shard into that many handles of (nearly) equal size, each on a stream of its own.
     For RQL / SQL this is worth doing even with ONE system type: a tick is {critic fit, actor kernel}, the fit is bound by
     the latency of its longest active-set walk (a few waves stay busy for 50 us) and the actor kernel by HBM, so the fit of
-    one part runs under the actor kernel of another - configs[2] (131072 tank envs, RQL, streamed): 0.473 ms per tick as one
-    handle, 0.422 ms as two (2.77e8 -> 3.10e8 env.control-steps/s; four parts: 0.443 ms, tools/split_probe.py)."""
+    one part runs under the actor kernel of another - configs[2] (131072 tank envs, RQL, streamed): 0.476 ms per tick as one
+    handle, 0.430 ms as two (2.75e8 -> 3.05e8 env.control-steps/s; four parts: 0.448 ms, tools/split_probe.py)."""
 
     def __init__(self, counts: Dict[str, int], rank: int = 0, world: int = 1, device: int = 0, dtype: str = "f32",
                  Nactor: int = 15, mode: str = "MPC", own_streams: bool = True, parts: int = 1, **over):

@@ -38,6 +38,13 @@ for S in (1, 2, 4, 1, 2):
         tick()
     a = [torch.cuda.Event(enable_timing=True) for _ in streams]
     b = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    here = [torch.cuda.Event() for _ in streams]  # align the streams on the device: the timed ticks start together
+    for ev, st in zip(here, streams):
+        ev.record(st)
+    for i, st in enumerate(streams):
+        for j, ev in enumerate(here):
+            if j != i:
+                st.wait_event(ev)
     for ev, st in zip(a, streams):
         ev.record(st)
     T = 300
