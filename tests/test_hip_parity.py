@@ -620,3 +620,40 @@ def test_few_candidates_per_env_on_packed_tiles(name, Nh, K, dtype):
                              what=f"{name} K={K} {dtype} t={t}")
     assert_kernel(eng, kernel)
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, 3, np.int32))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,Nh,K", [("3wrobot", 5, 16), ("2tank", 10, 12), ("3wrobotNI", 4, 32)])
+def test_packed_tiles_with_state_lag_and_per_env_parameters(name, Nh, K, dtype):
+    """k_actor_dma_packed with the reference's one-step state lag (rollout from STATE_PREV, y_0 = the observation: two
+    state vectors per lane) and heterogeneous per-env parameters (per-lane loads, the model constants prepared per tile):
+    a streamed closed loop on a ragged batch, every env and tick against the oracle."""
+    from oracle import parity as PAR
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(K + Nh)
+    B, T = 531, 4
+    kw = dict(n_actor=Nh, ref_lag=True)
+    pars = None
+    if name != "3wrobotNI":  # (the kinematic robot has no parameters)
+        kw["per_env_pars"] = True
+    eng, cfg = both(name, B, dtype, **kw)
+    if name == "3wrobot":
+        pars = np.stack([rng.uniform(5, 20, B), rng.uniform(0.5, 2, B)], axis=-1)
+    elif name == "2tank":
+        pars = np.asarray(cfg.pars)[None] * rng.uniform(0.8, 1.25, (B, 5))
+    if pars is not None:
+        eng.set_field(N.FIELD_PARS, pars.astype(eng.real))
+        pars = pars.astype(eng.real).astype(np.float64)
+    x0 = rand_states(rng, name, B).astype(eng.real)
+    eng.set_state(x0)
+    cand = rand_actions(rng, name, (B, K, Nh)).astype(eng.real)
+    dc = eng.to_device(cand)
+    env = O.new_batch(cfg, x0.astype(np.float64), pars=pars)
+    rep = PAR.TickReport()
+    for t in range(T):
+        eng.control_tick(dc, K=K)
+        env = PAR.check_tick(cfg, env, cand.astype(np.float64), PAR.device_fields(eng, N, with_prev=True), tol=TOL[dtype],
+                             report=rep, what=f"{name} K={K} {dtype} lag t={t}")
+    assert_kernel(eng, "k_actor_dma_packed", N.DMA_MPC_G1)
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
