@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Round 3 experiment: can the critic fit (oracle.rcg_oracle.critic_fit_single, k_critic_fit) reach its minimiser in a
+"""TEST INFRASTRUCTURE ONLY (an experiment ON the oracle, kept under oracle/ because it imports it; nothing in the product path,
+tools/ or bench.py uses it).
+
+Round 3 experiment: can the critic fit (oracle.rcg_oracle.critic_fit_single, k_critic_fit) reach its minimiser in a
 BOUNDED, small number of iterations?  (block principal pivoting or projected Newton.)  CPU only.
 
 Collects the TD stacks (A, b) that RQL / SQL closed loops of the oracle actually produce and solves each with
@@ -26,14 +29,14 @@ c iterations would bound the count but makes the result depend on the path, i.e.
 multiply-adds, numpy does not): parity with the oracle would then hold only up to pivot ties.  k_critic_fit therefore
 keeps the exact single-pivot walk; DESIGN.md records this under "critic fit".
 
-    python tools/fit_bpp_experiment.py [n_envs] [ticks]
+    python oracle/experiments/fit_bpp_experiment.py [n_envs] [ticks]
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import rcg_oracle as O  # noqa: E402
 from tests.helpers import oracle_cfg  # noqa: E402

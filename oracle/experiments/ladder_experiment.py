@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""How fine does the line-search ladder of the on-device actor optimiser (rcg_actor_optimize, oracle twin
+"""TEST INFRASTRUCTURE ONLY (an experiment ON the oracle, kept under oracle/ because it imports it; nothing in the product path,
+tools/ or bench.py uses it).
+
+How fine does the line-search ladder of the on-device actor optimiser (rcg_actor_optimize, oracle twin
 rcg_oracle.actor_optimize_single) have to be?  CPU experiment on the reference's own F8 states (cost SLSQP reaches):
 ladders over the same range (4 box widths .. 2^-28) with 64 / 32 / 16 step lengths, 5 and 10 iterations.
 
-    python tools/ladder_experiment.py
+    python oracle/experiments/ladder_experiment.py
 
 Result (2026-10, recorded in DESIGN.md 6): the three ladders reach the same cost to five digits on all three systems
 (median J / J_slsqp: 3wrobot 1.00013 / 1.00002, 3wrobotNI 1.00032 / 1.00012, 2tank 1.00000 after 5 / 10 iterations),
@@ -14,7 +17,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import rcg_oracle as O  # noqa: E402
 from tests.conftest import load_golden  # noqa: E402

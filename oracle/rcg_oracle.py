@@ -565,7 +565,7 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
     box widths down by a factor 4 per lane, to 2^-28) are evaluated with ``_actor_cost``; the best one (lower J, then
     lower l) replaces u if it improves J, otherwise the search stops.  Returns ``(u [N, du], J, iterations used)``.
     (Round 1 searched 64 step lengths of ratio sqrt 2 over the same range: on the F8 states both ladders reach the same
-    cost to five digits, tools/ladder_experiment.py, and the coarse one needs a quarter of the trial rollouts.)"""
+    cost to five digits, oracle/experiments/ladder_experiment.py, and the coarse one needs a quarter of the trial rollouts.)"""
     lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
     w = hi - lo
     u = np.array(u_init, dtype=np.float64).reshape(cfg.n_actor, cfg.du)

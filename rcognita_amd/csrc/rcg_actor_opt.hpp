@@ -15,7 +15,7 @@
 // lengths (ratio sqrt 2) per env with the whole wave - 56 k VALU instructions per wave for 5 iterations, 90 % of them the
 // line search (16 passes of a full rollout per iteration), issue slots 93 % busy: VALU-bound on trial rollouts.  On the
 // reference's own F8 states a 16-step ladder of ratio 4 over the same range (4 .. 2^-28 box widths) reaches the same
-// cost to five digits (tools/ladder_experiment.py), so v3 runs four envs per pass: 4 x fewer trial rollouts.
+// cost to five digits (oracle/experiments/ladder_experiment.py), so v3 runs four envs per pass: 4 x fewer trial rollouts.
 // No HBM traffic inside the loop.  Mirrors oracle/rcg_oracle.py::actor_optimize_single statement by statement; on the
 // reference's own test states it reaches SLSQP's cost within 0.2 % after 10 iterations
 // (tests/test_oracle_optimizer.py, tests/test_hip_optimizer.py).
