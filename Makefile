@@ -3,7 +3,7 @@
 #   make lib        -> HIP library only (hipcc cross-compiles without a GPU)
 #   make oracle     -> C oracle only (gcc)
 #   make dev        -> rcognita_amd/lib/librcg_dev.so: the same sources with -DRCG_DEV (timing-only switches RCG_DBG of
-#                      k_actor_dma compiled in; for tools/ only - select it with RCG_LIB=.../librcg_dev.so)
+#                      k_actor_dma compiled in; for tools/ only - a tool binds it with rcognita_amd._native.use_library(path))
 #   make asan       -> build/asan/abi_asan: the C oracle and the HOST side of librcg (host-only compile of the .hip units,
 #                      no device code) under clang -fsanitize=address,undefined, with tests/asan_driver.c; CPU only
 HIPCC   ?= hipcc

@@ -107,7 +107,7 @@ def parse(argv=None):
 # launcher: the parent of `python bench.py --gpus N` (never imports torch / librcg, never touches the GPU)
 # ---------------------------------------------------------------------------------------------------------------
 def refuse_dev_knobs():
-    """Result- or schedule-changing developer knobs of librcg (rcg_sysops.hpp::DevKnobs, _native.RCG_LIB) must not be
+    """Result- or schedule-changing developer knobs of librcg (rcg_sysops.hpp::DevKnobs) must not be
     set for a measurement: the bench line is quoted for the library as shipped."""
     bad = sorted(k for k in os.environ if k.startswith("RCG_"))
     if bad:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 114 /* 0.1.1 + rcg_last_launch, rcg_profile_samples, rcg_wait_stream (round 3) */
+#define RCG_VERSION 115 /* 0.1.1 + rcg_set_optimizer, rcg_candidates_refine; optimiser and T-tick launches in every mode (round 4) */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -258,18 +258,48 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
  * GPU that idles between short ticks clocks down (measured, streamed K = 64: B = 4096 102 us per tick from a Python loop, 9.6 us
  * here; B = 1024 11.7 -> 7.3 us).  Identical to T single calls; stops at the first error. */
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);
-/* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398), MPC with a
- * diagonal R1: `iters` iterations of {adjoint gradient of _actor_cost w.r.t. the whole sequence, box-scaled
- * projected line search over 16 step lengths (4 box widths down to 2^-28, ratio 4)}.  obs / state_sys as
+/* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398) for every mode
+ * (MPC / RQL / SQL, controllers.py:1304-1326; RQL / SQL read the handle's W_CRITIC), stage-cost structure (diagonal or
+ * full R1, biquadratic) and critic structure: `iters` iterations of projected limited-memory quasi-Newton descent -
+ * adjoint gradient of _actor_cost w.r.t. the whole sequence (closed-form gradients of the stage cost and of w . phi), L-BFGS
+ * direction over the last `memory` accepted steps on the free coordinates (box-scaled steepest descent without pairs), 16
+ * trial step lengths evaluated in parallel (quasi-Newton: 4 .. 2^-13 times the unit step; steepest descent: 4 box widths down
+ * to 2^-28), best feasible trial kept if it lowers J.  Deterministic, no finite differences.  obs / state_sys as
  * rcg_actor_cost; u_init [B][N][du] (NULL: action_sqn_init = action_init tiled, as the reference starts every call);
  * outputs, each may be NULL:
- * u_opt [B][N][du], action [du][B] (first du entries, controllers.py:1427), best_J [B], n_iter [B] int32. */
+ * u_opt [B][N][du], action [du][B] (first du entries, controllers.py:1427), best_J [B], n_iter [B] int32 (accepted steps).
+ * On the reference's own decisions (fixtures F8 / F8c: SLSQP's result at 12-32 states per system, mode and critic
+ * structure) 30 iterations end within 0.5 % of SLSQP's cost. */
 int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
                        void* u_opt, void* action, void* best_J, int32_t* n_iter);
-/* rcg_control_tick with rcg_actor_optimize as the decision: sim_step -> optimise -> ACTION, ACTION_SQN, BEST_J ->
- * ACCUM, STEP_IDX.  warm_start != 0: start from the previous tick's optimum shifted by one step (the reference
- * always restarts from action_sqn_init: warm_start = 0). */
+/* Curvature pairs rcg_actor_optimize keeps per env: 0 (projected steepest descent, round 3's optimiser) .. 8; default 4.
+ * Each pair costs 2 * N * du reals of LDS per env. */
+int rcg_set_optimizer(rcg_handle* h, int32_t memory);
+/* rcg_control_tick with rcg_actor_optimize as the decision: sim_step -> [RQL/SQL: buffer push + critic fit] -> optimise ->
+ * ACTION, ACTION_SQN, BEST_J -> ACCUM, STEP_IDX.  warm_start != 0: start from the previous tick's optimum shifted by one
+ * step (the reference always restarts from action_sqn_init: warm_start = 0). */
 int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start);
+/* Device-side candidate search, the sampling counterpart of rcg_actor_optimize (replacement of controllers.py:1330-1427 that
+ * needs no gradient): `rounds` rounds of K candidate sequences per env, GENERATED on the device, evaluated with
+ * _actor_cost where they are generated (they never exist in HBM) and refined around the round's winner - one launch, every
+ * mode and cost structure.  Round r (r = 0 .. rounds - 1) perturbs its centre - round 0: `centre` [B][N][du] (NULL:
+ * action_sqn_init) - by sigma_r xi with sigma_r = 0.5 (hi - lo) 2^-r, clipped to the box; candidate 0 is the centre itself
+ * (the cost never increases from round to round), candidate 1 of round 0 is action_sqn_init, candidates below K / 2 hold one
+ * draw per input over the horizon, the others draw per input and step.  xi: Philox4x32-10 keyed by (cfg.seed, global env id,
+ * EPISODE_IDX, STEP_IDX) and indexed by (candidate, chunk, round) - independent of batch size, sharding and launch geometry;
+ * Box-Muller in float32 (rcg_search.hpp).  K >= 64.  obs / state_sys as rcg_actor_cost; outputs, each may be NULL:
+ * u_best [B][N][du] (the last round's winner), action [du][B] (its first du entries), best_J [B], best_idx [B] int32 (the
+ * winner's index in the last round; 0 = the incumbent was kept). */
+int rcg_actor_search(rcg_handle* h, int32_t K, int32_t rounds, const void* obs, const void* state_sys, const void* centre,
+                     void* u_best, void* action, void* best_J, int32_t* best_idx);
+/* rcg_control_tick with rcg_actor_search as the decision: sim_step -> [RQL/SQL: buffer push + critic fit] -> search ->
+ * ACTION, ACTION_SQN, BEST_J, BEST_IDX -> ACCUM, STEP_IDX.  warm_start != 0: round 0 is centred on the previous tick's
+ * optimum shifted by one step (from the episode's second tick on). */
+int rcg_control_tick_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t warm_start);
+/* The producer alone: the K candidate rows rcg_actor_search evaluates in round `round` around `centre` [B][N][du] (NULL:
+ * action_sqn_init) at the handle's current (EPISODE_IDX, STEP_IDX), written to cand [B][K][N][du] (device) - for callers
+ * that stream candidates through rcg_actor_cost / rcg_actor_argmin / rcg_control_tick, and for tests. */
+int rcg_candidates_sample(rcg_handle* h, void* cand, int32_t K, int32_t round, const void* centre);
 /* Nominal (benchmark / safe-fallback) controllers for n points, replacing CtrlNominal3WRobot.compute_action_vanila /
  * compute_action / compute_LF (rcognita/controllers.py:1495-1755) and CtrlNominal3WRobotNI's
  * (controllers.py:1757-1956); the handle's system selects which.  obs: device [ds][n]; action (may be NULL): device
@@ -344,7 +374,8 @@ typedef enum rcg_kernel_id {
   RCG_KID_SIM_DIST = 8,   /* k_sim_dist: env step on the full state [state, disturb]                                  */
   RCG_KID_CRITIC_FIT = 9, /* k_critic_fit: [env step] + push + [fit]                                                  */
   RCG_KID_ACTOR_DMA_PACKED = 10, /* k_actor_dma_packed: k_actor_dma's data path with 64 / K envs per tile (4 <= K <= 32) */
-  RCG_KID_COUNT_ = 11
+  RCG_KID_ACTOR_SEARCH = 11, /* k_actor_search: candidates generated, evaluated and refined in one launch (rcg_actor_search) */
+  RCG_KID_COUNT_ = 12
 } rcg_kernel_id;
 /* variant: k_actor_dma: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL; k_actor / k_ticks: bit 0 generic
  * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates; k_critic_fit: critic_struct + 16 * (rows

@@ -522,29 +522,73 @@ def state_jac_T(sys_id, x, u, pars, lam):
     return ax, bu
 
 
-def actor_grad(u, obs, state_sys, cfg: OracleCfg, pars=None):
-    """Gradient of the MPC ``_actor_cost`` (diagonal R1) w.r.t. the whole action sequence ``u [N, du]`` by one
-    forward Euler rollout and one reverse (adjoint) sweep.  Returns ``(J, g [N, du])``."""
-    assert cfg.mode == MODE_MPC and cfg.stage_obj_struct == STAGE_QUADRATIC
+def stage_obj_grad(chi, cfg: OracleCfg):
+    """d rho / d chi of ``stage_obj`` (controllers.py:1076-1082) for ONE point ``chi [n]``:
+    quadratic ``chi R1 chi`` -> ``(R1 + R1^T) chi``; biquadratic adds ``2 chi * ((R2 + R2^T) chi^2)``."""
+    g = (cfg.R1 + cfg.R1.T) @ chi
+    if cfg.stage_obj_struct == STAGE_BIQUADRATIC:
+        g = g + 2.0 * chi * ((cfg.R2 + cfg.R2.T) @ (chi * chi))
+    return g
+
+
+def critic_grad(y, u, w, cfg: OracleCfg):
+    """(d Q / d y, d Q / d u) of ``_critic`` = ``w . phi`` (controllers.py:1192-1214) for ONE point, every structure.
+    chi = [y - target, u], so d chi / d y = I; quad-mix works on the RAW observation (controllers.py:1212)."""
+    ds, du = cfg.ds, cfg.du
+    n = ds + du
+    cs = cfg.critic_struct
+    if cs == CRITIC_QUAD_MIX:
+        W = np.asarray(w[ds:ds + ds * du]).reshape(ds, du)
+        gy = 2.0 * w[:ds] * y + W @ u
+        gu = W.T @ y + 2.0 * w[ds + ds * du:] * u
+        return gy, gu
+    chi = np.concatenate([y if cfg.target is None else y - cfg.target, u])
+    if cs == CRITIC_QUAD_NOMIX:
+        g = 2.0 * w * chi
+    else:
+        iu, ju = np.triu_indices(n)
+        M = np.zeros((n, n))
+        M[iu, ju] = w[:len(iu)]  # uptria2vec order (utilities.py:81-96)
+        g = (M + M.T) @ chi      # the diagonal appears in both -> 2 w_pp chi_p
+        if cs == CRITIC_QUAD_LIN:
+            g = g + w[len(iu):]
+    return g[:ds], g[ds:]
+
+
+def actor_grad(u, obs, state_sys, cfg: OracleCfg, pars=None, w_critic=None):
+    """Gradient of ``_actor_cost`` (every mode, every stage / critic structure) w.r.t. the whole action sequence
+    ``u [N, du]`` by one forward Euler rollout and one reverse (adjoint) sweep.  Returns ``(J, g [N, du])``.
+
+    J = sum_k c_k(y_k, u_k) with y_0 = obs (not a function of u), y_k = x_k, x_{k+1} = x_k + h f(x_k, u_k):
+      MPC c_k = gamma^k rho;  RQL c_k = gamma^k rho (k < N-1), c_{N-1} = Q_w;  SQL c_k = Q_w  (controllers.py:1304-1326).
+    lam_k = d J / d x_k = d c_k / d y + (I + h A_k^T) lam_{k+1};  g_k = d c_k / d u + h B_k^T lam_{k+1}."""
     N, du, ds, h = cfg.n_actor, cfg.du, cfg.ds, cfg.pred_step_size
     pars = cfg.pars if pars is None else pars
-    Rd = np.diag(cfg.R1)
     tgt = np.zeros(ds) if cfg.target is None else cfg.target
     X = [np.asarray(state_sys, dtype=np.float64)]
     for k in range(1, N):
         X.append(X[-1] + h * state_dyn(cfg.sys_id, X[-1], u[k - 1], pars))
     Y = [np.asarray(obs, dtype=np.float64)] + X[1:]
-    J, gk = 0.0, 1.0
-    gks = []
+    gks, gk = [], 1.0
     for k in range(N):
-        chi = np.concatenate([Y[k] - tgt, u[k]])
-        J += gk * float(np.sum(Rd * chi * chi))
         gks.append(gk)
         gk *= cfg.gamma
+
+    def is_critic_step(k):
+        return cfg.mode == MODE_SQL or (cfg.mode == MODE_RQL and k == N - 1)
+
+    def step_grad(k):  # (d c_k / d y, d c_k / d u)
+        if is_critic_step(k):
+            return critic_grad(Y[k], u[k], np.asarray(w_critic, dtype=np.float64), cfg)
+        gc = gks[k] * stage_obj_grad(np.concatenate([Y[k] - tgt, u[k]]), cfg)
+        return gc[:ds], gc[ds:]
+
+    J = float(actor_cost(u, obs, state_sys, cfg, pars=pars, w_critic=w_critic))
     g = np.zeros((N, du))
     lam = np.zeros(ds)  # d J / d x_{k+1}
     for k in range(N - 1, -1, -1):
-        g[k] = gks[k] * 2.0 * Rd[ds:] * u[k]
+        gy, gu = step_grad(k)
+        g[k] = gu
         if k < N - 1:
             ax, bu = state_jac_T(cfg.sys_id, X[k], u[k], pars, lam)
             g[k] = g[k] + h * bu
@@ -552,43 +596,138 @@ def actor_grad(u, obs, state_sys, cfg: OracleCfg, pars=None):
         else:
             lam_k = np.zeros(ds)
         if k >= 1:  # y_0 is the observation, not a function of the actions
-            lam_k = lam_k + gks[k] * 2.0 * Rd[:ds] * (Y[k] - tgt)
+            lam_k = lam_k + gy
         lam = lam_k
     return J, g
 
 
-def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None):
-    """Projected, box-scaled steepest descent with a 16-way line search.
+OPT_MEMORY = 4  # curvature pairs kept by the limited-memory quasi-Newton direction (0: projected steepest descent)
 
-    Per iteration: g = grad J(u); d = g * (hi - lo)^2 (the box-width metric makes the inputs commensurable);
-    the 16 candidates ``clip(u - alpha_l d)`` with ``alpha_l = 4^(1 - l) / max|d / (hi - lo)|``, l = 0..15 (from four
-    box widths down by a factor 4 per lane, to 2^-28) are evaluated with ``_actor_cost``; the best one (lower J, then
-    lower l) replaces u if it improves J, otherwise the search stops.  Returns ``(u [N, du], J, iterations used)``.
-    (Round 1 searched 64 step lengths of ratio sqrt 2 over the same range: on the F8 states both ladders reach the same
-    cost to five digits, oracle/experiments/ladder_experiment.py, and the coarse one needs a quarter of the trial rollouts.)"""
+
+def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY):
+    """Projected limited-memory quasi-Newton descent with a 16-way line search, every mode and cost structure.
+
+    Per iteration, with g = grad J(u) (adjoint sweep) and the box [lo, hi] of width w:
+      * free set: coordinate i is held iff it sits on a bound and -g_i points out of the box;
+      * the pair (s, y) = (u - u_prev, g - g_prev) of the last ACCEPTED step joins a ring of ``memory`` pairs;
+      * direction d = H g on the free coordinates by the L-BFGS two-loop recursion over the stored pairs restricted
+        to the free set (a pair with s.y <= 1e-12 |s| |y| there is skipped), initial metric H0 = scale * diag(w^2) with
+        scale = s.y / (y . w^2 y) of the newest pair (1 if that is not positive).  Without pairs, or if d is not a
+        descent direction (d . g <= 0: the memory is dropped), d = w^2 g on the free set - box-scaled steepest descent;
+      * 16 trial points clip(u - alpha_l d): quasi-Newton alpha_l = 2^(2 - l) (the unit step is l = 2), steepest
+        descent alpha_l = 4^(1 - l) / max_i |d_i / w_i| (four box widths down to 2^-28);  lower J wins, then lower l;
+      * the best trial replaces u if it lowers J; otherwise a quasi-Newton iteration drops its memory and the next one
+        retries with steepest descent, a steepest-descent iteration ends the search.
+    Deterministic, no finite differences.  Every sum runs in index order, as k_actor_opt (rcg_actor_opt.hpp) does.
+    Returns ``(u [N, du], J, accepted steps)``.  Round 3's optimiser was the ``memory = 0`` case (with the steepest-descent
+    step scaled over all coordinates): it stalls 3-14 % above SLSQP on the critic-mode fixtures F8c, whose terminal
+    action has 1e4 times the curvature of the others; four pairs close that to < 0.5 % in 20 iterations."""
     lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
-    w = hi - lo
-    u = np.array(u_init, dtype=np.float64).reshape(cfg.n_actor, cfg.du)
-    J = float(actor_cost(u, obs, state_sys, cfg, pars=pars))
+    N, du = cfg.n_actor, cfg.du
+    R = N * du
+    wbox = np.tile(hi - lo, N)
+    lo_f, hi_f = np.tile(lo, N), np.tile(hi, N)
+    h0 = wbox * wbox
+    M = int(memory)
+    u = np.array(u_init, dtype=np.float64).reshape(N, du)
+    J = float(actor_cost(u, obs, state_sys, cfg, pars=pars, w_critic=w_critic))
+    S = np.zeros((max(M, 1), R))
+    Y = np.zeros((max(M, 1), R))
+    head, n_pairs, pending = 0, 0, False
     used = 0
     for _ in range(int(iters)):
-        _, g = actor_grad(u, obs, state_sys, cfg, pars=pars)
-        d = g * w * w
-        gn = float(np.max(np.abs(d) / w))
+        _, g2 = actor_grad(u, obs, state_sys, cfg, pars=pars, w_critic=w_critic)
+        g = g2.reshape(R)
+        uf = u.reshape(R)
+        if pending:  # finish the pair of the last accepted step: Y[head] holds the gradient at its start point
+            for i in range(R):
+                Y[head, i] = g[i] - Y[head, i]
+            head = (head + 1) % M
+            n_pairs = min(n_pairs + 1, M)
+            pending = False
+        free = np.zeros(R, dtype=bool)
+        for i in range(R):
+            free[i] = not ((uf[i] <= lo_f[i] and g[i] > 0.0) or (uf[i] >= hi_f[i] and g[i] < 0.0))
+        d = np.zeros(R)
+        quasi = n_pairs > 0
+        if quasi:
+            q = np.where(free, g, 0.0)
+            a_t, sy_t, ok_t = np.zeros(M), np.zeros(M), np.zeros(M, dtype=bool)
+            scale = 1.0
+            for t in range(n_pairs):  # newest -> oldest
+                j = (head - 1 - t) % M
+                sy = ss = yy = sq = yhy = 0.0
+                for i in range(R):
+                    if free[i]:
+                        sy += S[j, i] * Y[j, i]
+                        ss += S[j, i] * S[j, i]
+                        yy += Y[j, i] * Y[j, i]
+                        sq += S[j, i] * q[i]
+                        yhy += (Y[j, i] * h0[i]) * Y[j, i]
+                ok = sy > 0.0 and sy * sy > 1e-24 * (ss * yy)
+                if t == 0 and ok and yhy > 0.0:
+                    scale = sy / yhy
+                ok_t[t], sy_t[t] = ok, sy
+                if ok:
+                    a_t[t] = sq / sy
+                    for i in range(R):
+                        if free[i]:
+                            q[i] = q[i] - a_t[t] * Y[j, i]
+            r = np.zeros(R)
+            for i in range(R):
+                r[i] = (scale * h0[i]) * q[i]
+            for t in range(n_pairs - 1, -1, -1):  # oldest -> newest
+                if not ok_t[t]:
+                    continue
+                j = (head - 1 - t) % M
+                yr = 0.0
+                for i in range(R):
+                    if free[i]:
+                        yr += Y[j, i] * r[i]
+                c = a_t[t] - yr / sy_t[t]
+                for i in range(R):
+                    if free[i]:
+                        r[i] = r[i] + S[j, i] * c
+            dg = 0.0
+            for i in range(R):
+                dg += r[i] * g[i]
+            if dg > 0.0 and np.isfinite(dg):
+                d = r
+            else:
+                quasi = False
+                n_pairs = 0
+        if not quasi:
+            for i in range(R):
+                d[i] = g[i] * h0[i] if free[i] else 0.0
+        gn = 0.0
+        for i in range(R):
+            m_ = abs(d[i]) / wbox[i]
+            gn = m_ if m_ > gn else gn
         if not (gn > 0.0) or not np.isfinite(gn):
             break
-        alphas = (1.0 / gn) * np.exp2(2.0 - 2.0 * np.arange(OPT_NALPHA))
-        cand = np.minimum(np.maximum(u[None] - alphas[:, None, None] * d[None], lo), hi)
-        Js = actor_cost(cand, obs, state_sys, cfg, pars=pars)
+        if quasi:
+            alphas = np.exp2(2.0 - np.arange(OPT_NALPHA))
+        else:
+            alphas = (1.0 / gn) * np.exp2(2.0 - 2.0 * np.arange(OPT_NALPHA))
+        cand = np.minimum(np.maximum(uf[None] - alphas[:, None] * d[None], lo_f), hi_f).reshape(OPT_NALPHA, N, du)
+        Js = actor_cost(cand, obs, state_sys, cfg, pars=pars, w_critic=w_critic)
         bj, bi = argmin_first(Js[None])
         if not (bj[0] < J):
+            if quasi:  # drop the memory, retry from the same point with steepest descent
+                n_pairs = 0
+                continue
             break
-        u, J = cand[int(bi[0])], float(bj[0])
+        u_new = cand[int(bi[0])]
+        if M > 0:
+            S[head] = u_new.reshape(R) - uf
+            Y[head] = g
+            pending = True
+        u, J = u_new, float(bj[0])
         used += 1
     return u, J, used
 
 
-def actor_optimize(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None):
+def actor_optimize(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY):
     """Batched wrapper: ``obs/state_sys [B, ds]``, ``u_init [B, N, du]`` or ``[N, du]`` ->
     ``(u [B, N, du], J [B], iterations [B] int32)``."""
     obs = np.asarray(obs, dtype=np.float64).reshape(-1, cfg.ds)
@@ -599,7 +738,8 @@ def actor_optimize(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None):
     U, Js, its = [], [], []
     for b in range(B):
         p = None if pars is None else np.asarray(pars)[b]
-        u, J, n = actor_optimize_single(cfg, obs[b], xs[b], u0[b], iters, pars=p)
+        wb = None if w_critic is None else np.asarray(w_critic, dtype=np.float64).reshape(-1, cfg.dc)[b if np.ndim(w_critic) == 2 else 0]
+        u, J, n = actor_optimize_single(cfg, obs[b], xs[b], u0[b], iters, pars=p, w_critic=wb, memory=memory)
         U.append(u)
         Js.append(J)
         its.append(n)
@@ -805,11 +945,16 @@ def critic_fit(cfg: OracleCfg, w_prev, obs_buf, act_buf, w_init=None, w_start=No
                                        w_start=None if w_start is None else np.asarray(w_start)[i]) for i in range(B)])
 
 
-def control_tick_opt(cfg: OracleCfg, env: EnvBatch, iters: int, warm_start: bool = False, action_init=None):
+def control_tick_opt(cfg: OracleCfg, env: EnvBatch, iters: int, warm_start: bool = False, action_init=None,
+                     memory=OPT_MEMORY):
     """``control_tick`` with :func:`actor_optimize` as the decision (twin of rcg_control_tick_opt): sim_step ->
-    optimise from ``action_sqn_init`` (or, with ``warm_start`` after the first tick, from the previous optimum shifted
-    by one step with the last step repeated) -> action = first ``du`` entries -> accum, step_idx."""
+    [RQL/SQL: buffer push + critic fit, as ``control_tick``] -> optimise from ``action_sqn_init`` (or, with
+    ``warm_start`` after the first tick, from the previous optimum shifted by one step with the last step repeated) ->
+    action = first ``du`` entries -> accum, step_idx."""
     sim_substeps(cfg, env, cfg.substeps_per_tick)
+    if cfg.mode != MODE_MPC:
+        every = max(int(cfg.critic_every_ticks), 1)
+        critic_update(cfg, env, do_fit=((env.tick_count + 1) % every) == 0)
     obs = env.state
     state_sys = env.state_prev if cfg.ref_lag else env.state
     B = obs.shape[0]
@@ -819,7 +964,8 @@ def control_tick_opt(cfg: OracleCfg, env: EnvBatch, iters: int, warm_start: bool
     else:
         u0 = np.broadcast_to(action_sqn_init(cfg, action_init), (B, cfg.n_actor, cfg.du))
     env.tick_count += 1
-    U, J, its = actor_optimize(cfg, obs, state_sys, u0, iters, pars=env.pars if env.pars.ndim == 2 else None)
+    U, J, its = actor_optimize(cfg, obs, state_sys, u0, iters, pars=env.pars if env.pars.ndim == 2 else None,
+                               w_critic=None if cfg.mode == MODE_MPC else env.w_critic, memory=memory)
     env.action_sqn, env.best_J, env.best_idx = U, J, its
     env.action = U[:, 0, :].copy()
     if not cfg.accum_every_substep:

@@ -31,7 +31,12 @@ from . import rcg_oracle as O
 
 
 class RefLoop:
-    def __init__(self, cfg: O.OracleCfg, state_init, t1, action_init=None, atol=1e-5, rtol=1e-3):
+    def __init__(self, cfg: O.OracleCfg, state_init, t1, action_init=None, atol=1e-5, rtol=1e-3, actor_tol=1e-7,
+                 critic_tol=1e-7):
+        # actor_tol / critic_tol: SLSQP's `tol` (the reference hard-codes 1e-7, controllers.py:1264, 1396); other values
+        # exist for ONE purpose - measuring how far the reference's own closed loop moves when nothing but the optimiser's
+        # stopping rule changes (tests/test_critic_traces.py: the band a different optimiser can be held to)
+        self.actor_tol, self.critic_tol = actor_tol, critic_tol
         self.cfg = cfg
         ds, du = cfg.ds, cfg.du
         self.dt = cfg.sampling_time
@@ -119,7 +124,7 @@ class RefLoop:
             warnings.simplefilter("ignore")
             try:
                 res = minimize(lambda a: self._actor_cost(a, obs), self.action_sqn_init.copy(), method="SLSQP",
-                               tol=1e-7, bounds=Bounds(self.sqn_min, self.sqn_max, keep_feasible=True),
+                               tol=self.actor_tol, bounds=Bounds(self.sqn_min, self.sqn_max, keep_feasible=True),
                                options={"maxiter": 300, "disp": False})
                 sqn = res.x
             except ValueError:  # controllers.py:1400-1402
@@ -129,7 +134,7 @@ class RefLoop:
     def _critic_optimizer(self):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            return minimize(self._critic_cost, self.w_init, method="SLSQP", tol=1e-7,
+            return minimize(self._critic_cost, self.w_init, method="SLSQP", tol=self.critic_tol,
                             bounds=Bounds(self.Wmin, self.Wmax, keep_feasible=True),
                             options={"maxiter": 200, "disp": False}).x
 

@@ -11,11 +11,12 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RCG_LIB lets a developer A/B another build of the same ABI; the default is the in-tree library
-LIB_PATH = os.environ.get("RCG_LIB") or os.path.join(_HERE, "lib", "librcg.so")
+# The in-tree library.  The binding reads NO environment variable; a tool that wants the -DRCG_DEV twin (librcg_dev.so, the
+# launcher's A/B knobs) says so in its own code, before the first handle: use_library(path).
+LIB_PATH = os.path.join(_HERE, "lib", "librcg.so")
 
 # ---- enums (include/rcg.h) -------------------------------------------------------------------
-RCG_VERSION = 114
+RCG_VERSION = 115
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
 SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
 MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
@@ -47,12 +48,13 @@ SYMBOLS = [
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
     "rcg_critic_update", "rcg_control_ticks", "rcg_control_tick_n", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
     "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
-    "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream", "rcg_nominal_theta",
+    "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream", "rcg_nominal_theta", "rcg_set_optimizer",
+    "rcg_actor_search", "rcg_control_tick_search", "rcg_candidates_sample",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 # rcg_kernel_id (rcg_last_launch)
 (KID_NONE, KID_ACTOR, KID_ACTOR_DMA, KID_TICKS, KID_ACTOR_OPT, KID_NOMINAL, KID_SIM, KID_SIM_V, KID_SIM_DIST,
- KID_CRITIC_FIT, KID_ACTOR_DMA_PACKED) = range(11)
+ KID_CRITIC_FIT, KID_ACTOR_DMA_PACKED, KID_ACTOR_SEARCH) = range(12)
 DMA_MPC_G1, DMA_MPC, DMA_RQL_0, DMA_SQL_0 = 0, 1, 2, 6  # variant of k_actor_dma (+ critic_struct; rcg_actor_dma.hpp)
 
 
@@ -85,6 +87,15 @@ class NativeError(RuntimeError):
 
 
 _lib = None
+
+
+def use_library(path):
+    """Bind another build of the same ABI (tools/ and tests/knob_probe.py: librcg_dev.so) instead of the in-tree
+    production library.  Must be called before anything has loaded the library."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library: librcg is already loaded")
+    LIB_PATH = os.path.abspath(path)
 
 
 def lib():
@@ -136,6 +147,10 @@ def lib():
         "rcg_control_tick_n": (C.c_int, [vp, vp, i32, i32]),
         "rcg_actor_optimize": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
+        "rcg_set_optimizer": (C.c_int, [vp, i32]),
+        "rcg_actor_search": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "rcg_control_tick_search": (C.c_int, [vp, i32, i32, i32]),
+        "rcg_candidates_sample": (C.c_int, [vp, vp, i32, i32, vp]),
         "rcg_nominal_action": (C.c_int, [vp, vp, vp, vp, i32, C.c_double, C.POINTER(C.c_double), i32]),
         "rcg_control_tick_nominal": (C.c_int, [vp, C.c_double, C.POINTER(C.c_double)]),
         "rcg_nominal_theta": (C.c_int, [vp, vp, vp, i32]),

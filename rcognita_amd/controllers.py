@@ -9,16 +9,14 @@ no NumPy/SciPy path in this module.
 
 What differs from the reference, by construction (SURVEY.md hard part 1):
 
-* ``_actor_optimizer``: the reference calls SciPy SLSQP (finite-difference gradients, one env).  Here, for
-  MPC with a diagonal quadratic stage cost (every preset), the decision is the on-device optimiser
-  ``rcg_actor_optimize`` (``actor_opt='auto'|'gradient'``): ``opt_iters`` iterations of adjoint gradient +
-  16-way projected line search from the reference's start sequence; on the reference's own test states it
-  reaches SLSQP's cost within 0.2 %.  Otherwise (RQL/SQL, non-diagonal costs, ``actor_opt='sampling'``) the
-  actor is a candidate search evaluated on the GPU: ``K`` action sequences per env go through ``_actor_cost``
-  in one launch and the argmin wins (ties -> lower index); candidates are either given explicitly
-  (``candidates=``), or produced by the built-in sampler below: the reference's start sequence, the previous
-  optimum shifted by one step, a level grid of constant sequences, then ``rounds - 1`` refinement rounds of
-  shrinking perturbations around the incumbent.
+* ``_actor_optimizer``: the reference calls SciPy SLSQP (finite-difference gradients, one env).  Here the decision is
+  made on the device, for every mode (MPC / RQL / SQL), stage-cost and critic structure:
+  ``actor_opt='auto'|'gradient'`` (default) - the on-device optimiser ``rcg_actor_optimize``: ``opt_iters`` iterations of
+  adjoint gradient + limited-memory quasi-Newton direction + 16-way projected line search from the reference's start
+  sequence; on the reference's own decisions (fixtures F8 / F8c) it ends within 0.5 % of SLSQP's cost;
+  ``actor_opt='sampling'`` - the device-side candidate search ``rcg_actor_search``: ``rounds`` rounds of ``n_candidates``
+  sequences generated (Philox), evaluated and refined around each round's winner in one launch; no candidate is ever
+  built on the host.  ``candidates=`` evaluates an explicit set instead (``rcg_actor_argmin``).
 * ``_critic_optimizer``: bounded least squares on the TD stack solved natively (rcg_critic_update),
   see rcognita_amd/csrc/rcg_critic_fit.hpp.
 * the sampling clock uses a tolerance instead of a bare float comparison, so that on the fixed-step
@@ -51,7 +49,7 @@ class CtrlOptPred:
                  model_est_checks=0, gamma=1, Ncritic=4, critic_period=0.1, critic_struct="quad-nomix",
                  stage_obj_struct="quadratic", stage_obj_pars=[], observation_target=[],
                  # ---- build-specific, keyword-only in spirit ----
-                 candidates=None, actor_opt="auto", opt_iters=10, n_candidates=256, rounds=6, seed=0, dtype="f32",
+                 candidates=None, actor_opt="auto", opt_iters=30, n_candidates=256, rounds=6, seed=0, dtype="f64",
                  device=0):
         if is_est_model:
             raise NotImplementedError("is_est_model=1 needs the absent `sippy` package and is out of scope "
@@ -112,7 +110,7 @@ class CtrlOptPred:
             stage_obj_struct=stage_obj_struct, critic_struct=critic_struct, Ncritic=Ncritic, buffer_size=buffer_size,
             dt_sim=sampling_time, sampling_time=sampling_time, pred_step_size=pred_step_size, gamma=gamma,
             pars=spec["pars"], ctrl_bnds=ctrl_bnds, R1=R1, R2=R2, observation_target=tgt,
-            action_init=None if len(action_init) == 0 else action_init))
+            action_init=None if len(action_init) == 0 else action_init, seed=int(seed)))
         self.dim_critic = self._eng.dc
         lo, hi = (-1e3, 1e3) if critic_struct in ("quad-lin", "quad-mix") else (0.0, 1e3)
         self.Wmin, self.Wmax = lo * np.ones(self.dim_critic), hi * np.ones(self.dim_critic)
@@ -124,14 +122,10 @@ class CtrlOptPred:
         self.candidates = None if candidates is None else np.asarray(candidates, dtype=float)
         self.n_candidates, self.rounds = int(n_candidates), int(rounds)
         self.opt_iters = int(opt_iters)
-        diag = np.count_nonzero(R1 - np.diag(np.diag(R1))) == 0
         if actor_opt not in ("auto", "gradient", "sampling"):
             raise ValueError(f"actor_opt must be 'auto', 'gradient' or 'sampling', got {actor_opt!r}")
-        native_ok = mode == "MPC" and stage_obj_struct == "quadratic" and diag
-        if actor_opt == "gradient" and not native_ok:
-            raise NotImplementedError("actor_opt='gradient' covers MPC with a diagonal quadratic stage cost")
-        self._use_gradient = native_ok and actor_opt in ("auto", "gradient")
-        self._rng = np.random.default_rng(seed)
+        self._use_gradient = actor_opt in ("auto", "gradient")
+        self._search_draw = 0  # decisions made so far: the draw counter of the device-side search
         self._prev_opt = None  # previous optimal sequence [B, N, du] (warm start)
         self.last_J = None
         self.last_idx = None
@@ -222,32 +216,12 @@ class CtrlOptPred:
             return J[:, 0] if self._batched else float(J[0, 0])
         return J if self._batched else J[0]
 
-    # ------------------------------------------------------------------ actor search
-    def _initial_candidates(self):
-        """Round 0: start sequence, shifted previous optimum, constant level grid, uniform fill."""
-        B, K, Nh, du = self.B, self.n_candidates, self.Nactor, self.dim_input
-        lo, hi = self.action_min, self.action_max
-        c = self._rng.uniform(lo, hi, size=(B, K, Nh, du))
-        k = 0
-        c[:, k] = self.action_sqn_init.reshape(Nh, du)  # the reference's (only) start point, controllers.py:1379
-        k += 1
-        if self._prev_opt is not None and k < K:
-            c[:, k, :-1] = self._prev_opt[:, 1:]
-            c[:, k, -1] = self._prev_opt[:, -1]
-            k += 1
-        g = int(np.floor((K // 2) ** (1.0 / du)))
-        if g >= 2:
-            axes = [np.linspace(lo[i], hi[i], g) for i in range(du)]
-            grid = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, du)
-            n = min(len(grid), K - k)
-            c[:, k:k + n] = grid[:n, None, :][None]
-        return c
-
+    # ------------------------------------------------------------------ actor
     def _actor_optimizer(self, observation):
-        """Replacement of rcognita/controllers.py:1330-1427.  Returns the first action of the best sequence."""
+        """Replacement of rcognita/controllers.py:1330-1427.  Returns the first action of the best sequence.  Every
+        variant decides on the device; like the reference, every call starts from ``action_sqn_init``."""
         obs = self._b(observation, self.dim_output)
         xs = self._b(self.state_sys, self.dim_output)
-        w = None
         if self.mode != "MPC":
             self._eng.set_field(N.FIELD_W_CRITIC, self._b(self.w_critic, self.dim_critic))
         if self.candidates is not None:
@@ -255,26 +229,14 @@ class CtrlOptPred:
             cand = np.broadcast_to(cand if cand.ndim == 4 else cand[None], (self.B,) + cand.shape[-3:])
             act, bj, bi = self._eng.actor_argmin(cand, obs=obs, state_sys=xs)
             self._prev_opt = cand[np.arange(self.B), bi]
-        elif self._use_gradient:
-            # on-device optimiser (rcg_actor_optimize): like the reference, every call starts from action_sqn_init
+        elif self._use_gradient:  # on-device optimiser (rcg_actor_optimize)
             act, useq, bj, bi = self._eng.actor_optimize(iters=self.opt_iters, obs=obs, state_sys=xs)
             self._prev_opt = useq.astype(float)
-        else:
-            lo, hi = self.action_min, self.action_max
-            cand = self._initial_candidates()
-            best_seq, bj = None, None
-            for r in range(max(self.rounds, 1)):
-                if r > 0:
-                    sigma = 0.25 * (hi - lo) * (0.45 ** (r - 1))
-                    noise = self._rng.standard_normal(cand.shape) * sigma
-                    # half of the perturbations are constant over the horizon, half are per step
-                    half = cand.shape[1] // 2
-                    noise[:, :half] = noise[:, :half, :1]
-                    cand = np.clip(best_seq[:, None] + noise, lo, hi)
-                    cand[:, 0] = best_seq  # keep the incumbent: the search is monotone
-                act, bj, bi = self._eng.actor_argmin(cand, obs=obs, state_sys=xs)
-                best_seq = cand[np.arange(self.B), bi]
-            self._prev_opt = best_seq
+        else:  # device-side candidate search (rcg_actor_search); the draw is keyed by (seed, env, decision number)
+            self._eng.set_field(N.FIELD_STEP_IDX, np.full(self.B, self._search_draw, dtype=np.int32))
+            self._search_draw += 1
+            act, useq, bj, bi = self._eng.actor_search(K=self.n_candidates, rounds=self.rounds, obs=obs, state_sys=xs)
+            self._prev_opt = useq.astype(float)
         self.last_J, self.last_idx = bj.astype(float), bi
         act = act.astype(float)
         return act if self._batched else act[0]

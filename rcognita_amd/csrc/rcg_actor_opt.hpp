@@ -1,24 +1,31 @@
 // rcg_actor_opt.hpp - k_actor_opt: on-device replacement of the SLSQP call in CtrlOptPred._actor_optimizer
-// (rcognita/controllers.py:1330-1427), MPC with a diagonal R1.
+// (rcognita/controllers.py:1330-1427) for every mode (MPC / RQL / SQL, controllers.py:1304-1326),
+// stage-cost structure (diagonal or full R1, biquadratic: controllers.py:1076-1082) and critic structure
+// (controllers.py:1204-1212).
 //
-// One wave owns OPT_G = 16 envs.  Per iteration:
+// Algorithm (oracle twin: oracle/rcg_oracle.py::actor_optimize_single, same statements in the same order): projected
+// limited-memory quasi-Newton descent on the box [lo, hi]^N.  One wave owns OPT_G = 16 envs.  Per iteration:
 //   1. lane e < 16 = env e: gradient of _actor_cost w.r.t. the whole action sequence u [N][du] by a forward Euler
-//      rollout (states to LDS) and a reverse (adjoint) sweep; direction d = g * (hi - lo)^2 (box-width metric) to LDS,
-//      gn = max |d / (hi - lo)| stays in the lane;
-//   2. four envs at a time, one per row of 16 lanes: OPT_NA = 16 step lengths alpha_l = 4^(1 - l) / gn, ONE PER LANE of
-//      the row; the lane evaluates _actor_cost of clip(u_e - alpha_l d_e) - the same rollout as k_actor, u and d from
-//      LDS (broadcast reads within the row); row argmin over (J, l) (lower J, then lower l; NaN = +inf; f32: four DPP
-//      stages, a DPP row IS 16 lanes); if it improves the incumbent, the row's lanes update u_e in LDS, otherwise env e
-//      stops.
+//      rollout (states to LDS) and a reverse (adjoint) sweep - the stage terms contribute gamma^k d rho / d chi, the
+//      critic terms of RQL (last step) and SQL (every step) d (w . phi) / d chi, closed form for all four structures;
+//      the (s, y) pair of the last accepted step is completed; the free set (a coordinate on a bound whose descent
+//      direction leaves the box is held) goes to a 64-bit mask; direction d = H g on the free set by the L-BFGS
+//      two-loop recursion over the <= `memory` pairs kept in LDS, initial metric scale * diag((hi - lo)^2); without
+//      pairs, or when d is not a descent direction, d = (hi - lo)^2 g (box-scaled steepest descent);
+//   2. four envs at a time, one per row of 16 lanes: OPT_NA = 16 step lengths, ONE PER LANE of the row - quasi-Newton
+//      alpha_l = 2^(2 - l), steepest descent alpha_l = 4^(1 - l) / max |d / (hi - lo)|; the lane evaluates _actor_cost of
+//      clip(u_e - alpha_l d_e), u and d from LDS (broadcast reads within the row); row argmin over (J, l) (lower J, then
+//      lower l; NaN = +inf; f32: four DPP stages, a DPP row IS 16 lanes); if it improves the incumbent the row's lanes
+//      update u_e and open the next pair, otherwise a quasi-Newton env drops its memory (and retries with steepest
+//      descent), a steepest-descent env stops.
+// No HBM traffic inside the loop.
 // History (profiles/r02_*_valu_pmc.json has the SQ counters): v1 gave every env a whole wave and computed the gradient
-// redundantly on all 64 lanes (55 % of its instruction stream); v2 shared a wave between 16 envs and searched 64 step
-// lengths (ratio sqrt 2) per env with the whole wave - 56 k VALU instructions per wave for 5 iterations, 90 % of them the
-// line search (16 passes of a full rollout per iteration), issue slots 93 % busy: VALU-bound on trial rollouts.  On the
-// reference's own F8 states a 16-step ladder of ratio 4 over the same range (4 .. 2^-28 box widths) reaches the same
-// cost to five digits (oracle/experiments/ladder_experiment.py), so v3 runs four envs per pass: 4 x fewer trial rollouts.
-// No HBM traffic inside the loop.  Mirrors oracle/rcg_oracle.py::actor_optimize_single statement by statement; on the
-// reference's own test states it reaches SLSQP's cost within 0.2 % after 10 iterations
-// (tests/test_oracle_optimizer.py, tests/test_hip_optimizer.py).
+// redundantly on all 64 lanes; v2 shared a wave between 16 envs and searched 64 step lengths (ratio sqrt 2) with the
+// whole wave - 90 % of its instructions were the line search; v3 (round 2-3): 16-step ladder of ratio 4, four envs per
+// pass, steepest descent only, MPC with a diagonal R1 only.  v4 (round 4): every mode and structure, and the curvature
+// pairs - steepest descent stalls 3-14 % above SLSQP's cost on the reference's critic-mode ticks (fixtures F8c: the
+// terminal action of RQL carries 1e4 times the curvature of the others), four pairs reach it within 0.5 % in 20
+// iterations (tests/test_oracle_optimizer.py, tests/test_hip_optimizer.py).
 #pragma once
 #include "rcg_kernels.hpp"
 
@@ -27,6 +34,7 @@ namespace rcg {
 constexpr int OPT_G = 16;   // envs per wave
 constexpr int OPT_NA = 16;  // step lengths tried per env and iteration = lanes of one DPP row
 constexpr int OPT_EP = 64 / OPT_NA;  // envs per line-search pass
+constexpr int OPT_MAXM = 8;  // most curvature pairs an env may keep (rcg_set_optimizer)
 
 // argmin over a row of 16 lanes of (cost, index): lower cost wins, ties -> lower index; every lane of the row ends with
 // the row's winner
@@ -63,6 +71,7 @@ struct OptArgs {
   const real* obs;        // [dy][B]
   const real* state_sys;  // [ds][B]
   const real* pars_env;   // [np][B] or nullptr
+  const real* w;          // [dc][B] critic weights (RQL / SQL) or nullptr
   const real* u_init;     // [B][N][du] or nullptr (-> u0 tiled over the horizon)
   real* u_opt;            // [B][N][du] or nullptr
   real* action_out;       // [du][B] or nullptr
@@ -73,6 +82,8 @@ struct OptArgs {
   real u0[RCG_MAX_DU];    // action_sqn_init entry (controllers.py:973-978)
   int iters;
   int shift;              // warm start: u_init is last tick's optimum, shift it by one step (last entry repeated)
+  int memory;             // curvature pairs kept per env, 0 .. OPT_MAXM (0: projected steepest descent)
+  int dcw;                // critic weights staged in LDS per env (dc for RQL / SQL, else 0)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -80,12 +91,102 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// reals of LDS one wave needs (host and device agree through this one function)
-__host__ __device__ constexpr int opt_lds_reals(int N, int DS, int DU, int NP) {
-  return OPT_G * (2 * N * DU + N * DS + 2 * DS + (NP > 0 ? NP : 1)) + N;
+// reals of LDS one wave needs (host and device agree through this one function):
+// u [G][R] | d [G][R] | X [N*DS][G] | y0 [DS][G] | xs [DS][G] | pars [NPS][G] | w [DC][G] | g [R][G] | q [R][G] |
+// S [M][R][G] | Y [M][R][G] | gamma^k [N]
+__host__ __device__ constexpr int opt_lds_reals(int N, int DS, int DU, int NP, int DC, int M) {
+  return OPT_G * (2 * N * DU + N * DS + 2 * DS + (NP > 0 ? NP : 1) + DC + 2 * N * DU + 2 * M * N * DU) + N;
 }
 
-template <typename Sys, typename real, bool TGT>
+// gk * d rho / d chi of stage_obj (controllers.py:1076-1082): quadratic chi R1 chi -> (R1 + R1^T) chi;
+// biquadratic adds chi^2 R2 chi^2 -> 2 chi * ((R2 + R2^T) chi^2)
+template <int NCHI, typename real>
+__device__ __forceinline__ void stage_grad_with(const KParams<real>& P, const real* chi, const int sk, real gk, real* g) {
+  if (!(sk & STAGE_FULL)) {
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) g[i] = ((real)2 * P.R1d[i]) * chi[i];
+    if (sk & STAGE_BIQUAD) {
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) g[i] = fma_r((real)4 * P.R2d[i] * (chi[i] * chi[i]), chi[i], g[i]);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < NCHI; ++p) {
+      real v = 0;
+#pragma unroll
+      for (int j = 0; j < NCHI; ++j) v = fma_r(P.Rfull[p * NCHI + j] + P.Rfull[j * NCHI + p], chi[j], v);
+      g[p] = v;
+    }
+    if (sk & STAGE_BIQUAD) {
+      real c2[NCHI];
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) c2[i] = chi[i] * chi[i];
+#pragma unroll
+      for (int p = 0; p < NCHI; ++p) {
+        real v = 0;
+#pragma unroll
+        for (int j = 0; j < NCHI; ++j) v = fma_r(P.Rfull[49 + p * NCHI + j] + P.Rfull[49 + j * NCHI + p], c2[j], v);
+        g[p] = fma_r((real)2 * chi[p], v, g[p]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCHI; ++i) g[i] *= gk;
+}
+
+// (d Q / d y, d Q / d u) of _critic = w . phi (controllers.py:1192-1214); chi = [y - target, u] so d chi / d y = I;
+// quad-mix works on the raw observation (controllers.py:1212).  Feature order = critic_with's.
+template <int DS, int DU, typename real, typename WGet>
+__device__ __forceinline__ void critic_grad_with(const real* chi, const real* y, const real* u, WGet w, const int cs,
+                                                 real* gy, real* gu) {
+  constexpr int NCHI = DS + DU;
+  if (cs == RCG_CRITIC_QUAD_MIX) {
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      real v = ((real)2 * w(i)) * y[i];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) v = fma_r(w(DS + i * DU + c), u[c], v);
+      gy[i] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < DU; ++c) {
+      real v = ((real)2 * w(DS + DS * DU + c)) * u[c];
+#pragma unroll
+      for (int i = 0; i < DS; ++i) v = fma_r(w(DS + i * DU + c), y[i], v);
+      gu[c] = v;
+    }
+    return;
+  }
+  real g[NCHI];
+  if (cs == RCG_CRITIC_QUAD_NOMIX) {
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) g[i] = ((real)2 * w(i)) * chi[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i) g[i] = 0;
+    int idx = 0;  // uptria2vec order; the diagonal entry is added twice: 2 w_pp chi_p
+#pragma unroll
+    for (int i = 0; i < NCHI; ++i)
+#pragma unroll
+      for (int j = i; j < NCHI; ++j) {
+        const real wij = w(idx++);
+        g[i] = fma_r(wij, chi[j], g[i]);
+        g[j] = fma_r(wij, chi[i], g[j]);
+      }
+    if (cs == RCG_CRITIC_QUAD_LIN) {
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) g[i] += w(idx++);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DS; ++i) gy[i] = g[i];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) gu[c] = g[DS + c];
+}
+
+// GENERIC = false: MPC with a diagonal quadratic stage cost (every preset in its default mode); true: the rest, mode and
+// structures read from KParams (wave-uniform branches)
+template <typename Sys, typename real, bool TGT, bool GENERIC>
 __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP, NPS = NP > 0 ? NP : 1, G = OPT_G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -97,14 +198,19 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
   if (b0 >= B) return;
   const int ng = (int)((B - b0) < G ? (B - b0) : G);  // envs of this wave (wave-uniform)
   const int N = P.n_actor, R = N * DU;
-  // per-wave LDS: u [G][R] | d [G][R] | X [N*DS][G] | y0 [DS][G] | xs [DS][G] | pars [NPS][G]
-  real* const su = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * opt_lds_reals(N, DS, DU, NP);
+  const int M = A.memory, DCW = A.dcw;
+  real* const su = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * opt_lds_reals(N, DS, DU, NP, DCW, M);
   real* const sd = su + G * R;
   real* const sX = sd + G * R;
   real* const sY = sX + N * DS * G;
   real* const sS = sY + DS * G;
   real* const sP = sS + DS * G;
-  real* const sg = sP + NPS * G;  // gamma^k, k < N, formed as the forward sum forms it (gk = 1; gk *= gamma)
+  real* const sW = sP + NPS * G;    // critic weights [DCW][G]
+  real* const sGc = sW + DCW * G;   // current gradient [R][G]
+  real* const sQ = sGc + R * G;     // two-loop work vector [R][G]
+  real* const sLS = sQ + R * G;     // pairs: s [M][R][G]
+  real* const sLY = sLS + M * R * G;  //        y [M][R][G]
+  real* const sg = sLY + M * R * G;  // gamma^k, k < N, formed as the forward sum forms it (gk = 1; gk *= gamma)
 
   const bool mine = lane < ng;       // lane == env view
   const long be = b0 + (mine ? lane : 0);
@@ -131,6 +237,8 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) sP[i * G + lane] = pve[i];
+    if (GENERIC)
+      for (int i = 0; i < DCW; ++i) sW[i * G + lane] = A.w[(long)i * B + be];
   }
 
   // initial sequences -> LDS, direction zero until the first gradient
@@ -157,9 +265,11 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
   wave_lds_sync();
 
   const bool g1 = P.gamma == (real)1;
-  // _actor_cost of clip(u_e - alpha d_e) from the state (y0, xs, pre): controllers.py:1284-1306
+  const int mode = GENERIC ? P.mode : (int)RCG_MODE_MPC, sk = GENERIC ? P.stage_kind : 0, cs = P.critic_struct;
+  // _actor_cost of clip(u_e - alpha d_e) from the state (y0, xs, pre): controllers.py:1284-1326; `wg(i)`: weight i of
+  // the env the caller stands for
   auto cost_of = [&](const real* ue, const real* de, const real* y0, const real* xs,
-                     const typename Sys::template Pre<real>& pre, real alpha) -> real {
+                     const typename Sys::template Pre<real>& pre, real alpha, auto wg) -> real {
     real x[DS], y[DS], up[DU];
 #pragma unroll
     for (int c = 0; c < DS; ++c) {
@@ -169,7 +279,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
 #pragma unroll
     for (int c = 0; c < DU; ++c) up[c] = 0;
     real J = 0;
-    real S[NCHI];  // gamma == 1: per-component sums of squares, weighted once at the end (as the rollout kernels)
+    real S[NCHI];  // MPC, diagonal, gamma == 1: per-component sums of squares, weighted once at the end
 #pragma unroll
     for (int i = 0; i < NCHI; ++i) S[i] = 0;
     for (int k = 0; k < N; ++k) {
@@ -178,7 +288,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
       for (int c = 0; c < DU; ++c) u[c] = clamp_r<real>(fma_r(-alpha, de[k * DU + c], ue[k * DU + c]), P.lo[c], P.hi[c]);
       if (k > 0) {
         real d[DS];
-        // f32: hardware v_sin/v_cos behind the exact reduction, as in every f32 rollout of the build (the 64 trial
+        // f32: hardware v_sin/v_cos behind the exact reduction, as in every f32 rollout of the build (the trial
         // rollouts of the line search are where this kernel spends its instructions)
         Sys::template rhs<real, true>(pre, x, up, d);
 #pragma unroll
@@ -189,33 +299,43 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
       }
       real chi[NCHI];
       make_chi<DS, DU, TGT, real>(P, y, u, chi);
-      if (g1) {  // wave-uniform
+      if (!GENERIC) {
+        if (g1) {  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
+          for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
+        } else {
+          J = fma_r(sg[k], stage_diag<NCHI, real>(P, chi), J);
+        }
+      } else if (mode == RCG_MODE_SQL || (mode == RCG_MODE_RQL && k == N - 1)) {  // wave-uniform
+        J += critic_with<DS, DU, real>(chi, y, u, wg, cs);
       } else {
-        J = fma_r(sg[k], stage_diag<NCHI, real>(P, chi), J);
+        J = fma_r(sg[k], stage_with<NCHI, real>(P, chi, sk), J);
       }
 #pragma unroll
       for (int c = 0; c < DU; ++c) up[c] = u[c];
     }
-    if (g1) {
+    if (!GENERIC && g1) {
 #pragma unroll
       for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[i], J);
     }
     return J;
   };
+  auto w_mine = [&](int i) -> real { return sW[i * G + lane]; };
 
   // lane == env registers
-  real Jinc = mine ? cost_of(su + lane * R, sd + lane * R, y0e, xse, pre_e, (real)0) : (real)0;
+  real Jinc = mine ? cost_of(su + lane * R, sd + lane * R, y0e, xse, pre_e, (real)0, w_mine) : (real)0;
   int used = 0;
   bool active = mine;
   real gn = 0;
+  bool quasi = false, pending = false;  // this iteration's direction is quasi-Newton; a pair waits for its y
+  int head = 0, n_pairs = 0;            // ring of curvature pairs: next slot, pairs held
   const int row = lane >> 4, tl = lane & (OPT_NA - 1);                    // row of 16 lanes = one env of the pass, trial
-  const real ladder = (real)exp2((double)2 - 2.0 * (double)tl);          // alpha_l * gn = 4^(1 - l)
+  const real ladder_sd = (real)exp2((double)2 - 2.0 * (double)tl);       // alpha_l * gn = 4^(1 - l)
+  const real ladder_qn = (real)exp2((double)2 - (double)tl);             // alpha_l = 2^(2 - l)
 
   for (int it = 0; it < A.iters; ++it) {
     if (__builtin_amdgcn_readfirstlane((int)__builtin_popcountll(__ballot(active))) == 0) break;
-    // ---- 1. lane == env: forward rollout (states to LDS), reverse adjoint sweep (direction to LDS) --------
+    // ---- 1. lane == env: forward rollout (states to LDS), reverse adjoint sweep, direction to LDS ---------
     if (active) {
       const real* ue = su + lane * R;
       real x[DS];
@@ -226,7 +346,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
 #pragma unroll
         for (int c = 0; c < DU; ++c) u[c] = ue[(k - 1) * DU + c];
         // f32: the hardware-trig rollout every cost evaluation of this kernel uses, so that the gradient is the gradient
-        // of the function the line search evaluates (and a third of phase 1's instructions go away)
+        // of the function the line search evaluates
         Sys::template rhs<real, true>(pre_e, x, u, d);
 #pragma unroll
         for (int c = 0; c < DS; ++c) {
@@ -234,20 +354,37 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
           sX[(k * DS + c) * G + lane] = x[c];
         }
       }
-      gn = 0;
       real lam[DS];
 #pragma unroll
       for (int c = 0; c < DS; ++c) lam[c] = 0;
       for (int k = N - 1; k >= 0; --k) {
         const real gk = sg[k];
-        real u[DU], xk[DS], g[DU];
+        real u[DU], xk[DS], g[DU], gy[DS];
 #pragma unroll
-        for (int c = 0; c < DU; ++c) {
-          u[c] = ue[k * DU + c];
-          g[c] = gk * (real)2 * P.R1d[DS + c] * u[c];
-        }
+        for (int c = 0; c < DU; ++c) u[c] = ue[k * DU + c];
 #pragma unroll
         for (int c = 0; c < DS; ++c) xk[c] = (k >= 1) ? sX[(k * DS + c) * G + lane] : xse[c];
+        if (!GENERIC) {
+#pragma unroll
+          for (int c = 0; c < DU; ++c) g[c] = gk * (real)2 * P.R1d[DS + c] * u[c];
+#pragma unroll
+          for (int c = 0; c < DS; ++c) gy[c] = gk * (real)2 * P.R1d[c] * (TGT ? xk[c] - P.target[c] : xk[c]);
+        } else {
+          real yk[DS], chi[NCHI];
+#pragma unroll
+          for (int c = 0; c < DS; ++c) yk[c] = (k >= 1) ? xk[c] : y0e[c];  // y_0 is the observation
+          make_chi<DS, DU, TGT, real>(P, yk, u, chi);
+          if (mode == RCG_MODE_SQL || (mode == RCG_MODE_RQL && k == N - 1)) {  // wave-uniform
+            critic_grad_with<DS, DU, real>(chi, yk, u, w_mine, cs, gy, g);
+          } else {
+            real gc[NCHI];
+            stage_grad_with<NCHI, real>(P, chi, sk, gk, gc);
+#pragma unroll
+            for (int c = 0; c < DS; ++c) gy[c] = gc[c];
+#pragma unroll
+            for (int c = 0; c < DU; ++c) g[c] = gc[DS + c];
+          }
+        }
         real lamk[DS];
         if (k < N - 1) {
           real ax[DS], bu[DU];
@@ -262,18 +399,98 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
         }
         if (k >= 1) {  // y_0 is the observation, not a function of the actions
 #pragma unroll
-          for (int c = 0; c < DS; ++c)
-            lamk[c] += gk * (real)2 * P.R1d[c] * (TGT ? xk[c] - P.target[c] : xk[c]);
+          for (int c = 0; c < DS; ++c) lamk[c] += gy[c];
         }
 #pragma unroll
         for (int c = 0; c < DS; ++c) lam[c] = lamk[c];
 #pragma unroll
-        for (int c = 0; c < DU; ++c) {
-          const real dc = g[c] * w2[c];
-          sd[lane * R + k * DU + c] = dc;
-          const real m = (dc < 0 ? -dc : dc) / w[c];
-          gn = m > gn ? m : gn;
+        for (int c = 0; c < DU; ++c) sGc[(k * DU + c) * G + lane] = g[c];
+      }
+      // the pair of the last accepted step: its slot holds the gradient at the step's start point
+      if (pending) {
+        for (int i = 0; i < R; ++i) {
+          real* const yp = sLY + ((size_t)head * R + i) * G + lane;
+          *yp = sGc[i * G + lane] - *yp;
         }
+        head = head + 1 == M ? 0 : head + 1;
+        n_pairs = n_pairs + 1 < M ? n_pairs + 1 : M;
+        pending = false;
+      }
+      // free set: a coordinate on a bound whose descent direction leaves the box is held
+      unsigned long long fm = 0ull;
+      for (int i = 0; i < R; ++i) {
+        const int c = i % DU;
+        const real ui = ue[i], gi = sGc[i * G + lane];
+        const bool held = (ui <= P.lo[c] && gi > (real)0) || (ui >= P.hi[c] && gi < (real)0);
+        if (!held) fm |= 1ull << i;
+      }
+      quasi = n_pairs > 0;
+      if (quasi) {  // L-BFGS two-loop recursion over the pairs restricted to the free set
+        for (int i = 0; i < R; ++i) sQ[i * G + lane] = ((fm >> i) & 1ull) ? sGc[i * G + lane] : (real)0;
+        real a_t[OPT_MAXM], sy_t[OPT_MAXM];
+        unsigned okm = 0u;
+        real scale = 1;
+#pragma unroll
+        for (int t = 0; t < OPT_MAXM; ++t) {  // newest -> oldest
+          a_t[t] = 0;
+          sy_t[t] = 1;
+          if (t < n_pairs) {
+            int j = head - 1 - t;
+            if (j < 0) j += M;
+            const real* const Sj = sLS + (size_t)j * R * G + lane;
+            const real* const Yj = sLY + (size_t)j * R * G + lane;
+            real sy = 0, ss = 0, yy = 0, sq = 0, yhy = 0;
+            for (int i = 0; i < R; ++i)
+              if ((fm >> i) & 1ull) {
+                const real s = Sj[i * G], y = Yj[i * G];
+                sy = fma_r(s, y, sy);
+                ss = fma_r(s, s, ss);
+                yy = fma_r(y, y, yy);
+                sq = fma_r(s, sQ[i * G + lane], sq);
+                yhy = fma_r(y * w2[i % DU], y, yhy);
+              }
+            const bool ok = sy > (real)0 && sy * sy > (real)1e-24 * (ss * yy);
+            if (t == 0 && ok && yhy > (real)0) scale = sy / yhy;
+            sy_t[t] = sy;
+            if (ok) {
+              okm |= 1u << t;
+              const real a = sq / sy;
+              a_t[t] = a;
+              for (int i = 0; i < R; ++i)
+                if ((fm >> i) & 1ull) sQ[i * G + lane] = fma_r(-a, Yj[i * G], sQ[i * G + lane]);
+            }
+          }
+        }
+        for (int i = 0; i < R; ++i) sQ[i * G + lane] = (scale * w2[i % DU]) * sQ[i * G + lane];
+#pragma unroll
+        for (int t = OPT_MAXM - 1; t >= 0; --t) {  // oldest -> newest
+          if (t < n_pairs && ((okm >> t) & 1u)) {
+            int j = head - 1 - t;
+            if (j < 0) j += M;
+            const real* const Sj = sLS + (size_t)j * R * G + lane;
+            const real* const Yj = sLY + (size_t)j * R * G + lane;
+            real yr = 0;
+            for (int i = 0; i < R; ++i)
+              if ((fm >> i) & 1ull) yr = fma_r(Yj[i * G], sQ[i * G + lane], yr);
+            const real cf = a_t[t] - yr / sy_t[t];
+            for (int i = 0; i < R; ++i)
+              if ((fm >> i) & 1ull) sQ[i * G + lane] = fma_r(Sj[i * G], cf, sQ[i * G + lane]);
+          }
+        }
+        real dg = 0;
+        for (int i = 0; i < R; ++i) dg = fma_r(sQ[i * G + lane], sGc[i * G + lane], dg);
+        if (!(dg > (real)0) || !finite_r<real>(dg)) {  // not a descent direction: drop the memory
+          quasi = false;
+          n_pairs = 0;
+        }
+      }
+      gn = 0;
+      for (int i = 0; i < R; ++i) {
+        const int c = i % DU;
+        const real dc = quasi ? sQ[i * G + lane] : (((fm >> i) & 1ull) ? sGc[i * G + lane] * w2[c] : (real)0);
+        sd[lane * R + i] = dc;
+        const real m = (dc < 0 ? -dc : dc) / w[c];
+        gn = m > gn ? m : gn;
       }
       if (!(gn > (real)0) || !finite_r<real>(gn)) active = false;
     }
@@ -288,6 +505,8 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
       const int es = on ? e : e0;                             // idle rows read a valid slot, their result is dropped
       const real gn_e = __shfl(gn, es, 64);
       const real Jinc_e = __shfl(Jinc, es, 64);
+      const int quasi_e = __shfl((int)quasi, es, 64);
+      const int head_e = __shfl(head, es, 64);
       real y0[DS], xs[DS], pv[NPS];
 #pragma unroll
       for (int c = 0; c < DS; ++c) {
@@ -299,22 +518,28 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
       const auto pre = Sys::template prepare<real>(pv);
       real* const ue = su + es * R;
       const real* const de = sd + es * R;
-      const real alpha = ((real)1 / gn_e) * ladder;
+      const real alpha = quasi_e ? ladder_qn : ((real)1 / gn_e) * ladder_sd;
       real bj = inf_r<real>();
       if (on) {
-        const real J = cost_of(ue, de, y0, xs, pre, alpha);
+        const real J = cost_of(ue, de, y0, xs, pre, alpha, [&](int i) -> real { return sW[i * G + es]; });
         bj = (J != J) ? inf_r<real>() : J;
       }
       int bi = tl;
       row16_argmin(bj, bi);
       const bool better = on && (bj < Jinc_e);  // row-uniform
-      // accept: u_e <- clip(u_e - alpha_best d_e); otherwise env e is done
-      const real abest = ((real)1 / gn_e) * (real)exp2((double)2 - 2.0 * (double)bi);
+      // accept: u_e <- clip(u_e - alpha_best d_e); otherwise env e drops its memory or is done
+      const real abest = quasi_e ? (real)exp2((double)2 - (double)bi) : ((real)1 / gn_e) * (real)exp2((double)2 - 2.0 * (double)bi);
       wave_lds_sync();  // every lane has finished reading its u_e
       if (better) {
         for (int i = tl; i < R; i += OPT_NA) {
           const int c = i % DU;
-          ue[i] = clamp_r<real>(fma_r(-abest, de[i], ue[i]), P.lo[c], P.hi[c]);
+          const real uo = ue[i];
+          const real un = clamp_r<real>(fma_r(-abest, de[i], uo), P.lo[c], P.hi[c]);
+          ue[i] = un;
+          if (M > 0) {  // open the pair of this step: s now, y = (next gradient) - (this gradient) in phase 1
+            sLS[((size_t)head_e * R + i) * G + es] = un - uo;
+            sLY[((size_t)head_e * R + i) * G + es] = sGc[i * G + es];
+          }
         }
       }
       // hand the rows' results to the env-view lanes (env e0 + r lives in lane e0 + r; its row is lanes 16 r ...)
@@ -327,6 +552,9 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
         if (better_me) {
           Jinc = bj_me;
           ++used;
+          pending = M > 0;
+        } else if (quasi) {
+          n_pairs = 0;  // retry from the same point with steepest descent
         } else {
           active = false;
         }
@@ -346,11 +574,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
     }
     if (A.best_J) A.best_J[be] = Jinc;
     if (A.n_iter) A.n_iter[be] = used;
-    if (A.accum) {
-      real chi[NCHI];
-      make_chi<DS, DU, TGT, real>(P, y0e, a, chi);
-      A.accum[be] += stage_diag<NCHI, real>(P, chi) * P.sampling_time;
-    }
+    if (A.accum) A.accum[be] = accum_update<Sys, TGT, real>(P, y0e, a, A.accum[be]);
     if (A.step_idx) A.step_idx[be] += 1;
   }
 }

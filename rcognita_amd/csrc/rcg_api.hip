@@ -9,6 +9,7 @@
 
 #include "rcg_disturb.hpp"
 #include "rcg_handle.hpp"
+#include "rcg_search.hpp"
 
 using namespace rcg;
 
@@ -206,6 +207,7 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->prof_stride = 1;
   memset(h->prof_seen, 0, sizeof h->prof_seen);
   h->tick_count = 0;
+  h->opt_memory = 4;
   h->cur_a = h->cur_b = nullptr;
   h->order_ev = nullptr;
   memset(h->last, 0, sizeof h->last);
@@ -570,6 +572,26 @@ static int check_candidates(rcg_handle* h, const char* who, const void* cand, in
   return RCG_OK;
 }
 
+// RQL / SQL bookkeeping of one tick, between the env step and the decision (controllers.py:1458-1477): env step + buffer
+// push + critic fit.  critic_period = critic_every_ticks * sampling_time: the reference starts critic_clock at t0 and refits
+// when t - critic_clock >= critic_period; tick j of an episode happens at t0 + (j+1)*dt, so the fits fall on ticks every-1,
+// 2*every-1, ...
+static int tick_critic_phase(rcg_handle* h, const char* who) {
+  if (h->cfg.n_critic - 1 > kFitMaxRows)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "%s: the native critic fit needs Ncritic-1 <= %d (got %d)", who, kFitMaxRows,
+                    h->cfg.n_critic - 1);
+  const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
+  const bool do_fit = ((h->tick_count + 1) % every) == 0;
+  const int m = h->cfg.n_critic - 1;
+  if ((h->cfg.flags & RCG_FLAG_DISTURB) || (do_fit && m < 1)) {  // the disturbed env step has its own kernel
+    const int rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
+    if (rc) return rc;
+    return rcg_critic_update(h, do_fit ? 1 : 0);
+  }
+  // env step + buffer push + fit: one launch (rcg_critic_fit.hpp)
+  return h->sys->critic_update(h, h->cfg.substeps_per_tick, 1, do_fit ? 1 : 0);
+}
+
 int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
   DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
@@ -577,22 +599,7 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
   if (rc) return rc;
   bool sim_first = true;  // MPC: env step, then the decision, both issued by the actor launcher
   if (h->cfg.mode != RCG_MODE_MPC) {  // RQL/SQL: the critic bookkeeping sits between the two
-    if (h->cfg.n_critic - 1 > kFitMaxRows)
-      return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick: the native critic fit needs Ncritic-1 <= %d (got %d)",
-                      kFitMaxRows, h->cfg.n_critic - 1);
-    // critic_period = critic_every_ticks * sampling_time.  The reference starts critic_clock at t0 and refits when
-    // t - critic_clock >= critic_period (controllers.py:1458-1471); tick j of an episode happens at t0 + (j+1)*dt, so
-    // the fits fall on ticks every-1, 2*every-1, ...
-    const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
-    const bool do_fit = ((h->tick_count + 1) % every) == 0;
-    const int m = h->cfg.n_critic - 1;
-    if ((h->cfg.flags & RCG_FLAG_DISTURB) || (do_fit && m < 1)) {  // the disturbed env step has its own kernel
-      rc = h->sys->sim_step(h, h->cfg.substeps_per_tick);
-      if (rc) return rc;
-      rc = rcg_critic_update(h, do_fit ? 1 : 0);
-    } else {  // env step + buffer push + fit: one launch (rcg_critic_fit.hpp)
-      rc = h->sys->critic_update(h, h->cfg.substeps_per_tick, 1, do_fit ? 1 : 0);
-    }
+    rc = tick_critic_phase(h, "rcg_control_tick");
     if (rc) return rc;
     sim_first = false;
   }
@@ -630,25 +637,116 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K) {
   return rc;
 }
 
+int rcg_set_optimizer(rcg_handle* h, int32_t memory) {
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (memory < 0 || memory > OPT_MAXM)
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_optimizer: memory must be in [0, %d]", OPT_MAXM);
+  h->opt_memory = memory;
+  return RCG_OK;
+}
+
+// refusals of the optimiser that depend on the handle's shape, made before a tick mutates anything
+static int check_optimizer(rcg_handle* h, const char* who) {
+  if (h->cfg.mode != RCG_MODE_MPC && !h->f[RCG_FIELD_W_CRITIC])
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: RQL/SQL need critic weights (buffer_size > 0)", who);
+  const size_t lds = opt_wave_lds_bytes(h);
+  if (lds > (size_t)160 * 1024)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "%s: horizon %d with %d curvature pairs needs %zu B of LDS per wave (rcg_set_optimizer)",
+                    who, h->cfg.n_actor, h->opt_memory, lds);
+  return RCG_OK;
+}
+
 int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
                        void* u_opt, void* action, void* best_J, int32_t* n_iter) {
   DeviceGuard dev_guard(h);
   if (!h || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_actor_optimize: iters must be >= 0");
-  return h->sys->optimize(h, iters, obs, state_sys, u_init, 0, u_opt, action, best_J, n_iter, false);
+  const int rc = check_optimizer(h, "rcg_actor_optimize");
+  if (rc) return rc;
+  return h->sys->optimize(h, iters, obs, state_sys, u_init, 0, u_opt, action, best_J, n_iter, false, false);
 }
 
 int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start) {
   DeviceGuard dev_guard(h);
   if (!h || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_tick_opt: iters must be >= 0");
-  if (h->cfg.mode != RCG_MODE_MPC)
-    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_opt: MPC only (RQL/SQL use rcg_control_tick)");
-  // (the env step of the tick is issued by the optimiser's launcher, after its argument checks)
+  int rc = check_optimizer(h, "rcg_control_tick_opt");
+  if (rc) return rc;
+  bool sim_first = true;  // MPC: the env step of the tick is issued by the optimiser's launcher
+  if (h->cfg.mode != RCG_MODE_MPC) {  // RQL/SQL: env step + buffer push + critic fit come first (one launch)
+    rc = tick_critic_phase(h, "rcg_control_tick_opt");
+    if (rc) return rc;
+    sim_first = false;
+  }
   const bool warm = warm_start && h->tick_count > 0;  // nothing to shift before the episode's first decision
   void* sqn = h->f[RCG_FIELD_ACTION_SQN];
-  const int rc = h->sys->optimize(h, iters, nullptr, nullptr, warm ? sqn : nullptr, warm ? 1 : 0, sqn,
-                                  h->f[RCG_FIELD_ACTION], h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true);
+  rc = h->sys->optimize(h, iters, nullptr, nullptr, warm ? sqn : nullptr, warm ? 1 : 0, sqn, h->f[RCG_FIELD_ACTION],
+                        h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, sim_first);
   if (rc == RCG_OK) h->tick_count += 1;
   return rc;
+}
+
+static int check_search(rcg_handle* h, const char* who, int32_t K, int32_t rounds) {
+  if (K < 64) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: K must be >= 64 (a wave evaluates 64 candidates at a time)", who);
+  if (rounds < 1 || rounds > 64) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: rounds must be in [1, 64]", who);
+  if (h->cfg.mode != RCG_MODE_MPC && !h->f[RCG_FIELD_W_CRITIC])
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: RQL/SQL need critic weights (buffer_size > 0)", who);
+  return RCG_OK;
+}
+
+int rcg_actor_search(rcg_handle* h, int32_t K, int32_t rounds, const void* obs, const void* state_sys, const void* centre,
+                     void* u_best, void* action, void* best_J, int32_t* best_idx) {
+  DeviceGuard dev_guard(h);
+  if (!h) return RCG_ERR_BAD_ARG;
+  const int rc = check_search(h, "rcg_actor_search", K, rounds);
+  if (rc) return rc;
+  return h->sys->search(h, K, rounds, 0, obs, state_sys, centre, 0, u_best, action, best_J, best_idx, false, false);
+}
+
+int rcg_control_tick_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t warm_start) {
+  DeviceGuard dev_guard(h);
+  if (!h) return RCG_ERR_BAD_ARG;
+  int rc = check_search(h, "rcg_control_tick_search", K, rounds);
+  if (rc) return rc;
+  bool sim_first = true;
+  if (h->cfg.mode != RCG_MODE_MPC) {
+    rc = tick_critic_phase(h, "rcg_control_tick_search");
+    if (rc) return rc;
+    sim_first = false;
+  }
+  const bool warm = warm_start && h->tick_count > 0;
+  void* sqn = h->f[RCG_FIELD_ACTION_SQN];
+  rc = h->sys->search(h, K, rounds, 0, nullptr, nullptr, warm ? sqn : nullptr, warm ? 1 : 0, sqn, h->f[RCG_FIELD_ACTION],
+                      h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, sim_first);
+  if (rc == RCG_OK) h->tick_count += 1;
+  return rc;
+}
+
+int rcg_candidates_sample(rcg_handle* h, void* cand, int32_t K, int32_t round, const void* centre) {
+  DeviceGuard dev_guard(h);
+  if (!h || !cand) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_candidates_sample: cand is required");
+  if (K < 1 || round < 0 || round > 63) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_candidates_sample: need K >= 1 and 0 <= round <= 63");
+  const long rows = (long)h->cfg.batch * K;
+  const int R = h->cfg.n_actor * h->du;
+  const int32_t* ep = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
+  const int32_t* st = (const int32_t*)h->f[RCG_FIELD_STEP_IDX];
+  const dim3 grid(blocks_for(rows)), block(256);
+#define RCG_SAMPLE(DU, real, P)                                                                                          \
+  hipLaunchKernelGGL((k_cand_sample<DU, real>), grid, block, 0, h->stream, (real*)cand, (const real*)centre, ep, st, (int)K, \
+                     (int)round, R, (uint64_t)h->cfg.seed, (int64_t)h->cfg.env_id_base, (real)h->cfg.action_init[0],     \
+                     (real)h->cfg.action_init[1], P)
+  if (h->cfg.dtype == RCG_F64) {
+    if (h->du == 1)
+      RCG_SAMPLE(1, double, h->p64);
+    else
+      RCG_SAMPLE(2, double, h->p64);
+  } else {
+    if (h->du == 1)
+      RCG_SAMPLE(1, float, h->p32);
+    else
+      RCG_SAMPLE(2, float, h->p32);
+  }
+#undef RCG_SAMPLE
+  HIPCHK(h, hipGetLastError());
+  return RCG_OK;
 }
 
 int rcg_nominal_action(rcg_handle* h, const void* obs, void* action, void* lyap, int32_t n, double ctrl_gain,
@@ -807,7 +905,7 @@ int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32
 const char* rcg_kernel_name(int32_t kernel_id) {
   static const char* const names[RCG_KID_COUNT_] = {"none",        "k_actor",   "k_actor_dma", "k_ticks",    "k_actor_opt",
                                                     "k_nominal",   "k_sim",     "k_sim_v",     "k_sim_dist", "k_critic_fit",
-                                                    "k_actor_dma_packed"};
+                                                    "k_actor_dma_packed", "k_actor_search"};
   return (kernel_id >= 0 && kernel_id < RCG_KID_COUNT_) ? names[kernel_id] : "?";
 }
 

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "rcg_actor_opt.hpp"
 #include "rcg_kernels.hpp"
 
 struct rcg_handle {
@@ -23,6 +24,7 @@ struct rcg_handle {
   size_t fbytes[RCG_FIELD_COUNT_];
   double* d_summary;
   long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
+  int opt_memory;   // curvature pairs of k_actor_opt (rcg_set_optimizer), default 4
   void* d_const;    // constant block in HBM, layout kConst* below
   rcg::KParams<float> p32;
   rcg::KParams<double> p64;
@@ -142,6 +144,13 @@ inline const rcg::KParams<double>& params<double>(const rcg_handle* h) {
   return h->p64;
 }
 
+// LDS bytes one wave of k_actor_opt needs for this handle (the launcher sizes its blocks with it; rcg_control_tick_opt
+// refuses a tick whose optimiser cannot be launched BEFORE it steps the env)
+static inline size_t opt_wave_lds_bytes(const rcg_handle* h) {
+  const int dcw = h->cfg.mode != RCG_MODE_MPC ? h->dc : 0;
+  return (size_t)rcg::opt_lds_reals(h->cfg.n_actor, h->ds, h->du, h->np, dcw, h->opt_memory) * h->esz;
+}
+
 static inline unsigned blocks_for(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 // Everything that depends on the system type, one table per environment (rcg_sys_*.hip).
@@ -156,11 +165,14 @@ struct SysVTable {
   // RQL / SQL bookkeeping between two decisions in ONE launch: [sim_step x n_substeps] -> [push] -> [fit]
   int (*critic_update)(rcg_handle*, int32_t n_substeps /* 0: no env step */, int32_t do_push, int32_t do_fit);
   int (*optimize)(rcg_handle*, int32_t iters, const void* obs, const void* state_sys, const void* u_init, int shift,
-                  void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick);
+                  void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick, bool sim_first);
   int (*nominal)(rcg_handle*, const void* obs, void* action, void* lyap, void* theta, int32_t n, double gain,
                  const double* ctrl_pars, int32_t clip, bool tick);
   int (*ticks)(rcg_handle*, int32_t T, int32_t K);
   int (*rhs_full)(rcg_handle*, const void* state, const void* disturb, const void* action, const void* xi, void* dstate,
                   void* ddisturb, void* clipped, int32_t n, int32_t clip);
+  int (*search)(rcg_handle*, int32_t K, int32_t rounds, int32_t round0, const void* obs, const void* state_sys,
+                const void* centre, int shift, void* u_best, void* action, void* best_J, int32_t* best_idx, bool tick,
+                bool sim_first);
 };
 extern const SysVTable kVt3WRobot, kVt3WRobotNI, kVt2Tank;

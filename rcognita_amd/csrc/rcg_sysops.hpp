@@ -13,6 +13,7 @@
 #include "rcg_disturb.hpp"
 #include "rcg_handle.hpp"
 #include "rcg_nominal.hpp"
+#include "rcg_search.hpp"
 
 namespace rcg {
 
@@ -200,7 +201,7 @@ static int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, 
 
 // Development knobs of the actor launcher.  They select between variants of the same computation for A/B measurements
 // (none changes results beyond rounding) and exist ONLY in -DRCG_DEV builds (`make dev`, librcg_dev.so, chosen by a tool
-// with RCG_LIB=...): the production library never reads the environment - its schedule is the one measured and shipped.
+// with rcognita_amd._native.use_library): the production library never reads the environment - its schedule is the one measured and shipped.
 //   RCG_ACTOR_KERNEL=plain  force k_actor instead of k_actor_dma      RCG_GPW=<n>  envs per persistent wave
 //   RCG_DBG=<bits>          1 skip the rollout, 2 skip argmin + writes, 4 skip env-state loads - timing only, wrong results
 //   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL / SQL on k_actor
@@ -457,14 +458,11 @@ static int op_actor(rcg_handle* h, const char* who, const void* cand, int K, con
 
 template <typename Sys>
 static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
-                       int shift, void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick) {
+                       int shift, void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick, bool sim_first) {
   const rcg_cfg& c = h->cfg;
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
     const KParams<real>& P = params<real>(h);
-    if (c.mode != RCG_MODE_MPC || P.stage_kind != 0)
-      return rcg_fail(h, RCG_ERR_UNSUPPORTED,
-                      "rcg_actor_optimize: the native optimiser covers MPC with a diagonal quadratic stage cost");
     OptArgs<real> A;
     memset(&A, 0, sizeof A);
     A.obs = obs ? (const real*)obs : (const real*)h->f[RCG_FIELD_STATE];
@@ -475,6 +473,9 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
     else
       A.state_sys = (const real*)h->f[(tick && (c.flags & RCG_FLAG_REF_LAG)) ? RCG_FIELD_STATE_PREV : RCG_FIELD_STATE];
     A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    A.w = (const real*)h->f[RCG_FIELD_W_CRITIC];
+    if (c.mode != RCG_MODE_MPC && !A.w)
+      return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_actor_optimize: RQL/SQL need critic weights (buffer_size > 0)");
     A.u_init = (const real*)u_init;
     A.u_opt = (real*)u_opt;
     A.action_out = (real*)action;
@@ -485,26 +486,103 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
     for (int i = 0; i < Sys::DU; ++i) A.u0[i] = (real)c.action_init[i];
     A.iters = iters;
     A.shift = shift;
-    const int N = c.n_actor;
-    const size_t lds = 4 * (size_t)opt_lds_reals(N, Sys::DS, Sys::DU, Sys::NP) * sizeof(real);  // 4 waves per block
-    if (lds > 160 * 1024)
-      return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_actor_optimize: horizon %d needs %zu B of LDS per block", N, lds);
-    const dim3 grid(blocks_for(c.batch, 4 * OPT_G)), block(256);  // a wave owns OPT_G envs
+    A.memory = h->opt_memory;
+    const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
+    A.dcw = c.mode != RCG_MODE_MPC ? h->dc : 0;
+    // waves per block: 4 (one per SIMD) while the block's LDS fits the CU's 160 KB, else 2 or 1 (long horizons in f64
+    // with curvature pairs: 3wrobot N = 20, f64, 4 pairs needs 70 KB per wave)
+    const size_t lds_wave = opt_wave_lds_bytes(h);
+    int wpb = 4;
+    while (wpb > 1 && lds_wave * wpb > (size_t)160 * 1024) wpb >>= 1;
+    const size_t lds = lds_wave * wpb;
+    if (lds > (size_t)160 * 1024)
+      return rcg_fail(h, RCG_ERR_UNSUPPORTED,
+                      "rcg_actor_optimize: horizon %d with %d curvature pairs needs %zu B of LDS per wave (rcg_set_optimizer)",
+                      c.n_actor, h->opt_memory, lds_wave);
+    const dim3 grid(blocks_for(c.batch, wpb * OPT_G)), block(64 * wpb);  // a wave owns OPT_G envs
     const bool tgt = c.flags & RCG_FLAG_HAS_TARGET;
-    if (tick) {  // rcg_control_tick_opt: the env step of the tick, once every argument check above has passed
+    if (tick && sim_first) {  // rcg_control_tick_opt (MPC): the env step of the tick, once every argument check has passed
       const int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
       if (rc) return rc;
     }
-    if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (the CU has 160 KB)
-      const void* fn = tgt ? (const void*)&k_actor_opt<Sys, real, true> : (const void*)&k_actor_opt<Sys, real, false>;
+    const void* fn = generic ? (tgt ? (const void*)&k_actor_opt<Sys, real, true, true> : (const void*)&k_actor_opt<Sys, real, false, true>)
+                             : (tgt ? (const void*)&k_actor_opt<Sys, real, true, false> : (const void*)&k_actor_opt<Sys, real, false, false>);
+    if (lds > 64 * 1024)  // beyond the default dynamic-LDS limit (the CU has 160 KB)
       HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+    if (generic && tgt)
+      RCG_LAUNCH(h, (k_actor_opt<Sys, real, true, true>), grid, block, lds, A, P);
+    else if (generic)
+      RCG_LAUNCH(h, (k_actor_opt<Sys, real, false, true>), grid, block, lds, A, P);
+    else if (tgt)
+      RCG_LAUNCH(h, (k_actor_opt<Sys, real, true, false>), grid, block, lds, A, P);
+    else
+      RCG_LAUNCH(h, (k_actor_opt<Sys, real, false, false>), grid, block, lds, A, P);
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_OPT, (generic ? 1 : 0) | (tgt ? 2 : 0), OPT_G);
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+// rcg_actor_search / rcg_control_tick_search: `rounds` rounds of K generated candidates per env, evaluated where they are
+// generated (k_actor_search, rcg_search.hpp).  The caller (rcg_api.hip) has checked K and the critic weights.
+template <typename Sys>
+static int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, const void* obs, const void* state_sys,
+                     const void* centre, int shift, void* u_best, void* action, void* best_J, int32_t* best_idx, bool tick,
+                     bool sim_first) {
+  const rcg_cfg& c = h->cfg;
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    const KParams<real>& P = params<real>(h);
+    SearchArgs<real> A;
+    memset(&A, 0, sizeof A);
+    A.obs = obs ? (const real*)obs : (const real*)h->f[RCG_FIELD_STATE];
+    if (state_sys)
+      A.state_sys = (const real*)state_sys;
+    else if (obs)
+      A.state_sys = (const real*)obs;
+    else
+      A.state_sys = (const real*)h->f[(tick && (c.flags & RCG_FLAG_REF_LAG)) ? RCG_FIELD_STATE_PREV : RCG_FIELD_STATE];
+    A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    A.w = (const real*)h->f[RCG_FIELD_W_CRITIC];
+    A.centre_in = (const real*)centre;
+    A.u_best = (real*)u_best;
+    A.action_out = (real*)action;
+    A.best_J = (real*)best_J;
+    A.best_idx = best_idx;
+    A.accum = (tick && !(c.flags & RCG_FLAG_ACCUM_EVERY_SUBSTEP)) ? (real*)h->f[RCG_FIELD_ACCUM] : nullptr;
+    A.step_rw = tick ? (int32_t*)h->f[RCG_FIELD_STEP_IDX] : nullptr;
+    A.episode_idx = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
+    A.step_idx = (const int32_t*)h->f[RCG_FIELD_STEP_IDX];
+    for (int i = 0; i < Sys::DU; ++i) A.u0[i] = (real)c.action_init[i];
+    A.K = K;
+    A.rounds = rounds;
+    A.round0 = round0;
+    A.shift = shift;
+    A.seed = c.seed;
+    A.env_id_base = c.env_id_base;
+    const int R = c.n_actor * Sys::DU;
+    int wpb = 4;  // waves (= envs) per workgroup
+    const size_t lds_wave = (size_t)search_lds_reals(R) * sizeof(real);
+    while (wpb > 1 && lds_wave * wpb > (size_t)64 * 1024) wpb >>= 1;
+    const size_t lds = lds_wave * wpb;
+    const dim3 grid(blocks_for(c.batch, wpb)), block(64 * wpb);
+    const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
+    const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
+    if (tick && sim_first) {
+      const int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
+      if (rc) return rc;
     }
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
-    if (tgt)
-      RCG_LAUNCH(h, (k_actor_opt<Sys, real, true>), grid, block, lds, A, P);
+    if (generic && tgt)
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, true, true>), grid, block, lds, A, P);
+    else if (generic)
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, true, false>), grid, block, lds, A, P);
+    else if (tgt)
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, true>), grid, block, lds, A, P);
     else
-      RCG_LAUNCH(h, (k_actor_opt<Sys, real, false>), grid, block, lds, A, P);
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_OPT, tgt ? 2 : 0, OPT_G);
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, false>), grid, block, lds, A, P);
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_SEARCH, (generic ? 1 : 0) | (tgt ? 2 : 0), 1);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
@@ -602,7 +680,7 @@ struct SysInstances {
   static SysVTable table() {
     return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,        &op_critic_cost<Sys>, &op_actor<Sys>,
                      &op_sim_step<Sys>, &op_critic_update<Sys>, &op_optimize<Sys>, &op_nominal<Sys>,
-                     &op_ticks<Sys>,  &op_rhs_full<Sys>};
+                     &op_ticks<Sys>,  &op_rhs_full<Sys>, &op_search<Sys>};
   }
 };
 

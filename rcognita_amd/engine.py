@@ -125,8 +125,9 @@ class EngineConfig:
                 q0 = np.asarray(self.disturb_init, dtype=np.float64).reshape(-1)
                 for k in range(dd):
                     c.disturb_init[k] = q0[k]
-            c.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
-            c.env_id_base = int(self.env_id_base)
+        # the counter-based generators (disturbance noise, candidate search) are keyed by (seed, global env id)
+        c.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
+        c.env_id_base = int(self.env_id_base)
         c.flags = flags
         return c
 
@@ -584,8 +585,9 @@ class Engine:
         N.check(N.lib().rcg_control_ticks(self._h, int(T), int(K)), self._h)
 
     def actor_optimize(self, iters=10, obs=None, state_sys=None, u_init=None):
-        """On-device actor optimiser (rcg_actor_optimize): adjoint gradient + 16-way projected line search.
-        ``u_init [B, N, du]`` (None: the reference's ``action_sqn_init``).  Returns
+        """On-device actor optimiser (rcg_actor_optimize), every mode and cost structure: adjoint gradient, limited-memory
+        quasi-Newton direction on the free coordinates, 16-way projected line search; RQL / SQL use the handle's
+        ``W_CRITIC``.  ``u_init [B, N, du]`` (None: the reference's ``action_sqn_init``).  Returns
         ``(action [B, du], u_opt [B, N, du], best_J [B], n_iter [B] int32)``."""
         keep = []
         u0 = None if u_init is None else np.broadcast_to(
@@ -599,8 +601,50 @@ class Engine:
         return act.T.copy(), uo, bj, ni
 
     def control_tick_opt(self, iters=10, warm_start=False):
-        """One env.control-step with the on-device optimiser as the decision (rcg_control_tick_opt)."""
+        """One env.control-step with the on-device optimiser as the decision (rcg_control_tick_opt); RQL / SQL: the
+        buffer push and the critic fit come between the env step and the decision, as in ``control_tick``."""
         N.check(N.lib().rcg_control_tick_opt(self._h, int(iters), 1 if warm_start else 0), self._h)
+
+    def actor_search(self, K=256, rounds=6, obs=None, state_sys=None, centre=None):
+        """Device-side candidate search (rcg_actor_search): ``rounds`` rounds of ``K`` candidates generated, evaluated and
+        refined in one launch; ``centre [B, N, du]`` (None: the reference's ``action_sqn_init``).  Returns
+        ``(action [B, du], u_best [B, N, du], best_J [B], best_idx [B] int32)``."""
+        keep = []
+        c0 = None if centre is None else np.broadcast_to(
+            np.asarray(centre, dtype=self.real).reshape(-1, self.N, self.du), (self.B, self.N, self.du))
+        pobs, pxs, pc = self._in_many([self._soa_item(obs, self.dy, "obs"), self._soa_item(state_sys, self.ds, "state_sys"),
+                                       (c0, None, None, "centre")], keep)
+        (pub, pact, pbj, pbi), fetch = self._out_many([((self.B, self.N, self.du), None), ((self.du, self.B), None),
+                                                       ((self.B,), None), ((self.B,), np.int32)])
+        N.check(N.lib().rcg_actor_search(self._h, int(K), int(rounds), pobs, pxs, pc, pub, pact, pbj, pbi), self._h)
+        ub, act, bj, bi = fetch()
+        return act.T.copy(), ub, bj, bi
+
+    def control_tick_search(self, K=256, rounds=6, warm_start=False):
+        """One env.control-step with the device-side candidate search as the decision (rcg_control_tick_search)."""
+        N.check(N.lib().rcg_control_tick_search(self._h, int(K), int(rounds), 1 if warm_start else 0), self._h)
+
+    def candidates_sample(self, K, round=0, centre=None, out=None):
+        """The candidate rows of one search round (rcg_candidates_sample) -> host ``[B, K, N, du]``, or, with ``out`` (a
+        DeviceArray / torch tensor of that shape), written there and left on the device."""
+        keep = []
+        c0 = None if centre is None else np.broadcast_to(
+            np.asarray(centre, dtype=self.real).reshape(-1, self.N, self.du), (self.B, self.N, self.du))
+        (pc,) = self._in_many([(c0, None, (self.B, self.N, self.du), "centre")], keep)
+        shape = (self.B, int(K), self.N, self.du)
+        if out is not None:
+            po = self._check_device_input(out, shape, self.real, "out")
+            N.check(N.lib().rcg_candidates_sample(self._h, po, int(K), int(round), pc), self._h)
+            if keep:
+                self.synchronize()
+            return out
+        d = self._tmp(shape)
+        N.check(N.lib().rcg_candidates_sample(self._h, C.c_void_p(d.ptr), int(K), int(round), pc), self._h)
+        return d.to_host()
+
+    def set_optimizer(self, memory=4):
+        """Curvature pairs the optimiser keeps per env (rcg_set_optimizer): 0 = projected steepest descent .. 8."""
+        N.check(N.lib().rcg_set_optimizer(self._h, int(memory)), self._h)
 
     @staticmethod
     def _ctrl_pars(ctrl_pars):

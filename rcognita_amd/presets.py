@@ -70,7 +70,8 @@ def build_parser(name: str) -> argparse.ArgumentParser:
     p.add_argument("--state_spread", type=float, default=0.5, help="uniform perturbation of state_init per env (batch>1)")
     p.add_argument("--n_candidates", type=int, default=256)
     p.add_argument("--rounds", type=int, default=6)
-    p.add_argument("--dtype", type=str, default="f32", choices=["f32", "f64"])
+    p.add_argument("--dtype", type=str, default="f64", choices=["f32", "f64"],
+                   help="element type of the device handles; the reference computes in float64")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--seed", type=int, default=0)
     return p

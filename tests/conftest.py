@@ -44,7 +44,7 @@ def golden():
 @pytest.fixture(autouse=True)
 def _gpu_tests_run_the_library_as_shipped(request):
     """The `-m gpu` parity claims are made for librcg.so as built and shipped: no RCG_* variable (the dev build's A/B
-    knobs, or RCG_LIB pointing at another library) may be set in the environment of a GPU test."""
+    knobs) may be set in the environment of a GPU test."""
     if request.node.get_closest_marker("gpu") is not None:
         bad = sorted(k for k in os.environ if k.startswith("RCG_"))
         assert not bad, f"GPU tests must run with a clean environment; unset {', '.join(bad)}"

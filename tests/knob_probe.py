@@ -11,7 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    from rcognita_amd import Engine, _native as N
+    from rcognita_amd import _native as N
+
+    if "--lib" in sys.argv:  # the -DRCG_DEV twin, selected by the caller in code (the binding reads no environment)
+        N.use_library(sys.argv[sys.argv.index("--lib") + 1])
+    from rcognita_amd import Engine
     from rcognita_amd.pool import preset_engine_config
 
     rng = np.random.default_rng(5)

@@ -89,3 +89,23 @@ def test_critic_fit_on_the_stacks_of_the_reference_loop(name, cs, mode):
     assert np.all(Jc <= z["tick_Jc_init"] * (1 + 1e-12) + 1e-12)
     lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
     assert np.all(w >= lo - 1e-12) and np.all(w <= hi + 1e-12)
+
+
+@pytest.mark.parametrize("key", ["2tank_RQL_quadratic", "3wrobotNI_SQL_quad-nomix", "3wrobot_RQL_quad-nomix"])
+def test_sensitivity_fixture_is_what_the_restated_loop_gives(key):
+    """tests/golden/F7c_sensitivity.json (oracle/gen_trace_sensitivity.py): how far the reference's own loop moves when only
+    SLSQP's stopping tolerance changes - the band tests/test_hip_ref_traces.py holds the HIP loop to.  Three entries are
+    recomputed here; the restated loop they come from reproduces every trace at the reference's tolerance (above)."""
+    import json
+    import os
+
+    from oracle.gen_trace_sensitivity import sensitivity
+    from tests.conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, "F7c_sensitivity.json")) as f:
+        fx = json.load(f)
+    name, mode, cs = key.split("_")
+    s = sensitivity(name, mode, cs)
+    assert abs(s["accum_window"] - fx["traces"][key]["accum_window"]) < 1e-6 * abs(s["accum_window"])
+    np.testing.assert_allclose(s["rel_change"], fx["traces"][key]["rel_change"], rtol=1e-3, atol=1e-5)
+    assert len(fx["traces"]) == 12

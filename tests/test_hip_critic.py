@@ -166,3 +166,36 @@ def test_streamed_rql_sql_on_the_production_kernel(name, mode, cs, dtype, tol):
     for e in np.flatnonzero(flipped):
         assert abs(J_or[e, bi[e]] - J_or[e, ref_i[e]]) <= 2 * tol * abs(J_or[e, ref_i[e]]) + (1e-6 if dtype == "f32" else 0.0)
     np.testing.assert_array_equal(a[~flipped], cand[np.arange(B), ref_i, 0, :][~flipped])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("mode", ["RQL", "SQL"])
+@pytest.mark.parametrize("name,cs", [("3wrobotNI", "quad-nomix"), ("3wrobotNI", "quad-mix"), ("3wrobot", "quad-nomix"),
+                                     ("2tank", "quad-nomix"), ("2tank", "quadratic"), ("2tank", "quad-lin")])
+def test_critic_fit_on_the_td_stacks_of_the_reference_closed_loop(name, cs, mode, dtype):
+    """Fixtures F7c: at every control tick of the reference's own RQL / SQL loop, the buffers and w_prev its
+    _critic_optimizer saw and the Jc its SLSQP reached.  k_critic_fit on those stacks (one env per tick): equals the
+    oracle twin, never above Jc(w_init), above SLSQP's Jc by at most DESIGN.md 6's band (4.4e-3 Jc(w_init): the mu term)."""
+    from rcognita_amd import _native as N
+
+    meta, z = load_golden(f"F7c_trace_{name}_{mode}_{cs}")
+    ob, ab, wp = z["tick_obs_buf"], z["tick_act_buf"], z["tick_w_prev"]
+    B = ob.shape[0]
+    eng, cfg = both(name, B, dtype, mode=O.MODE_IDS[mode], gamma=meta["gamma"], critic_struct=O.CRITIC_IDS[cs],
+                    n_critic=meta["Ncritic"], buffer_size=meta["buffer_size"], n_actor=meta["Nactor"])
+    _load_buffers(eng, N, ob, ab, wp)
+    eng.critic_update(do_fit=True)
+    assert_kernel(eng, "k_critic_fit", kind=N.KERNEL_CRITIC)
+    w = eng.get_field(N.FIELD_W_CRITIC).astype(np.float64)
+    rb = lambda a: a.astype(eng.real).astype(np.float64)
+    w_or = O.critic_fit(cfg, rb(wp), rb(ob), rb(ab))
+    Jc = O.critic_cost(w, rb(wp), rb(ob), rb(ab), cfg)
+    Jc_or = O.critic_cost(w_or, rb(wp), rb(ob), rb(ab), cfg)
+    J0, Js = z["tick_Jc_init"], z["tick_Jc"]
+    scale = np.maximum(J0, 1e-12)
+    assert np.all(np.abs(Jc - Jc_or) <= (1e-7 if dtype == "f64" else 1e-4) * scale + 1e-9)
+    slack = 1e-6 if dtype == "f64" else 1e-4
+    assert np.all(Jc <= J0 * (1 + slack) + 1e-9)
+    assert np.all(Jc <= Js + (4.4e-3 + slack) * scale + 1e-9), float(np.max((Jc - Js) / scale))
+    lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
+    assert np.all(w >= lo - 1e-4) and np.all(w <= hi + 1e-3)

@@ -18,10 +18,8 @@ DEV_LIB = os.path.join(ROOT, "rcognita_amd", "lib", "librcg_dev.so")
 def _run(env_extra, dev):
     env = {k: v for k, v in os.environ.items() if not k.startswith("RCG_")}
     env.update(env_extra)
-    if dev:
-        env["RCG_LIB"] = DEV_LIB
-    out = subprocess.run([sys.executable, os.path.join(HERE, "knob_probe.py")], capture_output=True, text=True, env=env,
-                         timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "knob_probe.py")] + (["--lib", DEV_LIB] if dev else []),
+                         capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("HASH ")]
     launch = [l for l in out.stdout.splitlines() if l.startswith("LAUNCH ")]

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import rcg_oracle as O
 from tests.conftest import load_golden
-from tests.helpers import PRESETS, SYSTEMS, both, rand_states, rel_err_norm
+from tests.helpers import PRESETS, SYSTEMS, assert_kernel, both, rand_states, rel_err_norm
 
 pytestmark = pytest.mark.gpu
 
@@ -105,13 +105,154 @@ def test_optimizer_beats_grid_search_in_closed_loop():
     assert acc["opt"] < acc["grid"]
 
 
-def test_optimizer_rejects_unsupported_modes():
+CRITIC_CASES = [("3wrobotNI", "quad-nomix"), ("3wrobotNI", "quad-mix"), ("3wrobot", "quad-nomix"), ("2tank", "quad-nomix"),
+                ("2tank", "quadratic"), ("2tank", "quad-lin")]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("mode", ["RQL", "SQL"])
+@pytest.mark.parametrize("name,cs", CRITIC_CASES)
+def test_optimizer_in_the_critic_modes_vs_reference_slsqp(name, cs, mode, dtype):
+    """Fixtures F8c: decisions of the reference's own closed loop in RQL / SQL (state_sys != obs, the critic weights the
+    reference had fitted at that tick, SLSQP's result).  k_actor_opt, 30 iterations from action_sqn_init: the cost it
+    reports is the oracle's _actor_cost of the sequence it reports; it never ends above the start and ends within 0.5 % of
+    SLSQP's cost on every decision; it follows its oracle twin."""
     from rcognita_amd import _native as Nn
 
-    eng, _ = both("2tank", 4, "f32", mode=O.MODE_RQL, buffer_size=6)
+    meta, z = load_golden(f"F8c_slsqp_actor_{name}_{mode}_{cs}")
+    B = z["state"].shape[0]
+    ai = [0.5] if name == "2tank" else None
+    eng, cfg = both(name, B, dtype, n_actor=meta["N"], mode=O.MODE_IDS[mode], gamma=meta["gamma"],
+                    critic_struct=O.CRITIC_IDS[cs], pred_step_size=meta["pred_step_size"], buffer_size=10,
+                    **({"action_init": ai} if ai else {}))
+    eng.set_field(Nn.FIELD_W_CRITIC, z["w"])
+    act, U, J, its = eng.actor_optimize(iters=30, obs=z["obs"], state_sys=z["state"])
+    ll = assert_kernel(eng, "k_actor_opt")
+    assert ll["variant"] & 1, ll  # the generic instance
+    lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
+    assert np.all(U >= lo - 1e-4) and np.all(U <= hi + 1e-4)
+    np.testing.assert_array_equal(act, U[:, 0, :])
+    r = eng.real
+    obs_r, st_r, w_r = (z[k].astype(r).astype(np.float64) for k in ("obs", "state", "w"))
+    J_chk = O.actor_cost(U.astype(np.float64), obs_r, st_r, cfg, w_critic=w_r)
+    scale = np.maximum(np.abs(z["J_init"]), 1.0)  # J is a difference of large terms when weights are negative
+    assert np.max(np.abs(J - J_chk) / scale) < (1e-10 if dtype == "f64" else 1e-5)
+    assert np.all(J <= z["J_init"] + (1e-9 if dtype == "f64" else 2e-5) * scale)
+    gap = (J - z["J_opt"]) / np.maximum(np.abs(z["J_opt"]), 1e-6 * scale)
+    print(f"\nF8c {name} {mode} {cs} {dtype}: J / J_slsqp - 1: median {np.median(gap):.2e} max {np.max(gap):.2e}; "
+          f"accepted steps {its.min()}..{its.max()}")
+    assert np.max(gap) < 5e-3, (np.median(gap), np.max(gap))
+    U_or, J_or, its_or = O.actor_optimize(cfg, obs_r, st_r, O.action_sqn_init(cfg, ai), iters=30, w_critic=w_r)
+    # the quasi-Newton path divides by curvature estimates: rounding-level differences between the kernel's fused
+    # multiply-adds and numpy move the iterates, not the cost reached
+    assert np.max(np.abs(J - J_or) / scale) < (1e-6 if dtype == "f64" else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", SYSTEMS)
+@pytest.mark.parametrize("mode,stage", [("MPC", "full"), ("MPC", "biquad"), ("RQL", "full"), ("RQL", "biquad")])
+def test_optimizer_with_full_and_biquadratic_stage_costs(name, mode, stage, dtype):
+    """A full (SPD) R1 and the biquadratic structure (controllers.py:1076-1082) through the generic instance: reported
+    cost = oracle cost of the reported sequence, monotone, the oracle twin's cost."""
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(f"{name} {mode} {stage}".encode()))
+    B, Nh = 21, 6
+    p = PRESETS[name]
+    n = len(p["R1"])
+    A = rng.uniform(-1, 1, (n, n))
+    kw = dict(n_actor=Nh, mode=O.MODE_IDS[mode], gamma=0.97, R1=A @ A.T + np.diag(p["R1"]), buffer_size=8,
+              critic_struct=O.CRITIC_QUADRATIC)
+    if stage == "biquad":
+        Bm = rng.uniform(-1, 1, (n, n))
+        kw.update(R2=1e-4 * (Bm @ Bm.T), stage_obj_struct=O.STAGE_BIQUADRATIC)
+    eng, cfg = both(name, B, dtype, **kw)
+    x = rand_states(rng, name, B)
+    obs = x + rng.uniform(-0.02, 0.02, x.shape)
+    w = rng.uniform(0, 2, (B, cfg.dc))
+    from rcognita_amd import _native as Nn
+
+    eng.set_field(Nn.FIELD_W_CRITIC, w)
+    act, U, J, its = eng.actor_optimize(iters=12, obs=obs, state_sys=x)
+    assert_kernel(eng, "k_actor_opt")
+    r = eng.real
+    obs_r, x_r, w_r = obs.astype(r).astype(np.float64), x.astype(r).astype(np.float64), w.astype(r).astype(np.float64)
+    J_chk = O.actor_cost(U.astype(np.float64), obs_r, x_r, cfg, w_critic=w_r)
+    assert rel_err_norm(J, J_chk) < (1e-10 if dtype == "f64" else 1e-5)
+    u0 = O.action_sqn_init(cfg, None)
+    J0 = O.actor_cost(np.broadcast_to(u0, (B,) + u0.shape), obs_r, x_r, cfg, w_critic=w_r)
+    assert np.all(J <= J0 * (1 + 1e-6) + 1e-9)
+    U_or, J_or, _ = O.actor_optimize(cfg, obs_r, x_r, u0, iters=12, w_critic=w_r)
+    assert rel_err_norm(J, J_or) < (1e-6 if dtype == "f64" else 2e-3)
+
+
+@pytest.mark.parametrize("name,mode,cs,N", [("2tank", "RQL", "quadratic", 8), ("3wrobotNI", "SQL", "quad-mix", 4),
+                                           ("3wrobot", "RQL", "quad-nomix", 5)])
+def test_control_tick_opt_closed_loop_in_the_critic_modes_vs_oracle(name, mode, cs, N):
+    """rcg_control_tick_opt in RQL / SQL: env step + buffer push + critic fit (one launch), then the optimiser on the fitted
+    weights - tick by tick against the oracle twin, every tick checked as a map from the device's own pre-tick values."""
+    from rcognita_amd import _native as Nn
+
+    rng = np.random.default_rng(77)
+    B, T = 11, 6
+    ai = [0.5] if name == "2tank" else None
+    eng, cfg = both(name, B, "f64", n_actor=N, mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs], n_critic=4,
+                    buffer_size=6, **({"action_init": ai} if ai else {}))
+    x0 = rand_states(rng, name, B) * 0.3
+    eng.set_state(x0)
+    env = O.new_batch(cfg, x0, action0=ai)
+    for t in range(T):
+        eng.control_tick_opt(iters=8)
+        O.control_tick_opt(cfg, env, 8, action_init=ai)
+        assert_kernel(eng, "k_actor_opt")
+        assert rel_err_norm(eng.get_state(), env.state) < 1e-9, t
+        # critic weights: a bounded least squares regularised at 1e-8 of its scale (DESIGN.md 9)
+        assert rel_err_norm(eng.get_field(Nn.FIELD_W_CRITIC), env.w_critic, floor=1.0) < 1e-6, t
+        scale = np.maximum(np.abs(env.best_J), 1.0)
+        assert np.max(np.abs(eng.get_field(Nn.FIELD_BEST_J) - env.best_J) / scale) < 1e-6, t
+        assert rel_err_norm(eng.get_field(Nn.FIELD_ACCUM), env.accum, floor=float(np.max(np.abs(env.accum)) + 1e-9)) < 1e-5
+        np.testing.assert_array_equal(eng.get_field(Nn.FIELD_STEP_IDX), env.step_idx)
+        # continue the oracle from the device's values: each tick is checked as a map (oracle/parity.py's rule)
+        env.state = eng.get_state().astype(np.float64)
+        env.state_prev = eng.get_field(Nn.FIELD_STATE_PREV).astype(np.float64)
+        env.action = eng.get_field(Nn.FIELD_ACTION).astype(np.float64)
+        env.accum = eng.get_field(Nn.FIELD_ACCUM).astype(np.float64)
+        env.w_critic = eng.get_field(Nn.FIELD_W_CRITIC).astype(np.float64)
+        env.w_prev = eng.get_field(Nn.FIELD_W_PREV).astype(np.float64)
+        env.obs_buf = eng.get_field(Nn.FIELD_OBS_BUF).astype(np.float64)
+        env.act_buf = eng.get_field(Nn.FIELD_ACT_BUF).astype(np.float64)
+
+
+def test_optimizer_memory_setting_and_refusals():
+    """rcg_set_optimizer: 0 .. 8 pairs; memory 0 is round 3's steepest descent and equals the oracle's memory = 0; a horizon
+    whose pairs do not fit the CU's LDS is refused before the env is stepped."""
+    from rcognita_amd import _native as Nn
+
+    rng = np.random.default_rng(3)
+    B = 19
+    eng, cfg = both("3wrobot", B, "f64", n_actor=7)
+    x = rand_states(rng, "3wrobot", B)
+    eng.set_state(x)
+    for bad in (-1, 9):
+        with pytest.raises(Nn.NativeError) as ei:
+            eng.set_optimizer(bad)
+        assert ei.value.code == Nn.ERR_BAD_ARG
+    for mem in (0, 2, 8):
+        eng.set_optimizer(mem)
+        act, U, J, its = eng.actor_optimize(iters=6)
+        U_or, J_or, _ = O.actor_optimize(cfg, x, x, O.action_sqn_init(cfg, None), iters=6, memory=mem)
+        assert rel_err_norm(J, J_or) < 1e-8, mem
+    big, _ = both("3wrobot", 4, "f64", n_actor=32)  # R = 64 doubles: 8 pairs need 16 * 20 * 64 * 8 B > 160 KB per wave
+    big.set_state(x[:4])
+    big.set_optimizer(8)
+    before = big.get_state().copy()
     with pytest.raises(Nn.NativeError) as ei:
-        eng.actor_optimize(iters=3)
+        big.control_tick_opt(iters=2)
     assert ei.value.code == Nn.ERR_UNSUPPORTED
+    np.testing.assert_array_equal(big.get_state(), before)  # refused before the env step
+    np.testing.assert_array_equal(big.get_field(Nn.FIELD_STEP_IDX), np.zeros(4, np.int32))
+    big.set_optimizer(2)
+    big.control_tick_opt(iters=2)
 
 
 def test_full_size_optimizer_tick():

@@ -48,3 +48,78 @@ def test_optimizer_reaches_reference_slsqp_cost(name):
     # monotone: more iterations never hurt
     _, J20, _ = O.actor_optimize(cfg, x, x, u0, iters=20)
     assert np.all(J20 <= J * (1 + 1e-12))
+
+
+CRITIC_CASES = [("3wrobotNI", "quad-nomix"), ("3wrobotNI", "quad-mix"), ("3wrobot", "quad-nomix"), ("2tank", "quad-nomix"),
+                ("2tank", "quadratic"), ("2tank", "quad-lin")]
+
+
+def fd_grad(u, obs, x, cfg, w):
+    gf = np.zeros_like(u)
+    for i in range(u.shape[0]):
+        for c in range(cfg.du):
+            e = 1e-6 * max(1.0, abs(u[i, c]))
+            up, um = u.copy(), u.copy()
+            up[i, c] += e
+            um[i, c] -= e
+            gf[i, c] = (O.actor_cost(up, obs, x, cfg, w_critic=w) - O.actor_cost(um, obs, x, cfg, w_critic=w)) / (2 * e)
+    return gf
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+@pytest.mark.parametrize("mode", ["MPC", "RQL", "SQL"])
+@pytest.mark.parametrize("cs", ["quad-lin", "quadratic", "quad-nomix", "quad-mix"])
+@pytest.mark.parametrize("stage", ["diag", "full", "biquad"])
+def test_adjoint_gradient_every_mode_and_structure(name, mode, cs, stage):
+    """The closed-form gradients of the stage cost (diagonal / full non-symmetric R1, biquadratic) and of w . phi (four
+    structures, with an observation target, negative weights included) through the adjoint sweep, against central
+    differences of the pinned ``_actor_cost``."""
+    if mode == "MPC" and cs != "quad-nomix":
+        pytest.skip("MPC has no critic term")
+    if mode == "SQL" and stage != "diag":
+        pytest.skip("SQL has no stage term")
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(f"{name} {mode} {cs} {stage}".encode()))
+    Nh = 6
+    base = oracle_cfg(name)
+    n = base.ds + base.du
+    kw = dict(n_actor=Nh, gamma=0.93, mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs],
+              target=rng.uniform(-1, 1, base.ds))
+    if stage != "diag":
+        kw["R1"] = rng.uniform(-1, 1, (n, n))  # full and not symmetric: chi R1 chi is still defined
+    if stage == "biquad":
+        kw["R2"] = 1e-3 * rng.uniform(-1, 1, (n, n))
+        kw["stage_obj_struct"] = O.STAGE_BIQUADRATIC
+    cfg = oracle_cfg(name, **kw)
+    x = rand_states(rng, name, 1)[0]
+    obs = x + 0.03
+    u = rand_actions(rng, name, (Nh,))
+    w = rng.uniform(-1, 2, cfg.dc)
+    J, g = O.actor_grad(u, obs, x, cfg, w_critic=w)
+    assert abs(J - O.actor_cost(u, obs, x, cfg, w_critic=w)) <= 1e-12 * max(abs(J), 1.0)
+    gf = fd_grad(u, obs, x, cfg, w)
+    assert np.max(np.abs(g - gf)) <= 5e-5 * max(np.max(np.abs(gf)), 1e-9), (g, gf)
+
+
+@pytest.mark.parametrize("mode", ["RQL", "SQL"])
+@pytest.mark.parametrize("name,cs", CRITIC_CASES)
+def test_optimizer_reaches_reference_slsqp_cost_in_the_critic_modes(name, cs, mode):
+    """Fixtures F8c: the decisions of the reference's own closed loop in RQL / SQL (state_sys != obs, the critic weights
+    the reference had fitted at that tick) with SLSQP's result.  30 iterations of the build's optimiser end within 0.5 %
+    of SLSQP's cost on every one of them (measured: <= 0.28 %; the median is at rounding level), never above the start."""
+    meta, z = load_golden(f"F8c_slsqp_actor_{name}_{mode}_{cs}")
+    cfg = oracle_cfg(name, n_actor=meta["N"], mode=O.MODE_IDS[mode], gamma=meta["gamma"],
+                     critic_struct=O.CRITIC_IDS[cs], pred_step_size=meta["pred_step_size"])
+    u0 = O.action_sqn_init(cfg, [0.5] if name == "2tank" else None)
+    U, J, its = O.actor_optimize(cfg, z["obs"], z["state"], u0, iters=30, w_critic=z["w"])
+    lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
+    assert np.all(U >= lo - 1e-12) and np.all(U <= hi + 1e-12)
+    np.testing.assert_allclose(J, O.actor_cost(U, z["obs"], z["state"], cfg, w_critic=z["w"]), rtol=1e-12, atol=1e-12)
+    assert np.all(J <= z["J_init"] + 1e-12 * np.abs(z["J_init"]))
+    gap = (J - z["J_opt"]) / np.maximum(np.abs(z["J_opt"]), 1e-9)
+    assert np.max(gap) < 5e-3, (np.median(gap), np.max(gap))
+    # round 3's optimiser (no curvature pairs) is what this replaces: it stays far above SLSQP on these decisions
+    if (name, cs, mode) in (("3wrobot", "quad-nomix", "RQL"), ("3wrobotNI", "quad-nomix", "RQL")):
+        _, J0, _ = O.actor_optimize(cfg, z["obs"], z["state"], u0, iters=30, w_critic=z["w"], memory=0)
+        assert np.max((J0 - z["J_opt"]) / np.abs(z["J_opt"])) > 2e-2

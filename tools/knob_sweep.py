@@ -21,8 +21,10 @@ B = int(os.environ.get("SWEEP_B", "65536"))
 K = int(os.environ.get("SWEEP_K", "256"))
 a.nactor = int(os.environ.get("SWEEP_N", "10"))
 a.dtype = os.environ.get("SWEEP_DTYPE", "f32")
-from rcognita_amd import Engine  # noqa: E402
 from rcognita_amd import _native as N  # noqa: E402
+
+N.use_library(os.path.join(ROOT, "rcognita_amd", "lib", "librcg_dev.so"))  # the knobs exist only in the -DRCG_DEV twin
+from rcognita_amd import Engine  # noqa: E402
 
 ecfg, bnds = bench.c2_engine_config(a, 0, B)
 eng = Engine(ecfg)

@@ -10,7 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
-from rcognita_amd import Engine, _native as N
+from rcognita_amd import _native as N
+N.use_library(%r)
+from rcognita_amd import Engine
 from rcognita_amd.pool import preset_engine_config
 B, Nh = 65536, 10
 K = int(sys.argv[1])
@@ -24,12 +26,12 @@ for _ in range(300): eng.control_tick(cand, K=K)
 s = eng.profile_samples(N.KERNEL_ACTOR); ll = eng.last_launch()
 byt = B * (K * Nh * 2 * 4 + 52)
 print("RES", ll["kernel"], ll["envs_per_wave"], round(float(np.median(s)) * 1e3, 2), round(float(s.min()) * 1e3, 2), round(byt / (np.median(s) * 1e-3) / 8e12, 3))
-''' % ROOT
+''' % (ROOT, os.path.join(ROOT, "rcognita_amd", "lib", "librcg_dev.so"))
 for K in (16, 32, 8):
     for knobs in ({}, {"RCG_GPW": str(64 // K)}, {"RCG_GPW": str(2 * (64 // K))}, {"RCG_GPW": "32"}, {"RCG_GPW": "64"},
                   {"RCG_PER_CU": "8"}, {"RCG_PER_CU": "2"}, {"RCG_GPW": "32", "RCG_PER_CU": "8"}):
         env = {k: v for k, v in os.environ.items() if not k.startswith("RCG_")}
-        env.update(knobs, RCG_LIB=os.path.join(ROOT, "rcognita_amd", "lib", "librcg_dev.so"))
+        env.update(knobs)
         out = subprocess.run([sys.executable, "-c", CHILD, str(K)], capture_output=True, text=True, env=env, timeout=600)
         res = [l for l in out.stdout.splitlines() if l.startswith("RES")]
         print("K", K, knobs, res[-1] if res else out.stderr[-300:], flush=True)
