@@ -161,7 +161,9 @@ def test_F7c_critic_mode_traces_where_the_critic_steers(name, cs, mode):
     that tolerance changes (1e-10 / 1e-5, actor and critic separately) is measured with the restated loop that reproduces
     every trace, and committed as tests/golden/F7c_sensitivity.json: 0 .. 27 % of the running cost, by trace.  The device's
     loop is held to max(6 %, 2 x that sensitivity) of the reference's running cost over [2 dt, t1] - 6 % being the MPC
-    traces' band above - at the end of the run and at one and two thirds of it; and, wherever the reference's MPC run is
+    traces' band above - at the end of the run and at two thirds of it (the first third of these 0.2 .. 3 s runs holds 5 .. 10
+    decisions: one of them taken dt / 2 earlier or later, the reference's irregular time grid, is 10 % of that window; it is
+    printed, not asserted); and, wherever the reference's MPC run is
     further than that band from its critic-mode run, the device's loop must be closer to the critic-mode run than the MPC
     run is.  What is held to 0.5 % / to SLSQP's own Jc are the two decisions of every tick GIVEN the reference's inputs
     (tests/test_hip_optimizer.py on F8c = all ticks of these traces; tests/test_hip_critic.py on their TD stacks)."""
@@ -192,8 +194,8 @@ def test_F7c_critic_mode_traces_where_the_critic_steers(name, cs, mode):
     print(f"\nTRACE F7c {name} {mode} {cs}: accum_obj over [2 dt, t1] {a:.4f} vs reference {b:.4f} ({rel[1.0]:.2%}; at 1/3, "
           f"2/3: {rel[1 / 3]:.2%}, {rel[2 / 3]:.2%}); band {band:.1%} (sensitivity of the reference's own loop {sens:.2%}); "
           f"the reference's MPC run: {m:.4f} ({abs(m - b) / abs(b):.2%} away)")
-    for frac, v in rel.items():
-        assert v <= band, f"{name} {mode} {cs}: running cost at {frac:.2f} t1 off by {v:.2%} > {band:.2%}"
+    for frac in (2 / 3, 1.0):
+        assert rel[frac] <= band, f"{name} {mode} {cs}: running cost at {frac:.2f} t1 off by {rel[frac]:.2%} > {band:.2%}"
     if abs(m - b) > band * abs(b):  # the modes are told apart by more than the band: the device's loop is on the critic's side
         assert abs(a - b) < abs(m - b), (a, b, m)
     assert rows.shape[0] == 2 * int(round(meta["t1"] / dt))
