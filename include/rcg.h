@@ -171,6 +171,11 @@ int rcg_use_own_stream(rcg_handle* h);
  * tensors, states - written on another stream than the handle's, e.g. torch's current stream when the handle runs on a
  * stream of its own.  No host synchronisation.  No-op when `producer_stream` is the handle's stream. */
 int rcg_wait_stream(rcg_handle* h, void* producer_stream);
+/* The reverse edge: order everything queued on `consumer_stream` from now on AFTER the work this handle has launched so far
+ * (an event recorded on the handle's stream, waited for on `consumer_stream`).  For a producer that REWRITES or frees a
+ * device-resident input - the candidate tensor of the next tick - on its own stream while this handle's kernels may still be
+ * reading the previous contents.  No host synchronisation.  No-op when `consumer_stream` is the handle's stream. */
+int rcg_release_stream(rcg_handle* h, void* consumer_stream);
 int rcg_synchronize(rcg_handle* h);
 
 /* Device-memory helpers so that a host language without a GPU array library can drive the ABI. */
@@ -229,11 +234,11 @@ int rcg_sim_step(rcg_handle* h, int32_t n_substeps);
  * obs / state_sys as rcg_actor_cost.  Outputs (each may be NULL): action [du][B] = first du
  * entries of the winner (controllers.py:1427), best_J [B], best_idx [B] int32.  Does not modify
  * the handle's ACTION.
- * Non-finite corner: with streamed candidates the stage cost is the full sum chi' R1 chi as numpy evaluates it, so a
- * component that overflows under a ZERO weight makes J NaN (0 * inf) and the candidate counts as +inf, exactly as in the
- * reference; the generated grid with the presets' R1 never computes zero-weighted terms (v, omega, F, M of the robots),
- * so there such a candidate keeps the finite cost of its weighted components.  The two agree whenever every rolled-out
- * component stays finite in the handle's element type (tests/test_hip_reset_and_guards.py pins both behaviours). */
+ * Non-finite corner: the stage cost is the full sum chi' R1 chi as numpy evaluates it, so a component that overflows under a
+ * ZERO weight makes J NaN (0 * inf) and the candidate counts as +inf, exactly as in the reference.  The generated grid with
+ * the presets' R1 does not accumulate its zero-weighted terms (v, omega, F, M of the robots) step by step; it tests the
+ * zero-weighted state components once, on the observation and on the last rolled-out state (a non-finite value is sticky
+ * under the Euler step), with the same outcome (tests/test_hip_reset_and_guards.py). */
 int rcg_actor_argmin(rcg_handle* h, const void* cand, int32_t K, const void* obs, const void* state_sys,
                      void* action, void* best_J, int32_t* best_idx);
 /* One env.control-step for every env (the loop body of presets/main_3wrobot.py:419-429):

@@ -19,6 +19,9 @@ F7c_trace_<system>_<mode>_<critic_struct>  the loop body of presets/main_3wrobot
               tick_action_sqn [N * du], tick_J (SLSQP's result, recomputed with the reference's own call and
               asserted bit-identical to the action the reference returned), tick_J_init (J at action_sqn_init),
               tick_nfev, tick_Jc (the reference's _critic_cost at the fitted weights), tick_Jc_init.
+    mpc_tick_*  the same per-tick record (t, obs, state_sys, action_sqn, J, J_init, nfev) of the MPC run: SLSQP's decisions
+              on the states the reference's own MPC loop visits (a tighter anchor for the optimiser than the closed-loop
+              bands of the MPC traces).
 F8c_slsqp_actor_<system>_<mode>_<critic_struct>  a subsample of those ticks as an optimiser-quality fixture in F8's layout
     (state = state_sys, obs, w, J_opt, action_sqn_opt, J_init, nfev) - the bar for rcg_actor_optimize in RQL / SQL.
 
@@ -72,7 +75,7 @@ def run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, critic
                            options={"maxiter": 300, "disp": False})
             assert np.array_equal(res.x[: p["du"]], np.asarray(action)), "recomputed SLSQP differs from the reference's"
             tk = dict(t=float(t), obs=np.array(obs, dtype=float), state_sys=state_sys_before,
-                      w=np.array(ctrl.w_critic, dtype=float), w_prev=w_prev_before,
+                      w=np.array(getattr(ctrl, "w_critic", ctrl.w_critic_init), dtype=float), w_prev=w_prev_before,
                       obs_buf=np.array(ctrl.observation_buffer, dtype=float),
                       act_buf=np.array(ctrl.action_buffer, dtype=float), action_sqn=np.array(res.x, dtype=float),
                       J=float(res.fun), J_init=float(ctrl._actor_cost(init, obs)), nfev=int(res.nfev))
@@ -107,7 +110,9 @@ def main():
     for name, x0, t1, Nactor, cs in CASES:
         p = PRESETS[name]
         ds, du = p["ds"], p["du"]
-        rows_mpc, _ = run_loop(systems, simulator, controllers, name, "MPC", x0, t1, Nactor, cs, capture=False)
+        rows_mpc, ticks_mpc = run_loop(systems, simulator, controllers, name, "MPC", x0, t1, Nactor, cs, capture=True)
+        mpc_arrays = {f"mpc_tick_{k}": np.stack([np.asarray(tk[k]) for tk in ticks_mpc])
+                      for k in ("t", "obs", "state_sys", "action_sqn", "J", "J_init", "nfev")}
         for mode in ("RQL", "SQL"):
             rows, ticks = run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, cs, capture=True)
             gap = assert_discriminating(rows, rows_mpc, ds, du, f"{name} {mode}")
@@ -119,7 +124,7 @@ def main():
                         accum_obj=float(rows[-1, -1]), accum_obj_mpc=float(rows_mpc[-1, -1]),
                         columns="t,state...,action...,stage_obj,accum_obj")
             tick_arrays = {f"tick_{k}": np.stack([np.asarray(tk[k]) for tk in ticks]) for k in ticks[0]}
-            save(f"F7c_trace_{name}_{mode}_{cs}", meta, rows=rows, rows_mpc=rows_mpc, **tick_arrays)
+            save(f"F7c_trace_{name}_{mode}_{cs}", meta, rows=rows, rows_mpc=rows_mpc, **tick_arrays, **mpc_arrays)
             # optimiser-quality subsample: every tick of the short runs, every 3rd of the long one, at most 32
             step = max(1, len(ticks) // 32)
             sel = ticks[::step][:32]

@@ -49,7 +49,7 @@ SYMBOLS = [
     "rcg_critic_update", "rcg_control_ticks", "rcg_control_tick_n", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
     "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
     "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream", "rcg_nominal_theta", "rcg_set_optimizer",
-    "rcg_actor_search", "rcg_control_tick_search", "rcg_candidates_sample",
+    "rcg_actor_search", "rcg_control_tick_search", "rcg_candidates_sample", "rcg_release_stream",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
 # rcg_kernel_id (rcg_last_launch)
@@ -166,6 +166,7 @@ def lib():
         "rcg_last_launch": (C.c_int, [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "rcg_kernel_name": (C.c_char_p, [i32]),
         "rcg_wait_stream": (C.c_int, [vp, vp]),
+        "rcg_release_stream": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export what rcg.h declares

@@ -28,13 +28,17 @@ int rcg_fail(rcg_handle* h, int code, const char* fmt, ...) {
   return code;
 }
 
-static void prof_drain(rcg_handle* h) {
-  if (h->ev_pending.empty()) return;  // nothing recorded: do not stall the stream (rcg_profile just before a timed region)
+// Turn the pending event pairs into totals and samples.  Returns RCG_OK, or RCG_ERR_HIP (text in the handle) when a
+// pair could not be read - e.g. one that no dispatch ever recorded: the readers pass that on instead of returning
+// totals that silently miss launches.
+static int prof_drain(rcg_handle* h) {
+  if (h->ev_pending.empty()) return RCG_OK;  // nothing recorded: do not stall the stream (rcg_profile just before a timed region)
   (void)hipStreamSynchronize(h->stream);
+  int rc = RCG_OK;
   for (auto& p : h->ev_pending) {
     float ms = 0.f;
     const hipError_t er = hipEventElapsedTime(&ms, p.a, p.b);
-    if (er != hipSuccess) rcg_fail(h, RCG_ERR_HIP, "rcg_profile: hipEventElapsedTime: %s", hipGetErrorString(er));
+    if (er != hipSuccess) rc = rcg_fail(h, RCG_ERR_HIP, "rcg_profile: hipEventElapsedTime: %s", hipGetErrorString(er));
     if (er == hipSuccess) {
       h->prof_ms[p.kernel] += ms;
       h->prof_n[p.kernel] += 1;
@@ -44,6 +48,7 @@ static void prof_drain(rcg_handle* h) {
     h->ev_free.push_back(p.b);
   }
   h->ev_pending.clear();
+  return rc;
 }
 
 // Every entry point that touches HIP runs on the handle's device whatever the calling thread's current device is
@@ -209,7 +214,9 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->tick_count = 0;
   h->opt_memory = 4;
   h->cur_a = h->cur_b = nullptr;
+  h->scope_due = false;
   h->order_ev = nullptr;
+  h->release_ev = nullptr;
   memset(h->last, 0, sizeof h->last);
   h->sys = cfg->sys_id == RCG_SYS_3WROBOT ? &kVt3WRobot : (cfg->sys_id == RCG_SYS_3WROBOT_NI ? &kVt3WRobotNI : &kVt2Tank);
   memset(h->prof_ms, 0, sizeof h->prof_ms);
@@ -333,6 +340,7 @@ int rcg_destroy(rcg_handle* h) {
   }
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->order_ev) (void)hipEventDestroy(h->order_ev);
+  if (h->release_ev) (void)hipEventDestroy(h->release_ev);
   delete h;
   return RCG_OK;
 }
@@ -343,7 +351,7 @@ int rcg_set_stream(rcg_handle* h, void* hip_stream) {
   if ((hipStream_t)hip_stream == h->stream) return RCG_OK;
   // work already queued on the old stream is finished before the first launch on the new one: the two streams are
   // not ordered with respect to each other (torch.cuda.Stream() is non-blocking)
-  prof_drain(h);
+  (void)prof_drain(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->stream = (hipStream_t)hip_stream;
   return RCG_OK;
@@ -363,6 +371,16 @@ int rcg_wait_stream(rcg_handle* h, void* producer_stream) {
   if (!h->order_ev) HIPCHK(h, hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
   HIPCHK(h, hipEventRecord(h->order_ev, (hipStream_t)producer_stream));
   HIPCHK(h, hipStreamWaitEvent(h->stream, h->order_ev, 0));
+  return RCG_OK;
+}
+
+int rcg_release_stream(rcg_handle* h, void* consumer_stream) {
+  DeviceGuard dev_guard(h);
+  if (!h) return RCG_ERR_BAD_ARG;
+  if ((hipStream_t)consumer_stream == h->stream) return RCG_OK;  // same stream: already ordered
+  if (!h->release_ev) HIPCHK(h, hipEventCreateWithFlags(&h->release_ev, hipEventDisableTiming));
+  HIPCHK(h, hipEventRecord(h->release_ev, h->stream));
+  HIPCHK(h, hipStreamWaitEvent((hipStream_t)consumer_stream, h->release_ev, 0));
   return RCG_OK;
 }
 
@@ -856,7 +874,7 @@ int rcg_profile(rcg_handle* h, int32_t enable) {
     h->prof_mask = 0;
     return RCG_OK;
   }
-  prof_drain(h);
+  const int drain_rc = prof_drain(h);
   h->prof_mask = (unsigned)enable & 0x7fu;
   h->prof_stride = (((unsigned)enable >> 8) & 0xfffu) ? (((unsigned)enable >> 8) & 0xfffu) : 1u;
   // bits 20..: launches of each kernel to let pass before the first sample (the first launch after a synchronisation
@@ -869,29 +887,29 @@ int rcg_profile(rcg_handle* h, int32_t enable) {
     memset(h->prof_n, 0, sizeof h->prof_n);
     for (auto& v : h->prof_samples) v.clear();
   }
-  return RCG_OK;
+  return drain_rc;
 }
 
 int rcg_profile_read(rcg_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
   DeviceGuard dev_guard(h);
   if (!h || kernel < 0 || kernel >= RCG_KERNEL_COUNT_)
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_profile_read: bad kernel id");
-  prof_drain(h);
+  const int drain_rc = prof_drain(h);
   if (total_ms) *total_ms = h->prof_ms[kernel];
   if (launches) *launches = h->prof_n[kernel];
-  return RCG_OK;
+  return drain_rc;
 }
 
 int rcg_profile_samples(rcg_handle* h, int32_t kernel, double* ms_out, int64_t cap, int64_t* n_out) {
   DeviceGuard dev_guard(h);
   if (!h || kernel < 0 || kernel >= RCG_KERNEL_COUNT_ || cap < 0 || (cap > 0 && !ms_out))
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_profile_samples: bad argument");
-  prof_drain(h);
+  const int drain_rc = prof_drain(h);
   const std::vector<float>& v = h->prof_samples[kernel];
   const int64_t n = (int64_t)v.size();
   for (int64_t i = 0; i < n && i < cap; ++i) ms_out[i] = (double)v[(size_t)i];
   if (n_out) *n_out = n;
-  return RCG_OK;
+  return drain_rc;
 }
 
 int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave) {

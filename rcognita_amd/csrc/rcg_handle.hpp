@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -43,8 +45,10 @@ struct rcg_handle {
   double prof_ms[RCG_KERNEL_COUNT_];
   int64_t prof_n[RCG_KERNEL_COUNT_];
   std::vector<float> prof_samples[RCG_KERNEL_COUNT_];  // per-launch durations (ms), launch order, first kProfMaxSamples
-  hipEvent_t cur_a, cur_b;  // event pair of the ProfScope whose sample is due: the next RCG_LAUNCH carries it
+  hipEvent_t cur_a, cur_b;  // event pair of the ProfScope whose sample is due: the next launch carries it (prof_take)
+  bool scope_due;           // a due ProfScope is alive (dev build: a second launch inside it aborts)
   hipEvent_t order_ev;      // rcg_wait_stream's event (created on first use)
+  hipEvent_t release_ev;    // rcg_release_stream's event (created on first use)
   // rcg_last_launch: which kernel served the last launch of each kind
   struct LastLaunch {
     int32_t kernel_id, variant, envs_per_wave;
@@ -105,9 +109,11 @@ struct ProfScope {
     }
     h->cur_a = a;
     h->cur_b = b;
+    h->scope_due = true;
   }
   ~ProfScope() {
     if (!on) return;
+    h->scope_due = false;
     if (h->cur_a == nullptr) {  // a launch took the pair
       h->ev_pending.push_back({a, b, kernel});
     } else {  // no launch was made inside the scope (an argument check failed): nothing to time
@@ -120,14 +126,39 @@ struct ProfScope {
   ProfScope& operator=(const ProfScope&) = delete;
 };
 
-// Launch on the handle's stream; inside a due ProfScope the FIRST launch carries the scope's event pair.
+// The event pair of the due ProfScope, handed to ONE dispatch: every launcher - RCG_LAUNCH below, launch_dma and
+// launch_dma_packed through launch_actor - takes it through prof_take, so the hand-off exists once.  A launcher that did
+// not launch after all (no kernel instance) gives the pair back.  A scope times one launch: a second launch inside a
+// due scope would go untimed and rcg_profile_read would under-report "the summed time of the kernel" - the -DRCG_DEV
+// build aborts on it.
+struct ProfPair {
+  hipEvent_t a, b;
+};
+static inline ProfPair prof_take(rcg_handle* h) {
+  const ProfPair p{h->cur_a, h->cur_b};
+  h->cur_a = h->cur_b = nullptr;
+#ifdef RCG_DEV
+  if (h->scope_due) {
+    if (!p.a) {
+      fprintf(stderr, "librcg (dev): a second launch inside one due ProfScope would go untimed\n");
+      abort();
+    }
+  }
+#endif
+  return p;
+}
+static inline void prof_give_back(rcg_handle* h, const ProfPair& p) {
+  h->cur_a = p.a;
+  h->cur_b = p.b;
+}
+
+// Launch on the handle's stream; inside a due ProfScope the launch carries the scope's event pair.
 #define RCG_LAUNCH(h, kern, grid, block, lds, ...)                                                                 \
   do {                                                                                                             \
     rcg_handle* h__ = (h);                                                                                         \
-    if (h__->cur_a) {                                                                                              \
-      hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)(lds), h__->stream, h__->cur_a, h__->cur_b, 0,       \
-                            __VA_ARGS__);                                                                          \
-      h__->cur_a = h__->cur_b = nullptr;                                                                           \
+    const ProfPair pp__ = prof_take(h__);                                                                          \
+    if (pp__.a) {                                                                                                  \
+      hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)(lds), h__->stream, pp__.a, pp__.b, 0, __VA_ARGS__); \
     } else {                                                                                                       \
       hipLaunchKernelGGL(kern, grid, block, lds, h__->stream, __VA_ARGS__);                                        \
     }                                                                                                              \

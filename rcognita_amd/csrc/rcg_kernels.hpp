@@ -388,6 +388,13 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
 #pragma unroll
     for (int i = 0; i < NCHI; ++i)
       if (!((ZW >> i) & 1u)) J = fma_r(P.R1d[i], S[G1 ? i : 0], J);  // fma(0, S_i, J) == J for finite S_i
+    // ... and NaN for a non-finite S_i (0 * inf), which is what numpy's chi R1 chi gives the reference: the skipped state
+    // components are tested once, on the observation and on the last rolled-out state (inf / NaN is sticky under
+    // x += h f), so that a component that overflows under a zero weight disqualifies the candidate here as it does in
+    // the streamed kernels.  (The skipped inputs are the grid's own bounded levels.)
+#pragma unroll
+    for (int i = 0; i < DS; ++i)
+      if ((ZW >> i) & 1u) J = fma_r(P.R1d[i], y[i] * y[i], fma_r(P.R1d[i], y0[i] * y0[i], J));
   }
   if (SUMF) {
 #pragma unroll
@@ -547,6 +554,9 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
 #pragma unroll
       for (int i = 0; i < NCHI; ++i)
         if (!((ZW >> i) & 1u)) J[c] = fma_r(P.R1d[i], S[c][G1 ? i : 0], J[c]);
+#pragma unroll
+      for (int i = 0; i < DS; ++i)  // zero-weighted state components: 0 * inf = NaN, as rollout_cost
+        if ((ZW >> i) & 1u) J[c] = fma_r(P.R1d[i], y[c][i] * y[c][i], fma_r(P.R1d[i], y0[i] * y0[i], J[c]));
     }
     Jout[c] = J[c];
   }

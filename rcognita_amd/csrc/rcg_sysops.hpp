@@ -355,22 +355,25 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     long gpw = pack_g;
     while (gpw * 2 <= 64 && B / (gpw * 2) >= 4096) gpw *= 2;
     if (knobs.gpw > 0 && knobs.gpw % pack_g == 0 && knobs.gpw <= 64) gpw = knobs.gpw;  // (dev build only)
-    A.G = pack_g;
-    A.gpw = (int)gpw;
-    A.jwave = 1;
     const long pw = (B + gpw - 1) / gpw;
     const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
     const size_t full_tile = (size_t)64 * R * esz;
     size_t lds_req = 4 * full_tile + (A.J ? 4 * esz * (size_t)gpw * K : 0);
     const size_t cap = knobs.per_cu == 2 ? (size_t)56 * 1024 : (knobs.per_cu == 8 ? 0 : (size_t)36 * 1024);
     if (lds_req < cap) lds_req = cap;  // 4 resident blocks per CU (dev build: RCG_PER_CU = 2 | 8)
-    const hipEvent_t ev_a = h->cur_a, ev_b = h->cur_b;
-    if (!launch_dma_packed<Sys, real>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b))
-      return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma_packed instance for a row of %d reals", who, R);
-    h->cur_a = h->cur_b = nullptr;
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA_PACKED, variant, (int)gpw);
-    HIPCHK(h, hipGetLastError());
-    return RCG_OK;
+    const ProfPair pp = prof_take(h);  // a due ProfScope's pair travels in the dispatch
+    ActorArgs<real> Ap = A;
+    Ap.G = pack_g;
+    Ap.gpw = (int)gpw;
+    Ap.jwave = 1;
+    // (an instance exists for every row the conditions above admit; should one ever be missing the tick is NOT refused
+    // half-way - the env step has been issued - but served by k_actor below)
+    if (launch_dma_packed<Sys, real>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b)) {
+      note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA_PACKED, variant, (int)gpw);
+      HIPCHK(h, hipGetLastError());
+      return RCG_OK;
+    }
+    prof_give_back(h, pp);
   }
   if (dma_ok) {
     // Launch geometry, measured on MI355X at C2 (B = 65536, K = 256, N = 10):
@@ -385,7 +388,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     while (gpw < 16 && B / (gpw * 2) >= 8192) gpw *= 2;
     if (knobs.gpw > 0) gpw = knobs.gpw;
     gpw = gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
-    A.gpw = (int)gpw;
+    ActorArgs<real> Ad = A;
+    Ad.gpw = (int)gpw;
     const long pw = (B + gpw - 1) / gpw;
     const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
     // blocks per CU: 2 for rows of >= 80 bytes (a block keeps R KiB in flight), 4 for shorter rows, which need more
@@ -396,8 +400,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     const bool long_slab = (size_t)gpw * K * row_bytes >= (size_t)64 * 1024;
     const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 80 && long_slab) ? 2 : 4);
     // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
-    A.jwave = (A.J && 4 * tile + wslot + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
-    size_t lds_req = 4 * tile + wslot + (A.J ? 4 * esz * K * (A.jwave ? gpw : 1) : 0);
+    Ad.jwave = (A.J && 4 * tile + wslot + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
+    size_t lds_req = 4 * tile + wslot + (A.J ? 4 * esz * K * (Ad.jwave ? gpw : 1) : 0);
     if (knobs.lds_pad > 0) {
       lds_req += (size_t)knobs.lds_pad;
     } else if (knobs.lds_pad == 0) {  // RCG_LDS_PAD=-1: no residency cap
@@ -407,18 +411,19 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     // (blocks of 4 waves = one wave per SIMD: blocks of 2 or 1 waves at the same 8 resident waves per CU measured
     // 10-13 % slower)
     bool ok = false;
-    const hipEvent_t ev_a = h->cur_a, ev_b = h->cur_b;  // a due ProfScope's pair travels in the dispatch
+    const ProfPair pp = prof_take(h);  // a due ProfScope's pair travels in the dispatch
     if (variant < DMA_RQL_0)
-      ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
+      ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);
     else if (variant >= DMA_SQL_0)
-      ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
+      ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);
     else
-      ok = launch_dma<Sys, real, 2>(R, variant, grid, block, lds_req, h->stream, A, P, ev_a, ev_b);
-    if (!ok) return rcg_fail(h, RCG_ERR_BAD_ARG, "%s: no k_actor_dma instance for a row of %d reals", who, R);
-    h->cur_a = h->cur_b = nullptr;
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA, variant, (int)gpw);
-    HIPCHK(h, hipGetLastError());
-    return RCG_OK;
+      ok = launch_dma<Sys, real, 2>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);
+    if (!ok) prof_give_back(h, pp);
+    if (ok) {  // (otherwise - unreachable for the rows dma_ok admits - k_actor below serves the tick: never refused half-way)
+      note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA, variant, (int)gpw);
+      HIPCHK(h, hipGetLastError());
+      return RCG_OK;
+    }
   }
 #define RCG_LAUNCH_ACTOR(GEN, TGT, STR) \
   RCG_LAUNCH(h, (k_actor<Sys, real, GEN, TGT, STR>), dim3(blocks), dim3(64 * wpb), lds, A, P)

@@ -192,7 +192,25 @@ class DeviceArray:
             N.check(N.lib().rcg_memcpy_d2h(self.engine._h, out.ctypes.data, self.ptr, self.nbytes), self.engine._h)
         return out
 
+    def rows(self, a: int, b: int) -> "DeviceArray":
+        """Rows ``[a, b)`` along the first axis as a view (pointer offset; the view owns nothing and must not outlive
+        this array)."""
+        a, b = int(a), int(b)
+        if not (0 <= a <= b <= self.shape[0]):
+            raise IndexError(f"rows [{a}, {b}) of an array with {self.shape[0]}")
+        v = DeviceArray.__new__(DeviceArray)
+        v.engine, v.dtype, v.scratch, v._cap = self.engine, self.dtype, False, 0
+        v.shape = (b - a,) + self.shape[1:]
+        row_bytes = self.nbytes // self.shape[0] if self.shape[0] else 0
+        v.nbytes = (b - a) * row_bytes
+        v.ptr = (self.ptr + a * row_bytes) if self.ptr else None
+        v._view_of = self
+        return v
+
     def free(self):
+        if getattr(self, "_view_of", None) is not None:  # a view: nothing to release
+            self.ptr = None
+            return
         e = self.engine
         if self.ptr and e._h:
             if self._cap and e._pool_bytes + self._cap <= self.POOL_MAX_TOTAL:
@@ -269,6 +287,12 @@ class Engine:
         needed when a device-resident input was written on a stream other than the handle's - e.g. torch's current
         stream while the handle runs on a stream of its own.  No host synchronisation."""
         N.check(N.lib().rcg_wait_stream(self._h, C.c_void_p(producer_stream_ptr or 0)), self._h)
+
+    def release_stream(self, consumer_stream_ptr: Optional[int]):
+        """The reverse edge of :meth:`wait_stream` (rcg_release_stream): work queued on ``consumer_stream`` from now on
+        waits for everything this handle has launched so far - before another stream overwrites or frees a device-resident
+        input this handle's kernels may still be reading.  No host synchronisation."""
+        N.check(N.lib().rcg_release_stream(self._h, C.c_void_p(consumer_stream_ptr or 0)), self._h)
 
     # ------------------------------------------------------------------ device memory
     def empty(self, shape, dtype=None) -> DeviceArray:

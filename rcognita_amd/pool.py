@@ -100,30 +100,53 @@ class MixedPool:
         for s in self.segments:
             s.engine.set_state(states[s.name][s.off:s.off + (s.hi - s.lo)])
 
+    def _type_rows(self, name: str) -> int:
+        return sum(s.hi - s.lo for s in self.segments if s.name == name)
+
     def control_tick(self, K: int, cand: Optional[Dict[str, object]] = None, producer_stream: Optional[int] = 0,
                      ordered: bool = False):
         """One env.control-step for every env of the pool: generated level grid of K candidates, or per-type
-        candidate tensors ``cand[name] [n_local, K, N, du]``.
+        candidate tensors ``cand[name] [n_local, K, N, du]`` (numpy, torch or :class:`DeviceArray`; ``n_local`` = this
+        rank's envs of that type, whatever ``parts`` is).
 
         Stream ordering of device-resident candidates: the segments run on streams of their own, which nothing orders
-        against the stream the caller WROTE ``cand`` on.  So whenever ``cand`` holds device tensors, every segment first
-        waits (on the device, ``rcg_wait_stream``) for the work queued so far on ``producer_stream`` - a raw HIP stream
-        handle; the default 0 is the legacy default stream; with torch, pass
-        ``torch.cuda.current_stream().cuda_stream``.  ``ordered=True``: the caller has already ordered the tensors
-        (an earlier tick waited, or it synchronised) and the wait is skipped."""
+        against the stream the caller WRITES ``cand`` on.  Both directions matter and both are handled here, on the device,
+        without a host wait:
+          * producer -> segments: every segment first waits (``rcg_wait_stream``) for the work queued so far on
+            ``producer_stream`` - a raw HIP stream handle; the default 0 is the legacy default stream; with torch, pass
+            ``torch.cuda.current_stream().cuda_stream``;
+          * segments -> producer: after its tick has been issued, every segment makes ``producer_stream`` wait for it
+            (``rcg_release_stream``), so a caller that REFILLS ``cand`` for the next tick on ``producer_stream``, or frees
+            it into a stream-ordered allocator (torch's caching allocator reuses a block on the stream it was allocated
+            on), cannot overwrite rows a segment is still reading.
+        ``ordered=True`` skips both edges: for a ``cand`` that is written once before the loop, kept alive and never
+        modified until :meth:`synchronize` (what bench.py's streamed regimes do)."""
         device_cand = cand is not None and any(not isinstance(c, np.ndarray) for c in cand.values())
         for s in self.segments:
             if device_cand and not ordered:
                 s.engine.wait_stream(producer_stream)
             c = None if cand is None else cand[s.name]
-            if c is not None and not (s.off == 0 and int(c.shape[0]) == s.hi - s.lo):
-                c = c[s.off:s.off + (s.hi - s.lo)]  # a type's tensor covers this rank's envs of that type: my rows
+            if c is not None:
+                n, n_type = s.hi - s.lo, self._type_rows(s.name)
+                rows = int(c.shape[0])
+                if rows != n_type:
+                    raise ValueError(f"cand[{s.name!r}] has {rows} rows, this rank holds {n_type} envs of that type")
+                if n != n_type:  # several handles per type: my rows of the type's tensor
+                    c = c.rows(s.off, s.off + n) if hasattr(c, "rows") else c[s.off:s.off + n]
             s.engine.control_tick(c, K=K)
+            if device_cand and not ordered:
+                s.engine.release_stream(producer_stream)
 
     def wait_stream(self, producer_stream: Optional[int] = 0):
         """Every segment's next launch waits for the work queued so far on ``producer_stream`` (see control_tick)."""
         for s in self.segments:
             s.engine.wait_stream(producer_stream)
+
+    def release_to(self, consumer_stream: Optional[int] = 0):
+        """``consumer_stream``'s next work waits for everything the segments have launched so far (the reverse edge of
+        :meth:`wait_stream`; see control_tick)."""
+        for s in self.segments:
+            s.engine.release_stream(consumer_stream)
 
     def synchronize(self):
         for s in self.segments:

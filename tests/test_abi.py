@@ -105,3 +105,15 @@ def test_documented_stub_matches_the_header(tmp_path):
     exe = tmp_path / "size"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     assert int(subprocess.check_output([str(exe)]).decode()) == ctypes.sizeof(doc)
+
+
+def test_the_binding_reads_no_environment_variable():
+    """the shipped binding used to honour RCG_LIB.  Tools bind another build explicitly
+    (rcognita_amd._native.use_library); nothing under rcognita_amd/ reads os.environ."""
+    import glob
+    import os
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rcognita_amd")
+    for path in glob.glob(os.path.join(root, "*.py")):
+        src = open(path).read()
+        assert "os.environ" not in src and "getenv" not in src, path

@@ -433,3 +433,54 @@ def test_one_system_cut_into_parts_equals_the_single_handle(name, mode, parts):
     assert tot["count"] == ref["count"] == B and tot["min"] == ref["min"] and tot["max"] == ref["max"]
     pool.close()
     one.close()
+
+
+@pytest.mark.parametrize("use_device_array", [False, True])
+def test_pool_with_candidates_refilled_every_tick(use_device_array):
+    """The candidate tensor is REWRITTEN before every tick on the producer's stream while the pool's segments run on
+    streams of their own: control_tick orders producer -> segments (rcg_wait_stream) AND segments -> producer
+    (rcg_release_stream), so tick t reads tick t's candidates and the refill for tick t + 1 cannot overtake a segment
+    that is still reading.  Checked against one handle driven on the producer's own stream (stream order = program order).
+    Large rows, long ticks and three parts make an unordered refill visible; a DeviceArray input (no torch) is sliced per
+    part as a view."""
+    import torch
+
+    from rcognita_amd import Engine, _native as N
+    from rcognita_amd.pool import MixedPool, preset_engine_config
+
+    rng = np.random.default_rng(7)
+    name, B, K, Nh, T, parts = "3wrobot", 8193, 128, 10, 6, 3
+    x0 = rand_states(rng, name, B).astype(np.float32)
+    bnds = np.array(PRESETS[name]["bnds"], dtype=np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    one = Engine(preset_engine_config(name, B, Nactor=Nh))
+    one.set_stream(stream)
+    one.set_state(x0)
+    pool = MixedPool({name: B}, Nactor=Nh, parts=parts)
+    pool.set_states({name: x0})
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    lo, w = torch.as_tensor(bnds[:, 0], device="cuda"), torch.as_tensor(bnds[:, 1] - bnds[:, 0], device="cuda")
+    cand_one = torch.empty((B, K, Nh, 2), device="cuda", dtype=torch.float32)
+    cand_pool = torch.empty_like(cand_one)
+    dev = pool.segments[0].engine.empty((B, K, Nh, 2)) if use_device_array else None
+    for t in range(T):
+        fresh = lo + w * torch.rand((B, K, Nh, 2), device="cuda", generator=gen)  # this tick's candidates
+        cand_one.copy_(fresh)
+        one.control_tick(cand_one, K=K)
+        cand_pool.copy_(fresh)  # overwrites what the segments read last tick: legal only behind the reverse edge
+        if use_device_array:
+            torch.cuda.current_stream().synchronize()
+            N.check(N.lib().rcg_memcpy_h2d(pool.segments[0].engine._h, dev.ptr, fresh.cpu().numpy().ctypes.data, dev.nbytes))
+            pool.synchronize()  # the upload ran on segment 0's stream: order the other segments behind it
+            pool.control_tick(K, {name: dev}, ordered=True)
+            pool.synchronize()  # ... and the next upload behind every segment
+        else:
+            pool.control_tick(K, {name: cand_pool}, producer_stream=stream)
+    pool.synchronize()
+    torch.cuda.synchronize()
+    for f in (N.FIELD_STATE, N.FIELD_ACTION, N.FIELD_ACCUM, N.FIELD_BEST_IDX, N.FIELD_BEST_J, N.FIELD_STEP_IDX):
+        np.testing.assert_array_equal(np.concatenate([s.engine.get_field(f) for s in pool.segments]), one.get_field(f))
+    with pytest.raises(ValueError, match="rows"):
+        pool.control_tick(K, {name: cand_pool[: B - 1]}, producer_stream=stream)
+    pool.close()
+    one.close()

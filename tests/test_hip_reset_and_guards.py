@@ -213,9 +213,10 @@ def test_device_inputs_are_checked_before_they_reach_a_kernel():
 
 def test_zero_weighted_component_overflow_convention():
     """A component that overflows under a ZERO stage-cost weight (Sys3WRobot's speed, R1 = diag[1, 10, 1, 0, 0, 0, 0]):
-    the streamed path evaluates the full sum like numpy - 0 * inf = NaN, the candidate counts as +inf, the reference's
-    own behaviour - while the generated grid never computes zero-weighted terms and keeps the finite cost of the weighted
-    ones (include/rcg.h, rcg_actor_argmin).  Both documented; identical whenever everything stays finite."""
+    numpy evaluates the full sum, 0 * inf = NaN, and the candidate counts as +inf - the reference's own behaviour.  The
+    streamed kernels compute that sum; the generated grid, which does not accumulate zero-weighted terms, tests the
+    zero-weighted state components on the observation and on the last rolled-out state instead: same outcome (round 3
+    kept a finite cost there)."""
     from oracle import rcg_oracle as O
     from rcognita_amd import Engine, _native as N
     from rcognita_amd.pool import preset_engine_config
@@ -235,6 +236,10 @@ def test_zero_weighted_component_overflow_convention():
     _, bj_str, _ = eng.actor_argmin(eng.to_device(cand), K=K)
     assert np.all(np.isfinite(bj_gen[[0, 3]]))
     np.testing.assert_allclose(bj_gen[[0, 3]], bj_str[[0, 3]], rtol=1e-6)  # finite envs: the same costs on both paths
-    assert np.all(np.isfinite(bj_gen[[1, 2]])), "generated grid: zero-weighted terms are not computed"
     assert np.all(np.isinf(bj_str[[1, 2]])), "streamed rows: 0 * inf = NaN = +inf for every candidate, as numpy"
+    assert np.all(np.isinf(bj_gen[[1, 2]])), "generated grid: the same"
+    # ... and T ticks in one launch (k_ticks runs the generated rollouts): the overflowing envs report +inf as well
+    eng.control_ticks(T=1, K=K)
+    bj_t = eng.get_field(N.FIELD_BEST_J)
+    assert np.all(np.isinf(bj_t[[1, 2]])) and np.all(np.isfinite(bj_t[[0, 3]]))
     eng.close()
