@@ -275,32 +275,97 @@ def cpu_baseline(args, seconds):
 REF_IN_BUILD_CONTAINER = {"reference_steps_per_s_per_core": 3.4, "ref_loop_steps_per_s_per_core": 3.3}
 
 
+def usable_cores():
+    """Host cores this process may really use: os.cpu_count() capped by the affinity mask and the cgroup CPU quota (a GPU
+    box hands a one-GPU job a share of the host's cores)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_reference_algorithm(args, seconds):
-    """The reference ALGORITHM on one host core: one env, SciPy RK45 + SLSQP over the oracle's operators
-    (oracle/ref_loop.py, pinned on traces captured from the reference).  Bounded by wall time."""
-    import numpy as np
-
-    from oracle.ref_loop import RefLoop
-
-    cfg = c2_oracle_cfg(args)
-    loop = RefLoop(cfg, np.array([5.0, 5.0, -3 * np.pi / 4, 0.0, 0.0]), t1=1e9)
+    """The reference ALGORITHM on the host cores, as BASELINE.md 4-1 prescribes it: one env per process - SciPy RK45 + SLSQP
+    over the oracle's operators (oracle/ref_loop.py, pinned on traces captured from the reference) - and P such
+    processes side by side, P = the cores this job may use; the aggregate and the per-core rate are both reported.
+    Bounded by wall time.  The workers never touch the GPU (numpy + scipy only)."""
+    P = usable_cores()
+    env = {k: v for k, v in os.environ.items()}
+    env.update(OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "oracle.ref_loop", "--seconds", str(seconds), "--nactor", str(args.nactor)]
     t0 = time.perf_counter()
-    ticks, last = 0, None
-    while time.perf_counter() - t0 < seconds:
-        row = loop.step()
-        act = tuple(row[1 + cfg.ds:1 + cfg.ds + cfg.du])
-        if last is not None and act != last:
-            ticks += 1
-        last = act
-    dt = time.perf_counter() - t0
+    procs = [subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(P)]
+    res = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=seconds * 4 + 120)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        if pr.returncode == 0 and lines:
+            res.append(json.loads(lines[-1]))
+    wall = time.perf_counter() - t0
+    if not res:
+        raise ImportError("no reference-algorithm worker finished (SciPy missing on this box?)")
+    rates = [r["ticks"] / r["seconds"] for r in res]
     cal = REF_IN_BUILD_CONTAINER
-    return {"value": ticks / dt, "unit": "env-control-steps/s", "cores": 1, "kind": "reference algorithm "
-            "(SciPy RK45 + SLSQP over the oracle's operators, preset main_3wrobot)",
-            "sample": f"1 env, {ticks} control ticks, {loop.nfev_actor} _actor_cost evaluations, {dt:.1f} s",
+    return {"value": float(sum(rates)), "unit": "env-control-steps/s", "cores": len(res),
+            "per_core": float(sum(rates) / len(rates)), "os_cpu_count": os.cpu_count(),
+            "kind": "reference algorithm (SciPy RK45 + SLSQP over the oracle's operators, preset main_3wrobot), one env "
+                    "per process",
+            "sample": f"{len(res)} processes x 1 env, {sum(r['ticks'] for r in res)} control ticks, "
+                      f"{sum(r['nfev_actor'] for r in res)} _actor_cost evaluations, {seconds:.0f} s each ({wall:.1f} s wall "
+                      "with interpreter start-up)",
             "calibration": {**cal, "ref_loop_over_reference": cal["ref_loop_steps_per_s_per_core"] /
                             cal["reference_steps_per_s_per_core"],
                             "note": "measured in the build container, where the reference can be imported; it cannot "
                                     "travel to this box"}}
+
+
+def parity_check_pool(args, device, stream_ptr, K, tol=1e-5, n_env=192, ticks=2):
+    """--config C5: the mixed pool's kernels (generated grid, one handle per system type) on fresh small handles of each
+    type, tick by tick against the CPU oracle (oracle/parity.py), same rule as parity_check."""
+    import numpy as np
+
+    from oracle import parity as PAR
+    from oracle import rcg_oracle as O
+    from rcognita_amd import Engine
+    from rcognita_amd import _native as N
+    from rcognita_amd.pool import PRESETS, preset_engine_config
+
+    rep = PAR.TickReport()
+    tol = tol if args.dtype == "f32" else 1e-11
+    real = np.float32 if args.dtype == "f32" else np.float64
+    out = {"ok": True, "tol": tol, "types": {}}
+    rng = np.random.default_rng(77)
+    for name, p in PRESETS.items():
+        eng = Engine(preset_engine_config(name, n_env, Nactor=args.nactor, dtype=args.dtype, device=device))
+        eng.set_stream(stream_ptr)
+        x0 = pool_states(rng, name, n_env)
+        eng.set_state(x0)
+        ocfg = O.OracleCfg(sys_id=p["sys_id"], n_actor=args.nactor, pars=p["pars"], ctrl_bnds=np.array(p["ctrl_bnds"]),
+                           R1=np.diag(np.array(p["R1"], dtype=float)), target=p["target"], dt_sim=p["dt"],
+                           sampling_time=p["dt"], pred_step_size=p["dt"] * p["mult"])
+        env = O.new_batch(ocfg, x0.astype(real).astype(np.float64))
+        cand_host = O.grid_candidates(ocfg, K)
+        try:
+            for t in range(ticks):
+                eng.control_tick(None, K=K)
+                env = PAR.check_tick(ocfg, env, cand_host, PAR.device_fields(eng, N, critic=False), tol=tol, report=rep,
+                                     what=f"bench parity {name} tick {t}")
+            out["types"][name] = {"ok": True, "kernel": eng.last_launch(N.KERNEL_ACTOR)["kernel"]}
+        except AssertionError as e:
+            out["ok"] = False
+            out["types"][name] = {"ok": False, "error": str(e)[:300]}
+        eng.close()
+    out.update(rep.as_dict())
+    return out
 
 
 def parity_check(args, device, stream_ptr, x0, cand, K, tol=1e-5, n_sample=64, ticks=2):
@@ -726,9 +791,11 @@ def main(argv=None):
     if traffic is not None and per_launch is not None:
         traffic *= len(engines)  # tick level, as `achieved`
     kinfo = launch_info[0]
+    width = "float32 storage and arithmetic (SURVEY 8a-1 / 8d; the reference computes in float64: value_f64 / roofline_f64)" \
+        if args.dtype == "f32" else "float64, the reference's width"
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
-              "candidates (BASELINE configs[1])",
+              f"candidates (BASELINE configs[1]); headline in {width}",
         "C3": f"Sys2Tank B={args.batch}/GPU RK4 dt=0.1 S=1, CtrlOptPred RQL Nactor={Nh} + quadratic critic TD fit every tick "
               f"(Ncritic=4, buffer 10), K={K} {args.regime} candidates (BASELINE configs[2])",
         "C4": f"Sys3WRobot {total_envs} envs sharded over {world} rank(s), RK4 dt=0.01, MPC Nactor={Nh}, K={K} "
@@ -750,6 +817,10 @@ def main(argv=None):
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
+        "value_definition": "total envs x K timed steps / (device time of the K steps, max over ranks, + K x allgather_ms / "
+                            f"{EPISODE_TICKS}): the design makes ONE exchange per {EPISODE_TICKS}-tick episode (SURVEY 8d, 8e); "
+                            "rounds 1-2 charged one exchange to the K steps and used the host clock between barriers - that "
+                            "figure is timing.value_k_steps_plus_one_exchange",
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": workload, "config": args.config, "envs_total": total_envs, "envs_rank0": B,
@@ -762,6 +833,7 @@ def main(argv=None):
         "timing": {"clock": "HIP events recorded in-stream around the K timed steps (device time, max over ranks)",
                    "ms_per_step_compute": step_ms_compute,
                    "value_compute_only": total_envs / (step_ms_compute * 1e-3),
+                   "value_k_steps_plus_one_exchange": units / ((compute_ms + allgather_ms) * 1e-3),
                    "allgather_ms": allgather_ms if dist is not None else None,
                    "episode_ticks": EPISODE_TICKS,
                    "allgather_ms_per_step": (allgather_ms / EPISODE_TICKS) if dist is not None else None,
@@ -831,8 +903,9 @@ def main(argv=None):
                                          "4-cycle wave64 issue model tops out at 3.9e13)",
                                "hbm_frac_for_completeness": hbm["frac"]}
 
-    if not args.no_parity and args.config != "C5":
-        out["parity"] = parity_check(args, local_rank, stream_ptr, x0, cand, K)
+    if not args.no_parity:
+        out["parity"] = (parity_check_pool(args, local_rank, stream_ptr, K) if args.config == "C5" else
+                         parity_check(args, local_rank, stream_ptr, x0, cand, K))
 
     if not args.no_secondary and world == 1 and args.config == "C2":
         out["secondary"] = secondary(args, local_rank, stream_ptr, x0, B, K, Nh, torch, Engine, N)
@@ -841,6 +914,16 @@ def main(argv=None):
                 out["secondary"]["two_handles"] = two_handles(args, local_rank, x0, cand, B, K, Nh, torch)
             except Exception as e:  # never let a secondary figure take the bench line down
                 out["secondary"]["two_handles"] = {"error": str(e)[:300]}
+
+    # the reference's arithmetic width next to the headline: the float64 run of the same tick
+    f64 = (out.get("secondary") or {}).get("f64")
+    if args.dtype == "f64":
+        out["value_f64"], out["roofline_f64"] = out["value"], {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    elif f64 and "env_control_steps_per_s" in f64:
+        out["value_f64"] = f64["env_control_steps_per_s"]
+        out["roofline_f64"] = dict(f64["roofline"], kernel=f64["kernel"], avg_launch_ms=f64["kernel_avg_ms"],
+                                   note="the same tick with float64 storage and arithmetic (the reference's width), "
+                                        "this run, secondary.f64")
 
     if not args.no_cpu_baseline and world == 1 and args.config == "C2":
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
@@ -965,6 +1048,56 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
     eng2.profile(False)
     sec["sim_step_only"] = {"env_steps_per_s_wall": B * n3 / d3, "kernel_avg_us": ms3 / max(c3, 1) * 1e3,
                             "kernel_GBps": B * ((3 * ds + du) * 4 + 4) / max(ms3 / max(c3, 1) * 1e-3, 1e-12) / 1e9}
+    # (2b) a closed loop whose candidates CHANGE every tick (the headline re-reads one static tensor).
+    #   device_search: k_actor_search - every lane generates its candidate row (Philox) where it evaluates it, the wave
+    #                  refines around the winner; nothing but state, action and cost touches HBM (VALU-bound);
+    #   produced_stream: the producer alone (k_cand_sample) writes this tick's [B][K][N][du] tensor, then the streamed tick
+    #                  reads it: 2 x 1.34 GB of HBM traffic per tick;
+    #   optimizer_tick: the on-device quasi-Newton optimiser as the decision (no candidates at all).
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
+    try:
+        nn = max(10, args.steps // 10)
+        ds_ = {}
+        for rounds in (1, 4):
+            dt_s = timed(lambda: eng2.control_tick_search(K=K, rounds=rounds, warm_start=True), nn)
+            ds_[f"rounds_{rounds}"] = {"env_control_steps_per_s": B / dt_s, "ms_per_step": dt_s * 1e3,
+                                       "actor_cost_evals_per_s": B * K * rounds / dt_s}
+        ds_["kernel"] = eng2.last_launch(N.KERNEL_ACTOR)["kernel"]
+        ds_["bound"] = "valu (Philox + Box-Muller + rollout per candidate; no candidate bytes in HBM)"
+        sec["device_search"] = ds_
+        if args.regime == "streamed":
+            td = torch.float32 if args.dtype == "f32" else torch.float64
+            cbuf = torch.empty((B, K, Nh, du), device="cuda", dtype=td)
+            torch.cuda.synchronize()
+
+            def produced():
+                eng2.candidates_sample(K, round=1, out=cbuf)
+                eng2.control_tick(cbuf, K=K)
+
+            dt_p = timed(produced, nn)
+            byt = 2 * B * K * Nh * du * (4 if args.dtype == "f32" else 8)
+            sec["produced_stream"] = {"env_control_steps_per_s": B / dt_p, "ms_per_step": dt_p * 1e3,
+                                      "hbm_GBps_candidates_written_and_read": byt / dt_p / 1e9,
+                                      "note": "k_cand_sample writes the tick's candidate tensor, k_actor_dma reads it back"}
+            del cbuf
+        ot = {}
+        for mem in (4, 0):
+            eng2.set_optimizer(mem)
+            dt_o = timed(lambda: eng2.control_tick_opt(iters=5, warm_start=True), nn)
+            ot[f"memory_{mem}"] = {"env_control_steps_per_s": B / dt_o, "ms_per_step": dt_o * 1e3, "iters": 5}
+        eng2.set_optimizer(4)
+        sec["optimizer_tick"] = ot
+    except Exception as e:  # never let a secondary figure take the bench line down
+        sec["device_search"] = {"error": str(e)[:300]}
     eng2.close()
     # (3) the reference's own arithmetic width: the same tick in float64 (streamed candidates, 2 x the bytes)
     if args.dtype == "f32" and args.regime == "streamed":

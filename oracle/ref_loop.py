@@ -176,3 +176,35 @@ class RefLoop:
             if self.solver.t >= self.t1:
                 break
         return np.stack(rows)
+
+
+def _worker_main(argv=None):
+    """``python -m oracle.ref_loop --seconds S --nactor N``: ONE env of the reference's algorithm on ONE core for S seconds
+    (the 3wrobot preset at the given horizon); prints one JSON line.  bench.py starts one of these per usable host core
+    for its ``cpu_baseline.reference_algorithm`` figure (one env per process, core count printed)."""
+    import argparse
+    import json
+    import time
+
+    p = argparse.ArgumentParser()
+    p.add_argument("--seconds", type=float, default=8.0)
+    p.add_argument("--nactor", type=int, default=10)
+    a = p.parse_args(argv)
+    cfg = O.OracleCfg(sys_id=O.SYS_3WROBOT, n_actor=a.nactor, pars=[10.0, 1.0],
+                      ctrl_bnds=np.array([[-300.0, 300.0], [-100.0, 100.0]]), R1=np.diag([1.0, 10.0, 1.0, 0, 0, 0, 0]),
+                      gamma=1.0, dt_sim=0.01, sampling_time=0.01, pred_step_size=0.02)
+    loop = RefLoop(cfg, np.array([5.0, 5.0, -3 * np.pi / 4, 0.0, 0.0]), t1=1e9)
+    t0 = time.perf_counter()
+    ticks, last = 0, None
+    while time.perf_counter() - t0 < a.seconds:
+        row = loop.step()
+        act = tuple(row[1 + cfg.ds:1 + cfg.ds + cfg.du])
+        if last is not None and act != last:
+            ticks += 1
+        last = act
+    dt = time.perf_counter() - t0
+    print(json.dumps({"ticks": ticks, "seconds": dt, "nfev_actor": loop.nfev_actor}))
+
+
+if __name__ == "__main__":
+    _worker_main()

@@ -160,6 +160,28 @@ def test_optimizer_in_the_critic_modes_vs_reference_slsqp(name, cs, mode, dtype)
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("name", SYSTEMS)
+def test_optimizer_on_every_decision_of_the_reference_mpc_loop(name, dtype):
+    """``mpc_tick_*`` of the F7c fixtures: every decision of the reference's own closed MPC loop - its observation, its
+    one-step-lagged state_sys, SLSQP's cost.  k_actor_opt (the MPC instance) ends within 0.5 % of SLSQP at every tick: the
+    per-decision anchor under the closed-loop bands of tests/test_hip_ref_traces.py."""
+    files = {"3wrobotNI": "F7c_trace_3wrobotNI_RQL_quad-nomix", "3wrobot": "F7c_trace_3wrobot_RQL_quad-nomix",
+             "2tank": "F7c_trace_2tank_RQL_quad-nomix"}
+    meta, z = load_golden(files[name])
+    B = z["mpc_tick_obs"].shape[0]
+    ai = [0.5] if name == "2tank" else None
+    eng, cfg = both(name, B, dtype, n_actor=meta["Nactor"], gamma=1.0, pred_step_size=meta["pred_step_size"],
+                    **({"action_init": ai} if ai else {}))
+    act, U, J, its = eng.actor_optimize(iters=30, obs=z["mpc_tick_obs"], state_sys=z["mpc_tick_state_sys"])
+    ll = assert_kernel(eng, "k_actor_opt")
+    assert not (ll["variant"] & 1), ll  # the MPC / diagonal instance
+    gap = (J - z["mpc_tick_J"]) / np.abs(z["mpc_tick_J"])
+    print(f"\nMPC ticks {name} {dtype}: J / J_slsqp - 1: median {np.median(gap):.2e} max {np.max(gap):.2e} over {B} decisions")
+    assert np.max(gap) < 5e-3
+    assert np.all(J <= z["mpc_tick_J_init"] * (1 + (1e-9 if dtype == "f64" else 1e-5)))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", SYSTEMS)
 @pytest.mark.parametrize("mode,stage", [("MPC", "full"), ("MPC", "biquad"), ("RQL", "full"), ("RQL", "biquad")])
 def test_optimizer_with_full_and_biquadratic_stage_costs(name, mode, stage, dtype):
     """A full (SPD) R1 and the biquadratic structure (controllers.py:1076-1082) through the generic instance: reported

@@ -123,3 +123,23 @@ def test_optimizer_reaches_reference_slsqp_cost_in_the_critic_modes(name, cs, mo
     if (name, cs, mode) in (("3wrobot", "quad-nomix", "RQL"), ("3wrobotNI", "quad-nomix", "RQL")):
         _, J0, _ = O.actor_optimize(cfg, z["obs"], z["state"], u0, iters=30, w_critic=z["w"], memory=0)
         assert np.max((J0 - z["J_opt"]) / np.abs(z["J_opt"])) > 2e-2
+
+
+MPC_TICK_FILES = {"3wrobotNI": "F7c_trace_3wrobotNI_RQL_quad-nomix", "3wrobot": "F7c_trace_3wrobot_RQL_quad-nomix",
+                  "2tank": "F7c_trace_2tank_RQL_quad-nomix"}
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_optimizer_on_every_decision_of_the_reference_mpc_loop(name):
+    """``mpc_tick_*`` of the F7c fixtures: every decision of the reference's own closed MPC loop (the state it had
+    reached, the one-step-lagged state_sys, SLSQP's sequence and cost).  A tighter anchor than the closed-loop bands of
+    the MPC traces: on the reference's own states the build's optimiser ends within 0.5 % of SLSQP at EVERY tick."""
+    meta, z = load_golden(MPC_TICK_FILES[name])
+    cfg = oracle_cfg(name, n_actor=meta["Nactor"], gamma=1.0, pred_step_size=meta["pred_step_size"])
+    u0 = O.action_sqn_init(cfg, [0.5] if name == "2tank" else None)
+    np.testing.assert_allclose(O.actor_cost(z["mpc_tick_action_sqn"], z["mpc_tick_obs"], z["mpc_tick_state_sys"], cfg),
+                               z["mpc_tick_J"], rtol=1e-11)
+    U, J, _ = O.actor_optimize(cfg, z["mpc_tick_obs"], z["mpc_tick_state_sys"], u0, iters=30)
+    assert np.all(J <= z["mpc_tick_J_init"] * (1 + 1e-12))
+    gap = (J - z["mpc_tick_J"]) / np.abs(z["mpc_tick_J"])
+    assert np.max(gap) < 5e-3, (np.median(gap), np.max(gap))
