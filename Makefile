@@ -69,6 +69,23 @@ $(LIBDIR)/librcg_dev.so: $(DEVOBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined $(DEVOBJS) -o $@
 
+# A/B build for tools/ab_lib.py: the same sources with extra defines (`make ab ABFLAGS="-DRCG_AB_..."`), linked as
+# rcognita_amd/lib/librcg_ab.so; never loaded by the package (a tool binds it with _native.use_library)
+ab: $(LIBDIR)/librcg_ab.so
+ABOBJDIR := $(ROOT)build/obj_ab
+ABOBJS   := $(call objs,$(ABOBJDIR))
+$(ABOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+	@mkdir -p $(ABOBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) $(DMAFLAGS) -c $< -o $@
+
+$(ABOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(ABOBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) -c $< -o $@
+
+$(LIBDIR)/librcg_ab.so: $(ABOBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,--no-undefined $(ABOBJS) -o $@
+
 # Sanitizer build (CPU only: GPU AddressSanitizer is not available on this pool).  --offload-host-only compiles the
 # host side of every .hip unit - the C ABI, argument checks, launch-geometry arithmetic - and drops the device code.
 asan: $(ASANDIR)/abi_asan
@@ -98,6 +115,6 @@ $(ASANDIR)/abi_asan: $(ASANOBJS) $(ASANDIR)/asan_driver.o $(ASANDIR)/no_device_i
 	$(HIPCC) $(SANFLAGS) $(ASANOBJS) $(ASANDIR)/asan_driver.o $(ASANDIR)/no_device_image.o -o $@ -lm
 
 clean:
-	rm -rf $(LIBDIR)/librcg.so $(LIBDIR)/librcg_dev.so $(OBJDIR) $(DEVOBJDIR) $(ASANDIR) $(ORACLE)/_build
+	rm -rf $(LIBDIR)/librcg.so $(LIBDIR)/librcg_dev.so $(LIBDIR)/librcg_ab.so $(OBJDIR) $(DEVOBJDIR) $(ABOBJDIR) $(ASANDIR) $(ORACLE)/_build
 
-.PHONY: all lib oracle dev asan clean
+.PHONY: all lib oracle dev ab asan clean

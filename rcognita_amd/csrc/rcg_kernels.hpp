@@ -392,9 +392,11 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     // components are tested once, on the observation and on the last rolled-out state (inf / NaN is sticky under
     // x += h f), so that a component that overflows under a zero weight disqualifies the candidate here as it does in
     // the streamed kernels.  (The skipped inputs are the grid's own bounded levels.)
+#ifndef RCG_AB_NO_ZWP
 #pragma unroll
     for (int i = 0; i < DS; ++i)
       if ((ZW >> i) & 1u) J = fma_r(P.R1d[i], y[i] * y[i], fma_r(P.R1d[i], y0[i] * y0[i], J));
+#endif
   }
   if (SUMF) {
 #pragma unroll
@@ -554,9 +556,11 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
 #pragma unroll
       for (int i = 0; i < NCHI; ++i)
         if (!((ZW >> i) & 1u)) J[c] = fma_r(P.R1d[i], S[c][G1 ? i : 0], J[c]);
+#ifndef RCG_AB_NO_ZWP
 #pragma unroll
       for (int i = 0; i < DS; ++i)  // zero-weighted state components: 0 * inf = NaN, as rollout_cost
         if ((ZW >> i) & 1u) J[c] = fma_r(P.R1d[i], y[c][i] * y[c][i], fma_r(P.R1d[i], y0[i] * y0[i], J[c]));
+#endif
     }
     Jout[c] = J[c];
   }

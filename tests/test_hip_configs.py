@@ -469,9 +469,8 @@ def test_pool_with_candidates_refilled_every_tick(use_device_array):
         one.control_tick(cand_one, K=K)
         cand_pool.copy_(fresh)  # overwrites what the segments read last tick: legal only behind the reverse edge
         if use_device_array:
-            torch.cuda.current_stream().synchronize()
-            N.check(N.lib().rcg_memcpy_h2d(pool.segments[0].engine._h, dev.ptr, fresh.cpu().numpy().ctypes.data, dev.nbytes))
-            pool.synchronize()  # the upload ran on segment 0's stream: order the other segments behind it
+            dev.upload(fresh.cpu().numpy())  # synchronous, on segment 0's stream
+            pool.synchronize()  # order the other segments behind it
             pool.control_tick(K, {name: dev}, ordered=True)
             pool.synchronize()  # ... and the next upload behind every segment
         else:
@@ -484,3 +483,67 @@ def test_pool_with_candidates_refilled_every_tick(use_device_array):
         pool.control_tick(K, {name: cand_pool[: B - 1]}, producer_stream=stream)
     pool.close()
     one.close()
+
+
+def test_C5_pool_sharded_eight_ways_equals_the_unsharded_pool():
+    """configs[4] by construction on one GPU: the mixed pool of 8 x 65536 + 5 envs (ragged: the 5 make the per-type
+    shards of the ranks differ by one env) as ONE pool, and as the 8 per-rank pools `shard_by_type` gives 8 ranks, run one
+    after the other here.  Every env's state comes from the job-wide table, so env g is the same env in both runs.  The
+    per-type concatenation of the ranks' per-env returns (what the ranks all_gather, in rank order) equals the unsharded
+    pool's bit for bit - with the device-side candidate search as the decision (k_actor_search: its Philox streams are keyed
+    by the GLOBAL env id, so this also checks env_id_base of every rank's handles) as well as with the generated grid -, the
+    merged 6-number summaries agree, counters exact."""
+    from rcognita_amd import _native as N
+    from rcognita_amd.parallel import merge_summaries, shard_by_type
+    from rcognita_amd.pool import MixedPool
+
+    world, T, K = 8, 2, 256
+    total = 65536 * world + 5
+    counts = {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
+    assert sum(counts.values()) == total
+    rng = np.random.default_rng(55)
+    job_states = {name: rand_states(rng, name, n).astype(np.float32) for name, n in counts.items()}
+
+    def run(pool, states, search):
+        pool.set_states(states)
+        for t in range(T):
+            if search:
+                for s in pool.segments:
+                    s.engine.control_tick_search(K=64, rounds=2, warm_start=True)
+            else:
+                pool.control_tick(K)
+        pool.synchronize()
+        out = {}
+        for s in pool.segments:
+            summ, ret = s.engine.episode_stats(from_accum=True, want_returns=True)
+            np.testing.assert_array_equal(s.engine.get_field(N.FIELD_STEP_IDX), np.full(s.hi - s.lo, T, np.int32))
+            out[s.name] = (summ, ret, s.engine.get_field(N.FIELD_ACTION))
+        return out
+
+    for search in (False, True):
+        whole_pool = MixedPool(counts, Nactor=15, dtype="f32", seed=9)
+        whole = run(whole_pool, job_states, search)
+        whole_pool.close()
+        rets = {name: [] for name in counts}
+        acts = {name: [] for name in counts}
+        summs = []
+        sizes = []
+        for r in range(world):
+            spans = shard_by_type(counts, r, world)
+            pool = MixedPool(counts, rank=r, world=world, Nactor=15, dtype="f32", seed=9)
+            for s in pool.segments:
+                assert (s.lo, s.hi) == spans[s.name] and s.engine.cfg.env_id_base == s.lo
+            sizes.append(pool.n_envs)
+            res = run(pool, {name: job_states[name][lo:hi] for name, (lo, hi) in spans.items()}, search)
+            for name, (summ, ret, act) in res.items():
+                rets[name].append(ret)
+                acts[name].append(act)
+                summs.append(summ)
+            pool.close()
+        assert sum(sizes) == total and max(sizes) - min(sizes) <= 3  # ragged: per-type shards differ by one env
+        for name in counts:
+            np.testing.assert_array_equal(np.concatenate(rets[name]), whole[name][1], err_msg=f"{name} search={search}")
+            np.testing.assert_array_equal(np.concatenate(acts[name]), whole[name][2])
+        m, w = merge_summaries(summs), merge_summaries([v[0] for v in whole.values()])
+        assert m["count"] == w["count"] == total and m["min"] == w["min"] and m["max"] == w["max"]
+        np.testing.assert_allclose(m["sum"], w["sum"], rtol=1e-9)

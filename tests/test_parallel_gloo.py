@@ -138,3 +138,107 @@ def test_gloo_sharded_run_equals_single_process(world, n_envs):
         assert total["min"] == ref.min() and total["max"] == ref.max()
         got = allr[~np.isnan(allr)]
         np.testing.assert_array_equal(got, ref)  # rank order == env order: sharding is a pure partition
+
+
+def _c5_counts(total):
+    return {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
+
+
+def _c5_state(name, g):
+    """Deterministic initial state of the job's env ``g`` of a type (a function of the global id only)."""
+    from tests.helpers import rand_states
+
+    return rand_states(np.random.default_rng([77, {"3wrobot": 0, "3wrobotNI": 1, "2tank": 2}[name], int(g)]), name, 1)[0]
+
+
+def _c5_env_return(name, g, ticks=2):
+    """The oracle as the engine: ``ticks`` control ticks of env ``g`` with the generated 16-candidate grid."""
+    from oracle import rcg_oracle as O
+    from tests.helpers import oracle_cfg
+
+    cfg = oracle_cfg(name, n_actor=4)
+    env = O.new_batch(cfg, _c5_state(name, g)[None])
+    cand = O.grid_candidates(cfg, 16)
+    for _ in range(ticks):
+        O.control_tick(cfg, env, cand)
+    return float(env.accum[0])
+
+
+def _c5_sample(lo, hi):
+    """Envs of a shard [lo, hi) that get computed: both ends (where ragged splits go wrong) and one in the middle."""
+    n = hi - lo
+    return sorted({lo + i for i in (0, 1, n // 2, n - 2, n - 1) if 0 <= i < n})
+
+
+def _worker_c5(rank, world, port, total, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts = _c5_counts(total)
+        spans = P.shard_by_type(counts, rank, world)
+        # this rank's per-env returns, types in sorted order (the pool's segment order), NaN = not computed here
+        local, summ_parts = [], []
+        for name in sorted(counts):
+            lo, hi = spans[name]
+            r = np.full(hi - lo, np.nan)
+            for g in _c5_sample(lo, hi):
+                r[g - lo] = _c5_env_return(name, g)
+            v = r[~np.isnan(r)]
+            summ_parts.append(dict(count=float(hi - lo), sum=float(v.sum()), sumsq=float((v * v).sum()), min=float(v.min()),
+                                   max=float(v.max()), n_failed=0.0))
+            local.append(r)
+        local = np.concatenate(local)
+        total_summ = P.gather_summaries(P.merge_summaries(summ_parts), dist)
+        width = max(sum(hi - lo for lo, hi in P.shard_by_type(counts, q_, world).values()) for q_ in range(world))
+        padded = np.full(width, np.nan)
+        padded[: len(local)] = local
+        allr = P.gather_returns(padded, dist)  # the episode-end exchange of configs[4]: ragged shards, padded payload
+        q.put((rank, total_summ, allr if rank == 0 else None, len(local)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world8_mixed_pool_with_ragged_totals():
+    """Pre-flight of the 8-rank run of configs[4] that no node has been available for: 8 gloo ranks, the job of 8 x 65536 + 5
+    envs sharded WITHIN each system type at full size (index arithmetic, payload widths and the padded all_gather are the
+    real ones: 4 MB), the oracle as each rank's engine on the envs at both ends and in the middle of every shard.  Rank 0
+    reassembles every type's global env order from the gathered payload and finds each computed env where the unsharded
+    job has it, with the value the single-process oracle gives."""
+    import torch.multiprocessing as mp
+
+    world, total = 8, 65536 * 8 + 5
+    counts = _c5_counts(total)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c5, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = [r[3] for r in results]
+    assert sum(sizes) == total and max(sizes) - min(sizes) <= 3
+    allr = results[0][2]
+    width = max(sizes)
+    assert allr.shape == (world * width,)
+    n_checked = 0
+    for rank in range(world):
+        spans = P.shard_by_type(counts, rank, world)
+        off = rank * width
+        for name in sorted(counts):
+            lo, hi = spans[name]
+            seg = allr[off:off + hi - lo]
+            for g in _c5_sample(lo, hi):
+                assert seg[g - lo] == _c5_env_return(name, g), (rank, name, g)
+                n_checked += 1
+            assert np.isnan(seg).sum() == (hi - lo) - len(_c5_sample(lo, hi))
+            off += hi - lo
+        assert np.all(np.isnan(allr[off:(rank + 1) * width]))  # the padding of a short shard
+    assert n_checked == world * 3 * 5
+    for _, summ, _, _ in results:  # every rank holds the same merged summary
+        assert summ["count"] == total and summ == results[0][1]
