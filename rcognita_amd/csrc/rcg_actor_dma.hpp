@@ -93,17 +93,6 @@ __host__ __device__ constexpr int dma_wslot(int esz, int variant, int ds, int du
   return dcmax > 9 ? ((dcmax * esz + 15) / 16) * 16 : 0;
 }
 
-// v_readlane of a real (the lane index is wave-uniform)
-__device__ __forceinline__ float readlane_r(float v, int l) {
-  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
-}
-__device__ __forceinline__ double readlane_r(double v, int l) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // wave argmin of (cost, index): lower cost wins, ties -> lower index; every lane ends with the winner's pair
 __device__ __forceinline__ void wave_argmin(float& bestJ, int& bestI) {
   const unsigned long long wkey = wave_min_u64(((unsigned long long)float_order_key(bestJ) << 32) | (unsigned)bestI);

@@ -343,6 +343,10 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
   for (int i = 0; i < NPHI; ++i) Phi[i] = 0;
 #pragma unroll
   for (int c = 0; c < DU; ++c) up[c] = 0;
+  real zw0 = 0;  // zero-weighted state components of the observation: 0, or NaN if one of them is not finite (see the end)
+#pragma unroll
+  for (int i = 0; i < DS; ++i)
+    if (G1 && ((ZW >> i) & 1u)) zw0 = fma_r(P.R1d[i], y0[i] * y0[i], zw0);
   for (int kk = 0; kk < N; ++kk) {
 #pragma unroll
     for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];
@@ -389,13 +393,14 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
     for (int i = 0; i < NCHI; ++i)
       if (!((ZW >> i) & 1u)) J = fma_r(P.R1d[i], S[G1 ? i : 0], J);  // fma(0, S_i, J) == J for finite S_i
     // ... and NaN for a non-finite S_i (0 * inf), which is what numpy's chi R1 chi gives the reference: the skipped state
-    // components are tested once, on the observation and on the last rolled-out state (inf / NaN is sticky under
-    // x += h f), so that a component that overflows under a zero weight disqualifies the candidate here as it does in
-    // the streamed kernels.  (The skipped inputs are the grid's own bounded levels.)
+    // components are tested once, on the observation (zw0, formed before the loop) and on the last rolled-out state
+    // (inf / NaN is sticky under x += h f), so that a component that overflows under a zero weight disqualifies the
+    // candidate here as it does in the streamed kernels.  (The skipped inputs are the grid's own bounded levels.)
 #ifndef RCG_AB_NO_ZWP
 #pragma unroll
     for (int i = 0; i < DS; ++i)
-      if ((ZW >> i) & 1u) J = fma_r(P.R1d[i], y[i] * y[i], fma_r(P.R1d[i], y0[i] * y0[i], J));
+      if ((ZW >> i) & 1u) J = fma_r(P.R1d[i], y[i] * y[i], J);
+    J += zw0;  // (exactly 0, or NaN: J is unchanged bit for bit whenever every zero-weighted component is finite)
 #endif
   }
   if (SUMF) {
@@ -492,6 +497,10 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
   const real h = P.h_pred;
   real x[NC][DS], y[NC][DS], u[NC][DU], J[NC], S[NC][G1 ? NCHI : 1];
   real gk = 1;
+  real zw0 = 0;  // as rollout_cost
+#pragma unroll
+  for (int i = 0; i < DS; ++i)
+    if (G1 && ((ZW >> i) & 1u)) zw0 = fma_r(P.R1d[i], y0[i] * y0[i], zw0);
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -559,17 +568,139 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
 #ifndef RCG_AB_NO_ZWP
 #pragma unroll
       for (int i = 0; i < DS; ++i)  // zero-weighted state components: 0 * inf = NaN, as rollout_cost
-        if ((ZW >> i) & 1u) J[c] = fma_r(P.R1d[i], y[c][i] * y[c][i], fma_r(P.R1d[i], y0[i] * y0[i], J[c]));
+        if ((ZW >> i) & 1u) J[c] = fma_r(P.R1d[i], y[c][i] * y[c][i], J[c]);
+      J[c] += zw0;
 #endif
     }
     Jout[c] = J[c];
   }
 }
 
+// ---- hand-packed form of rollout_mpc_gen_multi<Sys, float, false, true, 4, Sys::ZW_PRESET> ---------------------------
+// What the measurements said (tools/valu_rate.hip on MI355X, profiles/r04_valu_rate.txt): one wave issues one vector
+// instruction per ~5.5 cycles whether it is v_fma_f32 or v_pk_fma_f32, and a SIMD reaches the 2-cycle v_fma_f32 rate only
+// with 8 waves resident - at the 3-4 waves per SIMD these register-heavy rollouts run at, a packed instruction delivers
+// 0.91 of the lane peak where scalar ones deliver 0.73.  hipcc's SLP vectoriser already packed the multi-candidate rollout,
+// but around the value-aliasing trick above: 64 vector instructions per step of four candidates, 19 of them moves that
+// build register pairs, shared quantities computed per candidate and discarded, 125-135 VGPRs.  Written out with the two
+// candidates of a pair in the two halves of an ext-vector and the shared heading sub-trajectory computed once, the same
+// step is 26 instructions (15 packed) in 40 VGPRs.  Every component goes through the operation sequence of
+// rollout_cost<MPC, 0, -1, G1, ZW_PRESET> - fma for fma, product for product - so the costs are the same bits
+// (tests/test_hip_knobs.py: RCG_NO_GEN_MULTI, which runs the scalar form, hashes identically).
+template <typename Sys>
+struct GenPk {
+  static constexpr bool supported = false;
+};
+template <>
+struct GenPk<Sys3WRobot> {  // state (x, y, alpha, v, omega), inputs (F, M); candidates share M, hence alpha and omega
+  static constexpr bool supported = true;
+  __device__ __forceinline__ static void run(const KParams<float>& P, const Sys3WRobot::Pre<float>& pre, int N,
+                                             const float* xs, const float* y0, const float* u0v, float u1, float* Jout) {
+    const float h = P.h_pred;
+    v2f X[2], Y[2], V[2], S0[2], S1[2], D3[2];
+    float al = xs[2], om = xs[4];
+    float S2 = fma_r(y0[2], y0[2], 0.0f);
+    const float d4 = pre.inv_I * u1;
+    const float zw0 = fma_r(P.R1d[4], y0[4] * y0[4], fma_r(P.R1d[3], y0[3] * y0[3], 0.0f));
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      X[p] = pk_splat(xs[0]);
+      Y[p] = pk_splat(xs[1]);
+      V[p] = pk_splat(xs[3]);
+      S0[p] = pk_splat(fma_r(y0[0], y0[0], 0.0f));
+      S1[p] = pk_splat(fma_r(y0[1], y0[1], 0.0f));
+      D3[p] = pk_splat(pre.inv_m) * v2f{u0v[2 * p], u0v[2 * p + 1]};
+    }
+    for (int kk = 1; kk < N; ++kk) {
+      float s, c;
+      sincos_hw(al, &s, &c);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const v2f d0 = V[p] * pk_splat(c), d1 = V[p] * pk_splat(s);
+        X[p] = pk_fma(pk_splat(h), d0, X[p]);
+        Y[p] = pk_fma(pk_splat(h), d1, Y[p]);
+        V[p] = pk_fma(pk_splat(h), D3[p], V[p]);
+      }
+      const float aln = fma_r(h, om, al);
+      om = fma_r(h, d4, om);
+      al = aln;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        S0[p] = pk_fma(X[p], X[p], S0[p]);
+        S1[p] = pk_fma(Y[p], Y[p], S1[p]);
+      }
+      S2 = fma_r(al, al, S2);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      v2f J = pk_fma(pk_splat(P.R1d[0]), S0[p], pk_splat(0.0f));
+      J = pk_fma(pk_splat(P.R1d[1]), S1[p], J);
+      J = pk_fma(pk_splat(P.R1d[2]), pk_splat(S2), J);
+#ifndef RCG_AB_NO_ZWP
+      // the zero-weighted state components (v, omega): 0 * inf = NaN, as rollout_cost (J itself is untouched, bit for
+      // bit, whenever they are finite: the additions are of exact zeros)
+      const v2f vl = N > 1 ? V[p] : pk_splat(y0[3]);
+      const float ol = N > 1 ? om : y0[4];
+      J = pk_fma(pk_splat(P.R1d[3]), vl * vl, J);
+      J = J + pk_splat(fma_r(P.R1d[4], ol * ol, zw0));
+#endif
+      Jout[2 * p] = J.x;
+      Jout[2 * p + 1] = J.y;
+    }
+  }
+};
+template <>
+struct GenPk<Sys3WRobotNI> {  // state (x, y, alpha), inputs (v, omega); candidates share omega, hence alpha
+  static constexpr bool supported = true;
+  __device__ __forceinline__ static void run(const KParams<float>& P, const Sys3WRobotNI::Pre<float>&, int N,
+                                             const float* xs, const float* y0, const float* u0v, float u1, float* Jout) {
+    const float h = P.h_pred;
+    v2f X[2], Y[2], U0[2], S0[2], S1[2];
+    float al = xs[2];
+    float S2 = fma_r(y0[2], y0[2], 0.0f);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      X[p] = pk_splat(xs[0]);
+      Y[p] = pk_splat(xs[1]);
+      U0[p] = v2f{u0v[2 * p], u0v[2 * p + 1]};
+      S0[p] = pk_splat(fma_r(y0[0], y0[0], 0.0f));
+      S1[p] = pk_splat(fma_r(y0[1], y0[1], 0.0f));
+    }
+    for (int kk = 1; kk < N; ++kk) {
+      float s, c;
+      sincos_hw(al, &s, &c);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const v2f d0 = U0[p] * pk_splat(c), d1 = U0[p] * pk_splat(s);
+        X[p] = pk_fma(pk_splat(h), d0, X[p]);
+        Y[p] = pk_fma(pk_splat(h), d1, Y[p]);
+      }
+      al = fma_r(h, u1, al);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        S0[p] = pk_fma(X[p], X[p], S0[p]);
+        S1[p] = pk_fma(Y[p], Y[p], S1[p]);
+      }
+      S2 = fma_r(al, al, S2);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      v2f J = pk_fma(pk_splat(P.R1d[0]), S0[p], pk_splat(0.0f));
+      J = pk_fma(pk_splat(P.R1d[1]), S1[p], J);
+      J = pk_fma(pk_splat(P.R1d[2]), pk_splat(S2), J);
+      Jout[2 * p] = J.x;
+      Jout[2 * p + 1] = J.y;
+    }
+  }
+};
+
 // Tiles t .. t + NC - 1 of the generated grid for this lane through rollout_mpc_gen_multi, folded into the lane's
 // running (bestJ, bestI, bestU) in candidate order.  Requires one env per wave (K >= 64), du = 2 and 64 % g == 0, so
 // that candidate k + 64 has the same second level as candidate k.
-template <typename Sys, typename real, bool TGT, int NC>
+// PKONLY: the hand-packed rollout and nothing else - the caller (a kernel instance that exists for this one regime) has
+// checked gamma == 1, the preset's zero weights, float, no target: the register budget of that instance is the packed
+// rollout's (the instances that carry every variant need 125-235 VGPRs).
+template <typename Sys, typename real, bool TGT, int NC, bool PKONLY = false>
 __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
                                                 int K, int g, int t, int lane, bool env_ok, const real* xs,
                                                 const real* y0, real& bestJ, int& bestI, real* bestU) {
@@ -581,7 +712,10 @@ __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const ty
     gen_candidate<2, real>(P, g, k0 + 64 * c, ua[c]);
     u0v[c] = ua[c][0];
   }
-  if (P.gamma == (real)1)  // wave-uniform
+  if constexpr (PKONLY) {
+    static_assert(std::is_same<real, float>::value && !TGT && NC == 4 && GenPk<Sys>::supported, "see GenPk");
+    GenPk<Sys>::run(P, pre, N, xs, y0, u0v, ua[0][1], J);  // the same bits, two candidates per instruction
+  } else if (P.gamma == (real)1)  // wave-uniform
   {
     if (Sys::ZW_PRESET != 0u && (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET)  // wave-uniform, see rollout_dispatch
       rollout_mpc_gen_multi<Sys, real, TGT, true, NC, Sys::ZW_PRESET>(P, pre, N, xs, y0, u0v, ua[0][1], J);
@@ -612,8 +746,12 @@ __device__ __forceinline__ real accum_update(const KParams<real>& P, const real*
   return fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, accum);
 }
 
-template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM>
-__global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
+// PKONLY (generated level grid, float, MPC with the preset's diagonal R1 and gamma == 1, no target, K a multiple of 256
+// with 64 % g == 0 - the launcher checks all of it): the instance holds the hand-packed four-tile rollout alone.
+// (the instances without the generic cost structures ask for 4 waves per SIMD, i.e. <= 128 VGPRs: the generated-grid
+// instance sits at 125-129 registers depending on details, and the step from 4 to 3 resident waves costs it 15 %)
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false>
+__global__ __launch_bounds__(256, (GENERIC || sizeof(real) > 4) ? 1 : 4) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -669,6 +807,11 @@ __global__ __launch_bounds__(256) void k_actor(const ActorArgs<real> A, const KP
   const bool multi_ok = !STREAM && !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 &&
                         (64 % A.grid_g) == 0 && !A.no_multi;
   for (int t = 0; t < A.n_tiles; ++t) {
+    if constexpr (PKONLY) {
+      gen_multi_tiles<Sys, real, TGT, 4, true>(P, pre, N, K, A.grid_g, t, lane, env_ok, xs, y0, bestJ, bestI, bestU);
+      t += 3;
+      continue;
+    }
     if constexpr (!STREAM && !GENERIC && DU == 2 && Sys::SHARED_U1 != 0) {
       if (multi_ok && t + 4 <= A.n_tiles) {
         gen_multi_tiles<Sys, real, TGT, 4>(P, pre, N, K, A.grid_g, t, lane, env_ok, xs, y0, bestJ, bestI, bestU);
@@ -905,9 +1048,10 @@ struct TicksArgs {
   int n_sub;            // RK4 substeps per tick
   int K, Kp, G, n_tiles, grid_g;  // as ActorArgs
   int no_multi;                   // as ActorArgs
+  int gpw;                        // k_ticks_pk: consecutive envs per wave
 };
 
-template <typename Sys, typename real, bool GENERIC, bool TGT>
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool PKONLY = false>
 __global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU;
   const int lane = threadIdx.x & 63;
@@ -952,6 +1096,11 @@ __global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KP
     const bool multi_ok = !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 && (64 % A.grid_g) == 0 &&
                           !A.no_multi;
     for (int tl = 0; tl < A.n_tiles; ++tl) {  // k_actor, generated candidates
+      if constexpr (PKONLY) {
+        gen_multi_tiles<Sys, real, TGT, 4, true>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
+        tl += 3;
+        continue;
+      }
       if constexpr (!GENERIC && DU == 2 && Sys::SHARED_U1 != 0) {
         if (multi_ok && tl + 4 <= A.n_tiles) {
           gen_multi_tiles<Sys, real, TGT, 4>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
@@ -994,6 +1143,86 @@ __global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KP
     A.status[b] = st;
     A.best_J[b] = bestJ;
     A.best_idx[b] = bestI;
+  }
+}
+
+// k_ticks for the regime every preset benchmark runs, around the hand-packed rollout (GenPk): float, MPC with the preset's
+// diagonal R1 (its zero weights) and gamma == 1, no target, K = g * g a multiple of 256 with 64 % g == 0.  Same arithmetic as
+// k_ticks<..., PKONLY> - env_substeps, GenPk::run, accum_update - and the same results bit for bit; what differs is the
+// shell.  A wave owns `gpw` consecutive envs and keeps env e in LANE e: state, held action, accum, counters are loaded
+// once (coalesced), the env step of a tick runs for all of the wave's envs at once (lane = env: one RK4 per wave and tick
+// instead of one per env in all 64 lanes - in k_ticks the redundant env step is 40 % of a K = 256 tick), then the wave decides
+// env after env: the env's state is read out of its lane (v_readlane), the 4 x 64 candidates are rolled out two per
+// instruction, the argmin is DPP + readlane on the packed (cost, index) key instead of 6 x 4 ds_bpermute, the winner's
+// action is regenerated from its index and written back into the env's lane.  Every field is stored once, coalesced.
+template <typename Sys>
+__global__ __launch_bounds__(256, 4) void k_ticks_pk(const TicksArgs<float> A, const KParams<float> P) {
+  constexpr int DS = Sys::DS, DU = Sys::DU;
+  static_assert(DU == 2 && GenPk<Sys>::supported, "see GenPk");
+  const int lane = threadIdx.x & 63;
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+  const long B = P.B;
+  const int K = A.K, N = P.n_actor, gpw = A.gpw;
+  const long env0 = wave * gpw;
+  if (env0 >= B) return;  // wave-uniform
+  const int ne = (int)((B - env0) < gpw ? (B - env0) : gpw);
+  const bool mine = lane < ne;         // this lane holds env (env0 + lane)
+  const long bm = env0 + (mine ? lane : 0);
+
+  float x[DS], xp[DS], u[DU];
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    x[c] = A.state[(long)c * B + bm];
+    xp[c] = A.state_prev[(long)c * B + bm];
+  }
+#pragma unroll
+  for (int c = 0; c < DU; ++c) u[c] = A.action[(long)c * B + bm];
+  const auto pre = load_pre<Sys, float>(P, A.pars_env, bm);
+  uint32_t st = A.status[bm];
+  float accum = A.accum[bm];
+  int32_t steps = A.step_idx[bm];
+  float myJ = inf_r<float>();
+  int myI = 0x7fffffff;
+
+  for (int t = 0; t < A.T; ++t) {
+    if (mine) env_substeps<Sys, float, false>(P, pre, A.n_sub, x, xp, u, st, accum);  // k_sim, lane = env
+    for (int e = 0; e < ne; ++e) {  // the decision of env e, by the whole wave
+      float ye[DS], xse[DS];
+#pragma unroll
+      for (int c = 0; c < DS; ++c) {
+        ye[c] = readlane_r(x[c], e);
+        xse[c] = P.ref_lag ? readlane_r(xp[c], e) : ye[c];  // rcg_control_tick's state_sys
+      }
+      const auto pre_e = A.pars_env ? Sys::template bcast<float>(pre, e) : pre;
+      float bestJ = inf_r<float>();
+      int bestI = 0x7fffffff;
+      float bestU[DU] = {0, 0};
+      for (int tl = 0; tl < A.n_tiles; tl += 4)
+        gen_multi_tiles<Sys, float, false, 4, true>(P, pre_e, N, K, A.grid_g, tl, lane, true, xse, ye, bestJ, bestI, bestU);
+      const unsigned long long key = wave_min_u64(((unsigned long long)float_order_key(bestJ) << 32) | (unsigned)bestI);
+      if (lane == e) {  // receive_action (held until the next tick), upd_accum_obj, the tick counter: in the env's lane
+        myJ = float_from_order_key((unsigned)(key >> 32));
+        myI = (int)(unsigned)key;
+        gen_candidate<DU, float>(P, A.grid_g, myI, u);
+        if (!P.accum_every_substep) accum = accum_update<Sys, false, float>(P, x, u, accum);
+        steps += 1;
+      }
+    }
+  }
+  if (mine) {  // one coalesced write per field for the envs of this wave
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+      A.state[(long)c * B + bm] = x[c];
+      A.state_prev[(long)c * B + bm] = xp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < DU; ++c) A.action[(long)c * B + bm] = u[c];
+    A.accum[bm] = accum;
+    A.step_idx[bm] = steps;
+    A.status[bm] = st;
+    A.best_J[bm] = myJ;
+    A.best_idx[bm] = myI;
   }
 }
 

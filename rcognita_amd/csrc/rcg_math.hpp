@@ -96,6 +96,13 @@ __device__ __forceinline__ void sincos_sel<float, true>(float x, float* s, float
   sincos_hw(x, s, c);
 }
 
+// Two float lanes of work per instruction: ext-vector arithmetic that hipcc selects as v_pk_mul_f32 / v_pk_fma_f32 (a scalar
+// operand is a splat: op_sel on a register, or an SGPR pair).  Component-wise IEEE: pk_fma({a, b}, ...) rounds each
+// component exactly as v_fma_f32 does, so a packed rollout reproduces the scalar one bit for bit.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float s) { return v2f{s, s}; }
+
 // typed fused multiply-add (NB: __builtin_fma is the double form; on float operands it would
 // silently promote the whole expression to f64)
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -153,5 +160,17 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
   const unsigned long long a = r[1] < r[0] ? r[1] : r[0], b = r[3] < r[2] ? r[3] : r[2];
   return b < a ? b : a;
 }
+
+// v_readlane of a real (the lane index is wave-uniform)
+__device__ __forceinline__ float readlane_r(float v, int l) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+__device__ __forceinline__ double readlane_r(double v, int l) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 
 }  // namespace rcg

@@ -208,6 +208,7 @@ static int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, 
 //   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
 //   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor      RCG_NO_GEN_MULTI=1  generated tiles one at a time
 //   RCG_NO_PACK=1           streamed K < 40 on k_actor instead of the packed-tile k_actor_dma instances
+//   RCG_NO_PK=1             generated grid / k_ticks without the hand-packed instances (scalar-form rollouts, same bits)
 // tests/test_hip_knobs.py checks (on librcg_dev.so) that the scheduling variants reproduce the default launch bit for
 // bit, and that the production library ignores every one of them; bench.py refuses to run with any RCG_* variable set.
 struct DevKnobs {
@@ -223,6 +224,8 @@ struct DevKnobs {
   bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL and SQL go to k_actor (A/B against the critic instances)
   bool no_gen_multi = false;  // RCG_NO_GEN_MULTI=1: generated tiles one at a time (no shared sub-trajectory)
   bool no_pack = false;
+  bool no_tick_fuse = false;  // RCG_NO_TICK_FUSE=1: generated-grid tick as k_sim + k_actor (packed instance) instead of k_ticks_pk
+  bool no_pk = false;  // RCG_NO_PK=1: generated grid on the instances that carry every variant (A/B of the packed rollout)
 };
 static inline const DevKnobs& dev_knobs() {
   static const DevKnobs k = [] {
@@ -238,11 +241,16 @@ static inline const DevKnobs& dev_knobs() {
     v.no_gen_multi = getenv("RCG_NO_GEN_MULTI") != nullptr;
     v.no_g1 = getenv("RCG_NO_G1") != nullptr;
     v.no_pack = getenv("RCG_NO_PACK") != nullptr;
+    v.no_pk = getenv("RCG_NO_PK") != nullptr;
+    v.no_tick_fuse = getenv("RCG_NO_TICK_FUSE") != nullptr;
 #endif
     return v;
   }();
   return k;
 }
+
+template <typename Sys>
+static int op_ticks(rcg_handle* h, int32_t T, int32_t K);
 
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
 // `sim_first`: rcg_control_tick (MPC) - run the env step of the tick before the decision.
@@ -343,6 +351,16 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool pack_ok = cand && ((uintptr_t)cand % 16) == 0 && pack_g >= 2 && slab16 && R <= dma_max_row<real>() &&
                        P.stage_kind == 0 && c.mode == RCG_MODE_MPC && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
                        !knobs.no_pack;
+  // rcg_control_tick with the generated grid in the regime of the hand-packed rollout: env step and decision in ONE launch
+  // (k_ticks_pk with T = 1 - what rcg_control_ticks runs, so the two entry points cannot differ by a bit)
+  if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported) {
+    if (tick && sim_first && !cand && !generic && !tgt && c.gamma == 1.0 && Sys::ZW_PRESET != 0u &&
+        (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 && A.grid_g > 0 &&
+        (64 % A.grid_g) == 0 && !A.no_multi && !knobs.no_pk && !knobs.no_tick_fuse && !(c.flags & RCG_FLAG_DISTURB) && !obs &&
+        !state_sys &&
+        action == h->f[RCG_FIELD_ACTION] && best_J == h->f[RCG_FIELD_BEST_J] && (void*)best_idx == h->f[RCG_FIELD_BEST_IDX])
+      return op_ticks<Sys>(h, 1, K);
+  }
   // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
   if (sim_first) {
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
@@ -421,6 +439,20 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     if (!ok) prof_give_back(h, pp);
     if (ok) {  // (otherwise - unreachable for the rows dma_ok admits - k_actor below serves the tick: never refused half-way)
       note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA, variant, (int)gpw);
+      HIPCHK(h, hipGetLastError());
+      return RCG_OK;
+    }
+  }
+  // Generated level grid in the regime every preset benchmark runs (float, MPC, the preset's diagonal R1 with its zero
+  // weights, gamma == 1, no target, K = g * g a multiple of 256 with 64 % g == 0): the instance that holds the hand-packed
+  // four-tile rollout and nothing else (rcg_kernels.hpp::GenPk)
+  if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported) {
+    const bool pk_ok = !cand && !generic && !tgt && c.gamma == 1.0 && Sys::ZW_PRESET != 0u &&
+                       (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 && A.grid_g > 0 &&
+                       (64 % A.grid_g) == 0 && !A.no_multi && !knobs.no_pk;
+    if (pk_ok) {
+      RCG_LAUNCH(h, (k_actor<Sys, real, false, false, false, true>), dim3(blocks), dim3(64 * wpb), lds, A, P);
+      note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR, 8, A.G);  // variant bit 3: the packed instance
       HIPCHK(h, hipGetLastError());
       return RCG_OK;
     }
@@ -633,6 +665,24 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
     const bool generic = P.stage_kind != 0;
     const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+    if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported) {
+      const bool pk_ok = !generic && !tgt && c.gamma == 1.0 && Sys::ZW_PRESET != 0u &&
+                         (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 &&
+                         (64 % A.grid_g) == 0 && !A.no_multi && !dev_knobs().no_pk;
+      if (pk_ok) {  // the kernel around the hand-packed rollout (k_ticks_pk): several envs per wave
+        // envs per wave: a power of two <= 8 that leaves >= 16384 waves (four rounds of the ~4000 resident ones), so that a
+        // wave's loads, its argmin and its stores are amortised without unbalancing the launch
+        int gpw = 1;
+        while (gpw < 8 && c.batch / (gpw * 2) >= 16384) gpw *= 2;
+        if (dev_knobs().gpw > 0 && dev_knobs().gpw <= 64) gpw = (int)dev_knobs().gpw;
+        A.gpw = gpw;
+        const long pw = ((long)c.batch + gpw - 1) / gpw;
+        RCG_LAUNCH(h, (k_ticks_pk<Sys>), dim3((unsigned)((pw + 3) / 4)), block, 0, A, P);
+        note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_TICKS, 8, gpw);
+        HIPCHK(h, hipGetLastError());
+        return (int)RCG_OK;
+      }
+    }
     if (generic && tgt)
       RCG_LAUNCH(h, (k_ticks<Sys, real, true, true>), grid, block, 0, A, P);
     else if (generic)

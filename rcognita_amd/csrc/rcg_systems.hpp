@@ -29,6 +29,11 @@ struct Sys3WRobot {
   __device__ __forceinline__ static Pre<real> prepare(const real* p) {
     return {(real)1 / p[0], (real)1 / p[1]};
   }
+  // lane `l`'s Pre in every lane (l wave-uniform): kernels that keep one env per lane and decide with the whole wave
+  template <typename real>
+  __device__ __forceinline__ static Pre<real> bcast(const Pre<real>& q, int l) {
+    return {readlane_r(q.inv_m, l), readlane_r(q.inv_I, l)};
+  }
   template <typename real, bool HW = false>
   __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {
     real s, c;
@@ -67,6 +72,10 @@ struct Sys3WRobotNI {
   __device__ __forceinline__ static Pre<real> prepare(const real*) {
     return {};
   }
+  template <typename real>
+  __device__ __forceinline__ static Pre<real> bcast(const Pre<real>&, int) {
+    return {};
+  }
   template <typename real, bool HW = false>
   __device__ __forceinline__ static void rhs(const Pre<real>&, const real* x, const real* u, real* d) {
     real s, c;
@@ -101,6 +110,10 @@ struct Sys2Tank {
   template <typename real>
   __device__ __forceinline__ static Pre<real> prepare(const real* p) {
     return {(real)1 / p[0], (real)1 / p[1], p[2], p[3], p[4]};
+  }
+  template <typename real>
+  __device__ __forceinline__ static Pre<real> bcast(const Pre<real>& q, int l) {
+    return {readlane_r(q.inv_tau1, l), readlane_r(q.inv_tau2, l), readlane_r(q.K1, l), readlane_r(q.K2, l), readlane_r(q.K3, l)};
   }
   template <typename real, bool HW = false>
   __device__ __forceinline__ static void rhs(const Pre<real>& q, const real* x, const real* u, real* d) {

@@ -35,9 +35,10 @@ def main():
         h.update(np.ascontiguousarray(eng.get_field(f)).tobytes())
     # generated level grid on both robots, K = 256 (four tiles per lane: rolled out together with the shared heading
     # sub-trajectory unless RCG_NO_GEN_MULTI is set), single ticks and T ticks per launch
-    for name in ("3wrobot", "3wrobotNI"):
+    # (3wrobot and the second 3wrobotNI run, gamma = 1 with the preset's R1: the hand-packed instances unless RCG_NO_PK)
+    for name, gamma in (("3wrobot", 1.0), ("3wrobotNI", 0.97), ("3wrobotNI", 1.0)):
         B3 = 777
-        e3 = Engine(preset_engine_config(name, B3, Nactor=7, gamma=0.97 if name == "3wrobotNI" else 1.0))
+        e3 = Engine(preset_engine_config(name, B3, Nactor=7, gamma=gamma))
         ds = 5 if name == "3wrobot" else 3
         e3.set_state(rng.uniform(-3, 3, (B3, ds)).astype(np.float32))
         for _ in range(3):

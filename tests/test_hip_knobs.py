@@ -37,7 +37,8 @@ def test_scheduling_variants_are_bit_identical():
                           ({"RCG_GPW": "16", "RCG_PER_CU": "4"}, "LAUNCH k_actor_dma 0 16"),
                           ({"RCG_GPW": "3", "RCG_PER_CU": "8"}, "LAUNCH k_actor_dma 0 3"),  # not a power of two
                           ({"RCG_NO_G1": "1"}, None),             # the discounted instance with gamma = 1 (rounding differs)
-                          ({"RCG_NO_GEN_MULTI": "1"}, prod_launch)):  # generated tiles one at a time: same bits per candidate
+                          ({"RCG_NO_GEN_MULTI": "1"}, prod_launch),  # generated tiles one at a time: same bits per candidate
+                          ({"RCG_NO_PK": "1"}, prod_launch)):  # generated grid / k_ticks without the hand-packed instances
         got, got_launch = _run(knobs, dev=True)
         if launch is None:
             assert got_launch == "LAUNCH k_actor_dma 1 4", (knobs, got_launch)
@@ -51,6 +52,6 @@ def test_the_production_library_ignores_every_knob():
     (rcg_last_launch) nor a single output bit."""
     prod = _run({}, dev=False)
     loud = _run({"RCG_ACTOR_KERNEL": "plain", "RCG_GPW": "3", "RCG_PER_CU": "8", "RCG_NO_G1": "1", "RCG_DBG": "7",
-                 "RCG_LDS_PAD": "-1", "RCG_DMA_MPC_ONLY": "1", "RCG_NO_GEN_MULTI": "1", "RCG_PLAIN_LDS": "65536"},
+                 "RCG_LDS_PAD": "-1", "RCG_DMA_MPC_ONLY": "1", "RCG_NO_GEN_MULTI": "1", "RCG_PLAIN_LDS": "65536", "RCG_NO_PK": "1"},
                 dev=False)
     assert loud == prod

@@ -4,10 +4,11 @@ come from interleaved rounds on ONE device - devices differ by up to 12 % on VAL
 
     make ab ABFLAGS="-DRCG_AB_..."          # rcognita_amd/lib/librcg_ab.so
     python tools/ab_lib.py [--a lib/librcg.so] [--b lib/librcg_ab.so] [--rounds 3] [workload ...]
+    python tools/ab_lib.py --a rcognita_amd/lib/librcg_dev.so --b rcognita_amd/lib/librcg_dev.so --b-env RCG_NO_PK=1 gen ticks
 
 Workloads (median / min of the per-launch durations the dispatches carry, us):
   gen      generated 256-level grid, C2 shape (k_actor)          gen_c3   2tank N = 20 RQL generated
-  opt0/opt4 k_actor_opt, C2 shape, 5 iterations, memory 0 / 4    ticks    k_ticks B = 1024, K = 64, T = 64
+  opt0/opt4 k_actor_opt, C2 shape, 5 iterations, memory 0 / 4    ticks    k_ticks B = 1024, K = 64, T = 64 (ticks256: K = 256)
   search   k_actor_search C2 shape, one round                    fit      k_critic_fit, configs[2] in closed loop
   stream   k_actor_dma, C2 (the headline kernel)                 sql      streamed SQL quad-lin (VALU-bound instance)
 """
@@ -21,7 +22,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ALL = ["gen", "gen_c3", "opt0", "opt4", "ticks", "search", "fit", "stream", "sql"]
+ALL = ["gen", "gen_c3", "opt0", "opt4", "ticks", "ticks256", "search", "fit", "stream", "sql"]
 
 
 def child(lib, workload):
@@ -68,12 +69,12 @@ def child(lib, workload):
         step = lambda: eng.control_tick(None, K=K)
         if workload == "fit":
             kind = N.KERNEL_CRITIC
-    elif workload == "ticks":
+    elif workload in ("ticks", "ticks256"):
         B = 1024
         eng = Engine(preset_engine_config("3wrobot", B, Nactor=Nh))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.set_state(st3(B))
-        step = lambda: eng.control_ticks(T=64, K=64)
+        step = lambda: eng.control_ticks(T=64, K=256 if workload == "ticks256" else 64)
     else:
         raise SystemExit(f"unknown workload {workload}")
     for _ in range(150):
@@ -91,6 +92,8 @@ def main():
     p.add_argument("--a", default=os.path.join(ROOT, "rcognita_amd", "lib", "librcg.so"))
     p.add_argument("--b", default=os.path.join(ROOT, "rcognita_amd", "lib", "librcg_ab.so"))
     p.add_argument("--rounds", type=int, default=3)
+    p.add_argument("--a-env", default="", help="KEY=VAL[,KEY=VAL] set for the A children (dev-build knobs: RCG_NO_PK=1 ...)")
+    p.add_argument("--b-env", default="", help="the same for the B children")
     p.add_argument("--child", nargs=2, default=None)
     p.add_argument("workloads", nargs="*", default=["gen"])
     a = p.parse_args()
@@ -100,9 +103,11 @@ def main():
     for w in (ALL if a.workloads == ["all"] else a.workloads):
         res = {"A": [], "B": []}
         for _ in range(a.rounds):
-            for tag, lib in (("A", a.a), ("B", a.b)):
+            for tag, lib, extra in (("A", a.a, a.a_env), ("B", a.b, a.b_env)):
+                cenv = dict(env)
+                cenv.update(kv.split("=", 1) for kv in extra.split(",") if kv)
                 out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib, w], capture_output=True,
-                                     text=True, env=env, timeout=900)
+                                     text=True, env=cenv, timeout=900)
                 line = [l for l in out.stdout.splitlines() if l.startswith("RES ")]
                 if not line:
                     print(w, tag, "FAILED", out.stderr[-400:], flush=True)
