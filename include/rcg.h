@@ -247,21 +247,23 @@ int rcg_actor_argmin(rcg_handle* h, const void* cand, int32_t K, const void* obs
  * STEP_IDX += 1.  cand as rcg_actor_argmin. */
 int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
 /* T consecutive rcg_control_tick(h, NULL, K) - the loop of presets/main_3wrobot.py:415-468 for T sampling periods with
- * the generated candidate grid - in ONE kernel launch: each env's wave keeps state, held action, ACCUM and STEP_IDX in
- * registers and loops over {sim_step, K x _actor_cost, argmin, upd_accum_obj}.  Every field ends bit-identical to T
- * single ticks on the library as built (same source expressions; tests/test_hip_ticks.py checks it for every system,
- * element type and shape).  Across compilers the contract is "within rounding" for Sys2Tank: its rollout right-hand side
- * leaves the choice of fused multiply-adds to the compiler (18-26 % faster than the written-out form), and k_ticks and
- * k_actor inline it at different call sites; the robots' right-hand sides and every simulator step write their fusions
- * out.  A checkpoint taken under one entry point and resumed under the other inherits the same caveat.
- * BEST_J / BEST_IDX are the last tick's.  MPC without the disturbance model; other
- * handles get RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of small batches. */
+ * the generated candidate grid - in ONE kernel launch: each env's wave keeps state, held action, ACCUM and STEP_IDX (and,
+ * with the disturbance model, the disturbance state and the noise counter) in registers and loops over {sim_step, K x
+ * _actor_cost, argmin, upd_accum_obj}.  Every field ends bit-identical to T single ticks on the library as built (same
+ * source expressions; tests/test_hip_ticks.py checks it for every system, element type and shape).  Across compilers the
+ * contract is "within rounding" for Sys2Tank: its rollout right-hand side leaves the choice of fused multiply-adds to the
+ * compiler (18-26 % faster than the written-out form), and k_ticks and k_actor inline it at different call sites; the robots'
+ * right-hand sides and every simulator step write their fusions out.  A checkpoint taken under one entry point and resumed
+ * under the other inherits the same caveat.  BEST_J / BEST_IDX are the last tick's.  MPC handles (any stage-cost structure,
+ * with or without RCG_FLAG_DISTURB); RQL / SQL handles get RCG_ERR_UNSUPPORTED and loop rcg_control_tick (their critic fit
+ * sits between the env step and the decision).  Removes the launch-bound regime of small batches. */
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* T consecutive rcg_control_tick(h, cand, K) issued by ONE call: the loop of presets/main_3wrobot.py:415-468 for T sampling
- * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode - 2 (MPC) launches per
- * tick as rcg_control_tick makes them, without T trips through the caller's FFI: a Python caller needs ~12 us per call, and a
- * GPU that idles between short ticks clocks down (measured, streamed K = 64: B = 4096 102 us per tick from a Python loop, 9.6 us
- * here; B = 1024 11.7 -> 7.3 us).  Identical to T single calls; stops at the first error. */
+ * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode.  MPC handles of up to
+ * 16384 envs run them as ONE launch (k_ticks; a caller's tensor: the wave's candidate rows are staged into LDS once and
+ * re-walked T times); larger batches and RQL / SQL issue the launches of T single ticks without T trips through the
+ * caller's FFI (a Python caller needs ~12 us per call, and a GPU that idles between short ticks clocks down).  Either way
+ * every field ends as T single calls leave it, bit for bit; stops at the first error. */
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);
 /* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398) for every mode
  * (MPC / RQL / SQL, controllers.py:1304-1326; RQL / SQL read the handle's W_CRITIC), stage-cost structure (diagonal or

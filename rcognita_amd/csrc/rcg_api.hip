@@ -629,9 +629,23 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
   return rc;
 }
 
+// Batches up to this size are launch-bound under per-tick launches (two launches of a few microseconds of work each):
+// rcg_control_tick_n runs their T ticks in one persistent launch when the handle's mode allows it
+static const int kPersistentTicksMaxBatch = 16384;
+
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T) {
   if (!h) return RCG_ERR_BAD_ARG;
   if (T < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_tick_n: T must be >= 1");
+  if (T > 1 && h->cfg.mode == RCG_MODE_MPC && h->cfg.batch <= kPersistentTicksMaxBatch) {
+    // MPC (any stage-cost structure, with or without the disturbance model): k_ticks keeps the env in registers and, for a
+    // caller's tensor, the wave's candidate rows in LDS - every field ends as T single ticks leave it, bit for bit
+    DeviceGuard dev_guard(h);
+    int rc = check_candidates(h, "rcg_control_tick_n", cand, K);
+    if (rc) return rc;
+    rc = h->sys->ticks(h, T, K, cand);
+    if (rc == RCG_OK) h->tick_count += T;
+    return rc;
+  }
   for (int32_t t = 0; t < T; ++t) {
     const int rc = rcg_control_tick(h, cand, K);
     if (rc) return rc;
@@ -648,9 +662,7 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K) {
   if (h->cfg.mode != RCG_MODE_MPC)
     return rcg_fail(h, RCG_ERR_UNSUPPORTED,
                     "rcg_control_ticks: MPC only (RQL/SQL refit the critic between ticks: loop rcg_control_tick)");
-  if (h->cfg.flags & RCG_FLAG_DISTURB)
-    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: not with the disturbance model (loop rcg_control_tick)");
-  rc = h->sys->ticks(h, T, K);
+  rc = h->sys->ticks(h, T, K, nullptr);
   if (rc == RCG_OK) h->tick_count += T;
   return rc;
 }

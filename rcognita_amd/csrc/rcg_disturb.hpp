@@ -141,14 +141,68 @@ struct SimDistArgs {
   DisturbPars D;
 };
 
+// Simulator.sim_step x n_sub on the full state [state, disturb] of one env held in registers (shared by k_sim_dist and
+// k_ticks): the env_substeps of a handle with RCG_FLAG_DISTURB.  A frozen env is not stepped; a non-finite result freezes
+// the env at its last finite state (nothing is updated, the noise counter included) and sets the bit.
+template <typename Sys, typename real, bool TGT>
+__device__ __forceinline__ bool env_substeps_dist(const KParams<real>& P, const DisturbPars& D,
+                                                  const typename Sys::template Pre<real>& pre, int n_sub, int64_t env_id,
+                                                  int32_t ep, real* x, real* xp, real* q, int32_t& sub, const real* a_held,
+                                                  uint32_t& st, real& accum) {
+  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, DD = Disturb<Sys>::DD;
+  if (st & 1u) return false;  // frozen env
+  real u[DU], xn[DS], xq[DS], qn[DD];
+#pragma unroll
+  for (int c = 0; c < DU; ++c) u[c] = P.clip ? clamp_r<real>(a_held[c], P.lo[c], P.hi[c]) : a_held[c];  // systems.py:241-243
+#pragma unroll
+  for (int c = 0; c < DS; ++c) xq[c] = xn[c] = x[c];
+#pragma unroll
+  for (int c = 0; c < DD; ++c) qn[c] = q[c];
+  int32_t subn = sub;
+  real acc = 0;
+  for (int s = 0; s < n_sub; ++s) {
+#pragma unroll
+    for (int c = 0; c < DS; ++c) xq[c] = xn[c];
+    double xd[2];
+    normals_from_bits(noise_bits(D.seed, env_id, ep, subn), xd);
+    const real xi[2] = {(real)xd[0], (real)xd[1]};
+    rk4_step_full<Sys, real>(pre, D, xn, qn, u, xi, P.dt_sim);
+    subn += 1;
+    if (P.accum_every_substep) {
+      real chi[NCHI];
+      make_chi<DS, DU, TGT, real>(P, xn, u, chi);
+      acc = fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, acc);
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < DS; ++c) ok = ok && finite_r<real>(xn[c]);
+#pragma unroll
+  for (int c = 0; c < DD; ++c) ok = ok && finite_r<real>(qn[c]);
+  if (!ok) {
+    st |= 1u;
+    return false;
+  }
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    x[c] = xn[c];
+    xp[c] = xq[c];
+  }
+#pragma unroll
+  for (int c = 0; c < DD; ++c) q[c] = qn[c];
+  sub = subn;
+  if (P.accum_every_substep) accum += acc;
+  return true;
+}
+
 // k_sim for a handle with RCG_FLAG_DISTURB: same contract, full state [state, disturb]
 template <typename Sys, typename real, bool TGT>
 __global__ __launch_bounds__(256) void k_sim_dist(const SimDistArgs<real> A, const KParams<real> P) {
-  constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, DD = Disturb<Sys>::DD;
+  constexpr int DS = Sys::DS, DU = Sys::DU, DD = Disturb<Sys>::DD;
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long B = P.B;
   if (b >= B) return;
-  const uint32_t st = A.S.status[b];
+  uint32_t st = A.S.status[b];
   if (st & 1u) return;  // frozen env
 
   real x[DS], xp[DS], u[DU], q[DD];
@@ -157,37 +211,13 @@ __global__ __launch_bounds__(256) void k_sim_dist(const SimDistArgs<real> A, con
 #pragma unroll
   for (int c = 0; c < DD; ++c) q[c] = A.disturb[(long)c * B + b];
 #pragma unroll
-  for (int c = 0; c < DU; ++c) {
-    const real a = A.S.action[(long)c * B + b];
-    u[c] = P.clip ? clamp_r<real>(a, P.lo[c], P.hi[c]) : a;  // systems.py:241-243
-  }
+  for (int c = 0; c < DU; ++c) u[c] = A.S.action[(long)c * B + b];
   const auto pre = load_pre<Sys, real>(P, A.S.pars_env, b);
-  const int32_t ep = A.episode_idx[b];
   int32_t sub = A.substep_idx[b];
-  real acc = 0;
-
-  for (int s = 0; s < A.S.n_sub; ++s) {
-#pragma unroll
-    for (int c = 0; c < DS; ++c) xp[c] = x[c];
-    double xd[2];
-    normals_from_bits(noise_bits(A.D.seed, A.D.env_id_base + b, ep, sub), xd);
-    const real xi[2] = {(real)xd[0], (real)xd[1]};
-    rk4_step_full<Sys, real>(pre, A.D, x, q, u, xi, P.dt_sim);
-    sub += 1;
-    if (P.accum_every_substep) {
-      real chi[NCHI];
-      make_chi<DS, DU, TGT, real>(P, x, u, chi);
-      acc = fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, acc);
-    }
-  }
-
-  bool ok = true;
-#pragma unroll
-  for (int c = 0; c < DS; ++c) ok = ok && finite_r<real>(x[c]);
-#pragma unroll
-  for (int c = 0; c < DD; ++c) ok = ok && finite_r<real>(q[c]);
-  if (!ok) {
-    A.S.status[b] = st | 1u;
+  real accum = P.accum_every_substep ? A.S.accum[b] : (real)0;
+  if (!env_substeps_dist<Sys, real, TGT>(P, A.D, pre, A.S.n_sub, A.D.env_id_base + b, A.episode_idx[b], x, xp, q, sub, u,
+                                        st, accum)) {
+    A.S.status[b] = st;  // became non-finite: frozen at its last finite state, nothing else is written
     return;
   }
 #pragma unroll
@@ -198,7 +228,7 @@ __global__ __launch_bounds__(256) void k_sim_dist(const SimDistArgs<real> A, con
 #pragma unroll
   for (int c = 0; c < DD; ++c) A.disturb[(long)c * B + b] = q[c];
   A.substep_idx[b] = sub;
-  if (P.accum_every_substep) A.S.accum[b] += acc;
+  if (P.accum_every_substep) A.S.accum[b] = accum;
 }
 
 // unit operator: closed_loop_rhs on the full state for n points, noise given

@@ -199,7 +199,7 @@ struct SysVTable {
                   void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick, bool sim_first);
   int (*nominal)(rcg_handle*, const void* obs, void* action, void* lyap, void* theta, int32_t n, double gain,
                  const double* ctrl_pars, int32_t clip, bool tick);
-  int (*ticks)(rcg_handle*, int32_t T, int32_t K);
+  int (*ticks)(rcg_handle*, int32_t T, int32_t K, const void* cand);
   int (*rhs_full)(rcg_handle*, const void* state, const void* disturb, const void* action, const void* xi, void* dstate,
                   void* ddisturb, void* clipped, int32_t n, int32_t clip);
   int (*search)(rcg_handle*, int32_t K, int32_t rounds, int32_t round0, const void* obs, const void* state_sys,

@@ -737,17 +737,20 @@ __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const ty
   }
 }
 
-// upd_accum_obj (controllers.py:1086-1093): accum + rho(obs, action) * sampling_time, one rounding
+// upd_accum_obj (controllers.py:1086-1093): accum_obj_val += stage_obj(obs, action) * sampling_time - the product rounded,
+// then the sum rounded, as numpy evaluates the reference's statement and as the streamed production kernels do (their
+// sum is a no-return atomic add of the rounded product).  The contraction to one fused multiply-add is switched off
+// here, so that every tick kernel of the library leaves the same ACCUM bits (rounds 1-3 fused it in k_actor / k_ticks).
 template <typename Sys, bool TGT, typename real>
 __device__ __forceinline__ real accum_update(const KParams<real>& P, const real* obs, const real* act, real accum) {
+#pragma clang fp contract(off)
   constexpr int NCHI = Sys::DS + Sys::DU;
   real chi[NCHI];
   make_chi<Sys::DS, Sys::DU, TGT, real>(P, obs, act, chi);
-  return fma_r(stage_any<NCHI, real>(P, chi), P.sampling_time, accum);
+  const real inc = stage_any<NCHI, real>(P, chi) * P.sampling_time;
+  return accum + inc;
 }
 
-// PKONLY (generated level grid, float, MPC with the preset's diagonal R1 and gamma == 1, no target, K a multiple of 256
-// with 64 % g == 0 - the launcher checks all of it): the instance holds the hand-packed four-tile rollout alone.
 // (the instances without the generic cost structures ask for 4 waves per SIMD, i.e. <= 128 VGPRs: the generated-grid
 // instance sits at 125-129 registers depending on details, and the step from 4 to 3 resident waves costs it 15 %)
 template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false>
@@ -1019,210 +1022,6 @@ __global__ __launch_bounds__(256) void k_sim_v(const SimArgs<real> A, const KPar
     } else if (!(stv[e] & 1u)) {
       A.status[b] = sto[e];  // became non-finite in this step: frozen at its last finite state
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_ticks: T control ticks in ONE launch, generated candidates (rcg_control_ticks)
-// ---------------------------------------------------------------------------------------------
-// Envs never interact, so a tick needs no grid-wide step: the wave that owns an env (or, K < 64, a segment of it) keeps
-// the env's state, held action, accum and counters in registers and loops `T` times over {Simulator.sim_step,
-// K x _actor_cost, argmin, upd_accum_obj}.  Every lane of the env's segment integrates the env step redundantly (~100
-// VALU ops next to K/seg rollouts of N steps each) - no cross-lane traffic, no LDS, no barrier - and the argmin
-// butterfly leaves the winner in every lane, which becomes the held action of the next tick.  The arithmetic is the code
-// k_sim and k_actor run (env_substeps, rollout_dispatch, segment_argmin, accum_update), so T ticks here equal T calls of
-// rcg_control_tick bit for bit.  What it removes is the launch-bound regime of small batches: two launches (~8 us) per
-// tick against ~1 us of work at B = 1024, K = 64.
-template <typename real>
-struct TicksArgs {
-  real* state;          // [ds][B] in/out
-  real* state_prev;     // [ds][B] in/out
-  real* action;         // [du][B] in/out: the held action (ZOH)
-  const real* pars_env; // [np][B] or nullptr
-  real* accum;          // [B] in/out
-  int32_t* step_idx;    // [B] in/out
-  uint32_t* status;     // [B] in/out
-  real* best_J;         // [B] out (last tick)
-  int32_t* best_idx;    // [B] out (last tick)
-  int T;                // ticks
-  int n_sub;            // RK4 substeps per tick
-  int K, Kp, G, n_tiles, grid_g;  // as ActorArgs
-  int no_multi;                   // as ActorArgs
-  int gpw;                        // k_ticks_pk: consecutive envs per wave
-};
-
-template <typename Sys, typename real, bool GENERIC, bool TGT, bool PKONLY = false>
-__global__ __launch_bounds__(256) void k_ticks(const TicksArgs<real> A, const KParams<real> P) {
-  constexpr int DS = Sys::DS, DU = Sys::DU;
-  const int lane = threadIdx.x & 63;
-  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
-  const long B = P.B;
-  const int K = A.K, N = P.n_actor;
-  if (wave * A.G >= B) return;  // wave-uniform: every wave that stays runs all T ticks and exits
-
-  const bool big = K >= 64;
-  const int seg = big ? 64 : A.Kp;
-  const int e = big ? 0 : lane / seg;
-  const int kl = big ? lane : lane - e * seg;
-  const long b_raw = wave * A.G + e;
-  const bool env_ok = b_raw < B;
-  const long b = env_ok ? b_raw : B - 1;
-
-  real x[DS], xp[DS], u[DU];
-#pragma unroll
-  for (int c = 0; c < DS; ++c) {
-    x[c] = A.state[(long)c * B + b];
-    xp[c] = A.state_prev[(long)c * B + b];
-  }
-#pragma unroll
-  for (int c = 0; c < DU; ++c) u[c] = A.action[(long)c * B + b];
-  const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
-  uint32_t st = A.status[b];
-  real accum = A.accum[b];
-  int32_t steps = A.step_idx[b];
-  auto wget = [&](int) -> real { return (real)0; };  // MPC: no critic
-  real bestJ = inf_r<real>();
-  int bestI = 0x7fffffff;
-
-  for (int t = 0; t < A.T; ++t) {
-    env_substeps<Sys, real, TGT>(P, pre, A.n_sub, x, xp, u, st, accum);  // k_sim
-    const real* const xs = P.ref_lag ? xp : x;                           // rcg_control_tick's state_sys
-    bestJ = inf_r<real>();
-    bestI = 0x7fffffff;
-    real bestU[DU];
-#pragma unroll
-    for (int c = 0; c < DU; ++c) bestU[c] = 0;
-    const bool multi_ok = !GENERIC && DU == 2 && Sys::SHARED_U1 != 0 && big && A.grid_g > 0 && (64 % A.grid_g) == 0 &&
-                          !A.no_multi;
-    for (int tl = 0; tl < A.n_tiles; ++tl) {  // k_actor, generated candidates
-      if constexpr (PKONLY) {
-        gen_multi_tiles<Sys, real, TGT, 4, true>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
-        tl += 3;
-        continue;
-      }
-      if constexpr (!GENERIC && DU == 2 && Sys::SHARED_U1 != 0) {
-        if (multi_ok && tl + 4 <= A.n_tiles) {
-          gen_multi_tiles<Sys, real, TGT, 4>(P, pre, N, K, A.grid_g, tl, lane, env_ok, xs, x, bestJ, bestI, bestU);
-          tl += 3;
-          continue;
-        }
-      }
-      const int k = big ? tl * 64 + kl : kl;
-      const bool valid = env_ok && k < K;
-      real ugen[DU], u0[DU];
-#pragma unroll
-      for (int c = 0; c < DU; ++c) ugen[c] = 0;
-      gen_candidate<DU, real>(P, A.grid_g, k, ugen);
-      const real J = rollout_dispatch<Sys, real, GENERIC, TGT, false>(P, pre, N, xs, x, nullptr, ugen, wget, u0);
-      const real Jc = (J != J) ? inf_r<real>() : J;
-      if (valid && (Jc < bestJ || bestI == 0x7fffffff)) {
-        bestJ = Jc;
-        bestI = k;
-#pragma unroll
-        for (int c = 0; c < DU; ++c) bestU[c] = u0[c];
-      }
-    }
-    segment_argmin<DU, real>(seg, bestJ, bestI, bestU);
-#pragma unroll
-    for (int c = 0; c < DU; ++c) u[c] = bestU[c];  // receive_action: held until the next tick
-    if (!P.accum_every_substep) accum = accum_update<Sys, TGT, real>(P, x, u, accum);
-    steps += 1;
-  }
-
-  if (kl == 0 && env_ok) {
-#pragma unroll
-    for (int c = 0; c < DS; ++c) {
-      A.state[(long)c * B + b] = x[c];
-      A.state_prev[(long)c * B + b] = xp[c];
-    }
-#pragma unroll
-    for (int c = 0; c < DU; ++c) A.action[(long)c * B + b] = u[c];
-    A.accum[b] = accum;
-    A.step_idx[b] = steps;
-    A.status[b] = st;
-    A.best_J[b] = bestJ;
-    A.best_idx[b] = bestI;
-  }
-}
-
-// k_ticks for the regime every preset benchmark runs, around the hand-packed rollout (GenPk): float, MPC with the preset's
-// diagonal R1 (its zero weights) and gamma == 1, no target, K = g * g a multiple of 256 with 64 % g == 0.  Same arithmetic as
-// k_ticks<..., PKONLY> - env_substeps, GenPk::run, accum_update - and the same results bit for bit; what differs is the
-// shell.  A wave owns `gpw` consecutive envs and keeps env e in LANE e: state, held action, accum, counters are loaded
-// once (coalesced), the env step of a tick runs for all of the wave's envs at once (lane = env: one RK4 per wave and tick
-// instead of one per env in all 64 lanes - in k_ticks the redundant env step is 40 % of a K = 256 tick), then the wave decides
-// env after env: the env's state is read out of its lane (v_readlane), the 4 x 64 candidates are rolled out two per
-// instruction, the argmin is DPP + readlane on the packed (cost, index) key instead of 6 x 4 ds_bpermute, the winner's
-// action is regenerated from its index and written back into the env's lane.  Every field is stored once, coalesced.
-template <typename Sys>
-__global__ __launch_bounds__(256, 4) void k_ticks_pk(const TicksArgs<float> A, const KParams<float> P) {
-  constexpr int DS = Sys::DS, DU = Sys::DU;
-  static_assert(DU == 2 && GenPk<Sys>::supported, "see GenPk");
-  const int lane = threadIdx.x & 63;
-  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
-  const long B = P.B;
-  const int K = A.K, N = P.n_actor, gpw = A.gpw;
-  const long env0 = wave * gpw;
-  if (env0 >= B) return;  // wave-uniform
-  const int ne = (int)((B - env0) < gpw ? (B - env0) : gpw);
-  const bool mine = lane < ne;         // this lane holds env (env0 + lane)
-  const long bm = env0 + (mine ? lane : 0);
-
-  float x[DS], xp[DS], u[DU];
-#pragma unroll
-  for (int c = 0; c < DS; ++c) {
-    x[c] = A.state[(long)c * B + bm];
-    xp[c] = A.state_prev[(long)c * B + bm];
-  }
-#pragma unroll
-  for (int c = 0; c < DU; ++c) u[c] = A.action[(long)c * B + bm];
-  const auto pre = load_pre<Sys, float>(P, A.pars_env, bm);
-  uint32_t st = A.status[bm];
-  float accum = A.accum[bm];
-  int32_t steps = A.step_idx[bm];
-  float myJ = inf_r<float>();
-  int myI = 0x7fffffff;
-
-  for (int t = 0; t < A.T; ++t) {
-    if (mine) env_substeps<Sys, float, false>(P, pre, A.n_sub, x, xp, u, st, accum);  // k_sim, lane = env
-    for (int e = 0; e < ne; ++e) {  // the decision of env e, by the whole wave
-      float ye[DS], xse[DS];
-#pragma unroll
-      for (int c = 0; c < DS; ++c) {
-        ye[c] = readlane_r(x[c], e);
-        xse[c] = P.ref_lag ? readlane_r(xp[c], e) : ye[c];  // rcg_control_tick's state_sys
-      }
-      const auto pre_e = A.pars_env ? Sys::template bcast<float>(pre, e) : pre;
-      float bestJ = inf_r<float>();
-      int bestI = 0x7fffffff;
-      float bestU[DU] = {0, 0};
-      for (int tl = 0; tl < A.n_tiles; tl += 4)
-        gen_multi_tiles<Sys, float, false, 4, true>(P, pre_e, N, K, A.grid_g, tl, lane, true, xse, ye, bestJ, bestI, bestU);
-      const unsigned long long key = wave_min_u64(((unsigned long long)float_order_key(bestJ) << 32) | (unsigned)bestI);
-      if (lane == e) {  // receive_action (held until the next tick), upd_accum_obj, the tick counter: in the env's lane
-        myJ = float_from_order_key((unsigned)(key >> 32));
-        myI = (int)(unsigned)key;
-        gen_candidate<DU, float>(P, A.grid_g, myI, u);
-        if (!P.accum_every_substep) accum = accum_update<Sys, false, float>(P, x, u, accum);
-        steps += 1;
-      }
-    }
-  }
-  if (mine) {  // one coalesced write per field for the envs of this wave
-#pragma unroll
-    for (int c = 0; c < DS; ++c) {
-      A.state[(long)c * B + bm] = x[c];
-      A.state_prev[(long)c * B + bm] = xp[c];
-    }
-#pragma unroll
-    for (int c = 0; c < DU; ++c) A.action[(long)c * B + bm] = u[c];
-    A.accum[bm] = accum;
-    A.step_idx[bm] = steps;
-    A.status[bm] = st;
-    A.best_J[bm] = myJ;
-    A.best_idx[bm] = myI;
   }
 }
 

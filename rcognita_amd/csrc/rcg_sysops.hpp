@@ -14,6 +14,7 @@
 #include "rcg_handle.hpp"
 #include "rcg_nominal.hpp"
 #include "rcg_search.hpp"
+#include "rcg_ticks.hpp"
 
 namespace rcg {
 
@@ -250,7 +251,7 @@ static inline const DevKnobs& dev_knobs() {
 }
 
 template <typename Sys>
-static int op_ticks(rcg_handle* h, int32_t T, int32_t K);
+static int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand);
 
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
 // `sim_first`: rcg_control_tick (MPC) - run the env step of the tick before the decision.
@@ -359,7 +360,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
         (64 % A.grid_g) == 0 && !A.no_multi && !knobs.no_pk && !knobs.no_tick_fuse && !(c.flags & RCG_FLAG_DISTURB) && !obs &&
         !state_sys &&
         action == h->f[RCG_FIELD_ACTION] && best_J == h->f[RCG_FIELD_BEST_J] && (void*)best_idx == h->f[RCG_FIELD_BEST_IDX])
-      return op_ticks<Sys>(h, 1, K);
+      return op_ticks<Sys>(h, 1, K, nullptr);
   }
   // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
   if (sim_first) {
@@ -625,9 +626,11 @@ static int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, c
   });
 }
 
-// rcg_control_ticks: T ticks with generated candidates in one launch (k_ticks).  The caller has checked mode / flags / K.
+// rcg_control_ticks / rcg_control_tick_n: T MPC ticks in one launch (k_ticks, k_ticks_pk; rcg_ticks.hpp), generated grid
+// (cand == nullptr) or the caller's candidate tensor, with or without the disturbance model.  The caller has checked
+// mode / K.
 template <typename Sys>
-static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
+static int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
   constexpr int DU = Sys::DU;
   const rcg_cfg& c = h->cfg;
   return by_dtype(h, [&](auto r) {
@@ -644,10 +647,18 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
     A.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
     A.best_J = (real*)h->f[RCG_FIELD_BEST_J];
     A.best_idx = (int32_t*)h->f[RCG_FIELD_BEST_IDX];
+    A.cand = (const real*)cand;
+    A.dist = (c.flags & RCG_FLAG_DISTURB) ? 1 : 0;
+    if (A.dist) {
+      A.disturb = (real*)h->f[RCG_FIELD_DISTURB];
+      A.substep_idx = (int32_t*)h->f[RCG_FIELD_SUBSTEP_IDX];
+      A.episode_idx = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
+      A.D = disturb_pars(h);
+    }
     A.T = T;
     A.n_sub = c.substeps_per_tick;
     A.K = K;
-    if (K >= 64) {  // the tiling of launch_actor for generated candidates
+    if (K >= 64) {  // the tiling of launch_actor
       A.Kp = 64;
       A.G = 1;
       A.n_tiles = (K + 63) / 64;
@@ -658,15 +669,29 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
       A.G = 64 / kp;
       A.n_tiles = 1;
     }
-    A.grid_g = DU == 1 ? K : (int)std::floor(std::sqrt((double)K) + 1e-9);
+    A.grid_g = cand ? 0 : (DU == 1 ? K : (int)std::floor(std::sqrt((double)K) + 1e-9));
     A.no_multi = dev_knobs().no_gen_multi ? 1 : 0;
     const long n_waves = (c.batch + A.G - 1) / A.G;
-    const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
     const bool generic = P.stage_kind != 0;
     const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
+    // streamed candidates: the wave's rows stay in LDS for all T ticks when they fit (32 KB per wave: four waves per block,
+    // one block per CU at worst), else they are re-staged tile by tile every tick (served by L2 / Infinity Cache at the
+    // batch sizes this entry point is for)
+    const int R = c.n_actor * DU;
+    const size_t row_bytes = (size_t)R * sizeof(real);
+    size_t lds = 0;
+    if (cand) {
+      const size_t rows_wave = K >= 64 ? (size_t)K : (size_t)A.G * K;
+      A.vec_ok = (row_bytes % 16 == 0 && ((uintptr_t)cand % 16) == 0) ? 1 : 0;
+      A.stage_once = rows_wave * row_bytes <= (size_t)32 * 1024 ? 1 : 0;
+      const size_t per_wave = (A.stage_once ? rows_wave : (size_t)64) * row_bytes;
+      A.lds_reals = (int)((per_wave + 15) / 16 * 16 / sizeof(real));
+      lds = (size_t)A.lds_reals * sizeof(real) * 4;
+    }
+    const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
     if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported) {
-      const bool pk_ok = !generic && !tgt && c.gamma == 1.0 && Sys::ZW_PRESET != 0u &&
+      const bool pk_ok = !cand && !A.dist && !generic && !tgt && c.gamma == 1.0 && Sys::ZW_PRESET != 0u &&
                          (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 &&
                          (64 % A.grid_g) == 0 && !A.no_multi && !dev_knobs().no_pk;
       if (pk_ok) {  // the kernel around the hand-packed rollout (k_ticks_pk): several envs per wave
@@ -683,15 +708,28 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K) {
         return (int)RCG_OK;
       }
     }
+#define RCG_TICKS(GEN, TGT)                                                             \
+  do {                                                                                  \
+    if (cand)                                                                           \
+      RCG_LAUNCH(h, (k_ticks<Sys, real, GEN, TGT, true>), grid, block, lds, A, P);     \
+    else                                                                                \
+      RCG_LAUNCH(h, (k_ticks<Sys, real, GEN, TGT, false>), grid, block, 0, A, P);      \
+  } while (0)
+    if (lds > 64 * 1024) {
+      const void* fn = generic ? (tgt ? (const void*)&k_ticks<Sys, real, true, true, true> : (const void*)&k_ticks<Sys, real, true, false, true>)
+                               : (tgt ? (const void*)&k_ticks<Sys, real, false, true, true> : (const void*)&k_ticks<Sys, real, false, false, true>);
+      HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (generic && tgt)
-      RCG_LAUNCH(h, (k_ticks<Sys, real, true, true>), grid, block, 0, A, P);
+      RCG_TICKS(true, true);
     else if (generic)
-      RCG_LAUNCH(h, (k_ticks<Sys, real, true, false>), grid, block, 0, A, P);
+      RCG_TICKS(true, false);
     else if (tgt)
-      RCG_LAUNCH(h, (k_ticks<Sys, real, false, true>), grid, block, 0, A, P);
+      RCG_TICKS(false, true);
     else
-      RCG_LAUNCH(h, (k_ticks<Sys, real, false, false>), grid, block, 0, A, P);
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_TICKS, (generic ? 1 : 0) | (tgt ? 2 : 0), A.G);
+      RCG_TICKS(false, false);
+#undef RCG_TICKS
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_TICKS, (generic ? 1 : 0) | (tgt ? 2 : 0) | (cand ? 4 : 0), A.G);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
