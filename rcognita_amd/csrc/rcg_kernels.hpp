@@ -739,15 +739,24 @@ __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const ty
 
 // upd_accum_obj (controllers.py:1086-1093): accum_obj_val += stage_obj(obs, action) * sampling_time - the product rounded,
 // then the sum rounded, as numpy evaluates the reference's statement and as the streamed production kernels do (their
-// sum is a no-return atomic add of the rounded product).  The contraction to one fused multiply-add is switched off
-// here, so that every tick kernel of the library leaves the same ACCUM bits (rounds 1-3 fused it in k_actor / k_ticks).
+// sum is a no-return atomic add of the rounded product).  Under -ffp-contract=fast the backend fuses a product into the
+// sum that consumes it whatever the source says (a `#pragma clang fp contract(off)` does not reach it), so the product is
+// passed through an empty asm statement, which makes it a value of its own: every tick kernel of the library then leaves
+// the same ACCUM bits (rounds 1-3 had a fused multiply-add in k_actor / k_ticks and two roundings in k_actor_dma).
+__device__ __forceinline__ float opaque_r(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ double opaque_r(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 template <typename Sys, bool TGT, typename real>
 __device__ __forceinline__ real accum_update(const KParams<real>& P, const real* obs, const real* act, real accum) {
-#pragma clang fp contract(off)
   constexpr int NCHI = Sys::DS + Sys::DU;
   real chi[NCHI];
   make_chi<Sys::DS, Sys::DU, TGT, real>(P, obs, act, chi);
-  const real inc = stage_any<NCHI, real>(P, chi) * P.sampling_time;
+  const real inc = opaque_r(stage_any<NCHI, real>(P, chi) * P.sampling_time);
   return accum + inc;
 }
 

@@ -695,10 +695,11 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
                          (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 &&
                          (64 % A.grid_g) == 0 && !A.no_multi && !dev_knobs().no_pk;
       if (pk_ok) {  // the kernel around the hand-packed rollout (k_ticks_pk): several envs per wave
-        // envs per wave: a power of two <= 8 that leaves >= 16384 waves (four rounds of the ~4000 resident ones), so that a
-        // wave's loads, its argmin and its stores are amortised without unbalancing the launch
+        // envs per wave: a power of two <= 8 that leaves >= 8192 waves, so that a wave's loads, the env step (one RK4 for
+        // all of its envs) and its stores are amortised without unbalancing the launch (65 536 envs, one tick, us per
+        // launch by envs per wave: 1: 93.5, 2: 75.6, 4: 67.0, 8: 63.8, 16: 65.1 - profiles/r04_ab_ticks_pk.txt)
         int gpw = 1;
-        while (gpw < 8 && c.batch / (gpw * 2) >= 16384) gpw *= 2;
+        while (gpw < 8 && c.batch / (gpw * 2) >= 8192) gpw *= 2;
         if (dev_knobs().gpw > 0 && dev_knobs().gpw <= 64) gpw = (int)dev_knobs().gpw;
         A.gpw = gpw;
         const long pw = ((long)c.batch + gpw - 1) / gpw;
