@@ -254,14 +254,17 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
  * contract is "within rounding" for Sys2Tank: its rollout right-hand side leaves the choice of fused multiply-adds to the
  * compiler (18-26 % faster than the written-out form), and k_ticks and k_actor inline it at different call sites; the robots'
  * right-hand sides and every simulator step write their fusions out.  A checkpoint taken under one entry point and resumed
- * under the other inherits the same caveat.  BEST_J / BEST_IDX are the last tick's.  MPC handles (any stage-cost structure,
- * with or without RCG_FLAG_DISTURB); RQL / SQL handles get RCG_ERR_UNSUPPORTED and loop rcg_control_tick (their critic fit
- * sits between the env step and the decision).  Removes the launch-bound regime of small batches. */
+ * under the other inherits the same caveat.  BEST_J / BEST_IDX are the last tick's.  MPC handles: any stage-cost structure,
+ * with or without RCG_FLAG_DISTURB.  RQL / SQL handles (1 <= Ncritic - 1 <= 8, no disturbance model, the preset's observation
+ * target setting): the two launches of a tick - env step + buffer push + critic fit, then the decision - run as phases of
+ * one persistent launch (k_ticks_mem), same functions on the same memory, bit-identical as well; other RQL / SQL handles get
+ * RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of small batches. */
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* T consecutive rcg_control_tick(h, cand, K) issued by ONE call: the loop of presets/main_3wrobot.py:415-468 for T sampling
- * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode.  MPC handles of up to
- * 16384 envs run them as ONE launch (k_ticks; a caller's tensor: the wave's candidate rows are staged into LDS once and
- * re-walked T times); larger batches and RQL / SQL issue the launches of T single ticks without T trips through the
+ * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode.  Handles of up to
+ * 16384 envs run them as ONE launch: MPC on k_ticks (a caller's tensor: the wave's candidate rows are staged into LDS once
+ * and re-walked T times), RQL / SQL with the generated grid on k_ticks_mem; larger batches, and RQL / SQL with a caller's
+ * tensor (their single ticks run on k_actor_dma), issue the launches of T single ticks without T trips through the
  * caller's FFI (a Python caller needs ~12 us per call, and a GPU that idles between short ticks clocks down).  Either way
  * every field ends as T single calls leave it, bit for bit; stops at the first error. */
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);

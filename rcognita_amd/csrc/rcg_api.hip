@@ -646,6 +646,11 @@ int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T) {
     if (rc == RCG_OK) h->tick_count += T;
     return rc;
   }
+  if (T > 1 && !cand && h->cfg.mode != RCG_MODE_MPC && h->cfg.batch <= kPersistentTicksMaxBatch &&
+      h->cfg.n_critic - 1 >= 1 && h->cfg.n_critic - 1 <= kFitMaxRows && !(h->cfg.flags & RCG_FLAG_DISTURB)) {
+    const int rc = rcg_control_ticks(h, T, K);  // RQL / SQL, generated grid: k_ticks_mem
+    if (rc != RCG_ERR_UNSUPPORTED) return rc;  // (no instance for this observation target: the loop below)
+  }
   for (int32_t t = 0; t < T; ++t) {
     const int rc = rcg_control_tick(h, cand, K);
     if (rc) return rc;
@@ -659,9 +664,16 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K) {
   if (T < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_ticks: T must be >= 1");
   int rc = check_candidates(h, "rcg_control_ticks", nullptr, K);
   if (rc) return rc;
-  if (h->cfg.mode != RCG_MODE_MPC)
-    return rcg_fail(h, RCG_ERR_UNSUPPORTED,
-                    "rcg_control_ticks: MPC only (RQL/SQL refit the critic between ticks: loop rcg_control_tick)");
+  if (h->cfg.mode != RCG_MODE_MPC) {  // RQL / SQL: the launches of a tick as phases of one persistent launch
+    const int m = h->cfg.n_critic - 1;
+    if (m < 1 || m > kFitMaxRows || (h->cfg.flags & RCG_FLAG_DISTURB))
+      return rcg_fail(h, RCG_ERR_UNSUPPORTED,
+                      "rcg_control_ticks: RQL/SQL need 1 <= Ncritic-1 <= %d rows and no disturbance model here (loop "
+                      "rcg_control_tick)", kFitMaxRows);
+    rc = h->sys->ticks_mem(h, T, K);
+    if (rc == RCG_OK) h->tick_count += T;
+    return rc;
+  }
   rc = h->sys->ticks(h, T, K, nullptr);
   if (rc == RCG_OK) h->tick_count += T;
   return rc;

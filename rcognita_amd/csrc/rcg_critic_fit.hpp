@@ -90,14 +90,15 @@ struct FitArgs {
   const real* action;     // [du][B] do_push: the held action (action_curr)
 };
 
+// Everything of one env, lane-private: [env step] -> [push] -> [fit], in and out through the handle's tensors.  The body of
+// k_critic_fit (lane == env) and of the critic phase of k_ticks_mem (rcg_ticks.hpp: the lanes that stand for the wave's envs).
 template <typename Sys, typename real, int CS, int MAXM>
-__global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
+__device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const KParams<double>& P, const KParams<real>& Pr,
+                                                  const long b) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, DC = CriticDim<CS, DS, DU>::value;
   // rows of the shifted buffers that stay in registers for the TD stack: new row r = old row r + 1, r = 0 .. KEEP - 1
   constexpr int KEEP = MAXM + 1 <= 4 ? MAXM + 1 : 4;
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long B = P.B;
-  if (b >= B) return;
   const int m = P.n_critic - 1;  // rows of the TD stack, 1 <= m <= MAXM (checked on the host)
   const int bs = Pr.buffer_size;
 
@@ -430,6 +431,13 @@ __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const 
     F.w_critic[(long)i * B + b] = (real)v;
     F.w_prev[(long)i * B + b] = (real)v;  // w_critic_prev = w_critic (controllers.py:1471)
   }
+}
+
+template <typename Sys, typename real, int CS, int MAXM>
+__global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P.B) return;
+  critic_update_env<Sys, real, CS, MAXM>(F, P, Pr, b);
 }
 
 }  // namespace rcg

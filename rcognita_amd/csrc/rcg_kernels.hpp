@@ -760,23 +760,15 @@ __device__ __forceinline__ real accum_update(const KParams<real>& P, const real*
   return accum + inc;
 }
 
-// (the instances without the generic cost structures ask for 4 waves per SIMD, i.e. <= 128 VGPRs: the generated-grid
-// instance sits at 125-129 registers depending on details, and the step from 4 to 3 resident waves costs it 15 %)
+// The decision of one wave's env(s): K x _actor_cost + argmin + tick epilogue.  The body of k_actor, and of the decision
+// phase of k_ticks_mem (rcg_ticks.hpp).  `wave`: the wave's index in the grid (wave-uniform), `lds`: its LDS region (streamed).
 template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false>
-__global__ __launch_bounds__(256, (GENERIC || sizeof(real) > 4) ? 1 : 4) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
+__device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KParams<real>& P, const long wave, real* const lds) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-
   const int lane = threadIdx.x & 63;
-  // readfirstlane makes the wave index provably wave-uniform: tile bases, row counts and the env's
-  // addresses then live in SGPRs and the staging control flow is scalar (no exec-mask branches)
-  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
   const long B = P.B;
   const int K = A.K, N = P.n_actor, R = N * DU;
   if (wave * A.G >= B) return;  // wave-uniform; no workgroup barrier is used below
-
-  real* const lds = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * 64 * R;
 
   const bool big = K >= 64;
   const int seg = big ? 64 : A.Kp;          // lanes that share one env
@@ -874,6 +866,19 @@ __global__ __launch_bounds__(256, (GENERIC || sizeof(real) > 4) ? 1 : 4) void k_
     if (A.accum) A.accum[b] = accum_update<Sys, TGT, real>(P, y0, bestU, A.accum[b]);
     if (A.step_idx) A.step_idx[b] += 1;
   }
+}
+
+// (the instances without the generic cost structures ask for 4 waves per SIMD, i.e. <= 128 VGPRs: the generated-grid
+// instance sits at 125-129 registers depending on details, and the step from 4 to 3 resident waves costs it 15 %)
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false>
+__global__ __launch_bounds__(256, (GENERIC || sizeof(real) > 4) ? 1 : 4) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // readfirstlane makes the wave index provably wave-uniform: tile bases, row counts and the env's
+  // addresses then live in SGPRs and the staging control flow is scalar (no exec-mask branches)
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+  real* const lds = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * 64 * (P.n_actor * Sys::DU);
+  actor_wave<Sys, real, GENERIC, TGT, STREAM, PKONLY>(A, P, wave, lds);
 }
 
 // ---------------------------------------------------------------------------------------------

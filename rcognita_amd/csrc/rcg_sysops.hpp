@@ -736,6 +736,93 @@ static int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
   });
 }
 
+// rcg_control_ticks on an RQL / SQL handle: T ticks in one launch (k_ticks_mem), generated candidates.  The caller has
+// checked K, the critic buffers, 1 <= Ncritic - 1 <= kFitMaxRows, no disturbance model, and that an instance exists
+// (ticks_mem_ok).
+template <typename Sys>
+static bool ticks_mem_ok(const rcg_handle* h) {
+  const bool tgt = (h->cfg.flags & RCG_FLAG_HAS_TARGET) != 0;
+  return tgt == Sys::TGT || (!tgt && Sys::TGT);  // instances exist for the preset's target setting (zeros serve "no target")
+}
+
+template <typename Sys>
+static int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
+  constexpr int DU = Sys::DU;
+  const rcg_cfg& c = h->cfg;
+  if (!ticks_mem_ok<Sys>(h)) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: no persistent RQL/SQL instance for this observation target");
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    const KParams<real>& P = params<real>(h);
+    TicksMemArgs<real> M;
+    memset(&M, 0, sizeof M);
+    ActorArgs<real>& A = M.A;
+    A.obs = (const real*)h->f[RCG_FIELD_STATE];
+    A.state_sys = (const real*)h->f[(c.flags & RCG_FLAG_REF_LAG) ? RCG_FIELD_STATE_PREV : RCG_FIELD_STATE];
+    A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    A.w = (const real*)h->f[RCG_FIELD_W_CRITIC];
+    A.action_out = (real*)h->f[RCG_FIELD_ACTION];
+    A.best_J = (real*)h->f[RCG_FIELD_BEST_J];
+    A.best_idx = (int32_t*)h->f[RCG_FIELD_BEST_IDX];
+    A.accum = !(c.flags & RCG_FLAG_ACCUM_EVERY_SUBSTEP) ? (real*)h->f[RCG_FIELD_ACCUM] : nullptr;
+    A.step_idx = (int32_t*)h->f[RCG_FIELD_STEP_IDX];
+    A.K = K;
+    if (K >= 64) {
+      A.Kp = 64;
+      A.G = 1;
+      A.n_tiles = (K + 63) / 64;
+    } else {
+      int kp = 1;
+      while (kp < K) kp <<= 1;
+      A.Kp = kp;
+      A.G = 64 / kp;
+      A.n_tiles = 1;
+    }
+    A.grid_g = DU == 1 ? K : (int)std::floor(std::sqrt((double)K) + 1e-9);
+    A.no_multi = dev_knobs().no_gen_multi ? 1 : 0;
+    FitArgs<real>& F = M.F;
+    F.w_critic = (real*)h->f[RCG_FIELD_W_CRITIC];
+    F.w_prev = (real*)h->f[RCG_FIELD_W_PREV];
+    F.obs_buf = (real*)h->f[RCG_FIELD_OBS_BUF];
+    F.act_buf = (real*)h->f[RCG_FIELD_ACT_BUF];
+    F.wcfg = reinterpret_cast<const double*>((unsigned char*)h->d_const + kConstW);
+    F.do_sim = 1;
+    F.do_push = 1;
+    F.state = (const real*)h->f[RCG_FIELD_STATE];
+    F.action = (const real*)h->f[RCG_FIELD_ACTION];
+    F.sim.state = (real*)h->f[RCG_FIELD_STATE];
+    F.sim.state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
+    F.sim.action = (const real*)h->f[RCG_FIELD_ACTION];
+    F.sim.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    F.sim.accum = (real*)h->f[RCG_FIELD_ACCUM];
+    F.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+    F.sim.n_sub = c.substeps_per_tick;
+    M.T = T;
+    M.tick0 = (int)h->tick_count;
+    M.every = c.critic_every_ticks > 1 ? c.critic_every_ticks : 1;
+    const int m = c.n_critic - 1;
+    const long n_waves = (c.batch + A.G - 1) / A.G;
+    const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
+    ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
+#define RCG_TM(CS)                                                                                              \
+  do {                                                                                                          \
+    if (m <= 3)                                                                                                 \
+      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, 3, Sys::TGT>), grid, block, 0, M, h->p64, P);                  \
+    else                                                                                                        \
+      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, kFitMaxRows, Sys::TGT>), grid, block, 0, M, h->p64, P);        \
+  } while (0)
+    switch (c.critic_struct) {
+      case RCG_CRITIC_QUAD_LIN: RCG_TM(RCG_CRITIC_QUAD_LIN); break;
+      case RCG_CRITIC_QUADRATIC: RCG_TM(RCG_CRITIC_QUADRATIC); break;
+      case RCG_CRITIC_QUAD_NOMIX: RCG_TM(RCG_CRITIC_QUAD_NOMIX); break;
+      default: RCG_TM(RCG_CRITIC_QUAD_MIX); break;
+    }
+#undef RCG_TM
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_TICKS, 16 | 1 | (Sys::TGT ? 2 : 0), A.G);  // variant bit 4: k_ticks_mem
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
 // CtrlNominal3WRobot / CtrlNominal3WRobotNI for n points (tick: the handle's envs, with the tick epilogue)
 template <typename Sys>
 static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, void* theta, int32_t n, double gain,
@@ -774,7 +861,7 @@ struct SysInstances {
   static SysVTable table() {
     return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,        &op_critic_cost<Sys>, &op_actor<Sys>,
                      &op_sim_step<Sys>, &op_critic_update<Sys>, &op_optimize<Sys>, &op_nominal<Sys>,
-                     &op_ticks<Sys>,  &op_rhs_full<Sys>, &op_search<Sys>};
+                     &op_ticks<Sys>,  &op_rhs_full<Sys>, &op_search<Sys>, &op_ticks_mem<Sys>};
   }
 };
 

@@ -17,6 +17,7 @@
 // RQL / SQL ticks refit the critic between the env step and the decision; they go through k_ticks_mem (below), which runs
 // the launches of rcg_control_tick as phases of one persistent launch.
 #pragma once
+#include "rcg_critic_fit.hpp"
 #include "rcg_disturb.hpp"
 #include "rcg_kernels.hpp"
 
@@ -252,6 +253,53 @@ __global__ __launch_bounds__(256, 4) void k_ticks_pk(const TicksArgs<float> A, c
     A.status[bm] = st;
     A.best_J[bm] = myJ;
     A.best_idx[bm] = myI;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ticks_mem: T RQL / SQL ticks in ONE launch
+// ---------------------------------------------------------------------------------------------
+// An RQL / SQL tick is two launches - k_critic_fit (env step + buffer push + critic fit, lane = env) and the decision
+// kernel - that exchange everything through the handle's tensors, and an env's tick depends on nothing but that env.  So
+// the wave that decides for env(s) [wave G, wave G + G) can run both launches' bodies for THOSE envs back to back, T times:
+// phase 1, the lanes that stand for the wave's envs run critic_update_env (the body of k_critic_fit); phase 2, the whole
+// wave runs actor_wave (the body of k_actor).  Same functions on the same memory: every field ends bit-identical to T
+// single ticks.  Between the phases the wave's stores have to be visible to its own later loads through the CU's vector
+// L1: a workgroup-scope release / acquire pair (a wait for the stores and an L1 invalidate of ~100 cycles: no other CU is
+// involved, the wave talks to itself).  Generated candidates; with a caller's tensor the single ticks of a critic-mode
+// handle run on k_actor_dma, whose rollouts round differently, so those stay per-tick launches (rcg_control_tick_n).
+template <typename real>
+struct TicksMemArgs {
+  ActorArgs<real> A;
+  FitArgs<real> F;
+  int T;       // ticks
+  int tick0;   // control ticks of the episode issued before this launch (the critic period's phase)
+  int every;   // critic_every_ticks (>= 1)
+};
+
+template <typename Sys, typename real, int CS, int MAXM, bool TGT>
+__global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, const KParams<double> P64,
+                                                   const KParams<real> P) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+  const long B = P.B;
+  const int G = M.A.G;
+  if (wave * G >= B) return;  // wave-uniform: every wave that stays runs all T ticks and exits
+  const int envs_here = (int)((B - wave * G) < G ? (B - wave * G) : G);
+  FitArgs<real> F = M.F;
+  for (int t = 0; t < M.T; ++t) {
+    F.do_fit = ((M.tick0 + t + 1) % M.every) == 0 ? 1 : 0;  // fits on ticks every - 1, 2 every - 1, ... of the episode
+    if (lane < envs_here) critic_update_env<Sys, real, CS, MAXM>(F, P64, P, wave * G + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    actor_wave<Sys, real, true, TGT, false>(M.A, P, wave, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

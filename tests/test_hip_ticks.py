@@ -83,11 +83,12 @@ def test_ticks_follow_the_oracle_and_freeze_nonfinite_envs():
 def test_ticks_refusals_change_nothing():
     from rcognita_amd import _native as N
 
-    eng, _ = both("2tank", 8, "f32", n_actor=4, mode=O.MODE_RQL, n_critic=3, buffer_size=5)
+    # RQL with an empty TD stack (Ncritic = 1): the single ticks keep w = clip(w_init) through a separate fill, no instance
+    eng, _ = both("2tank", 8, "f32", n_actor=4, mode=O.MODE_RQL, n_critic=1, buffer_size=5)
     eng.set_state(rand_states(np.random.default_rng(0), "2tank", 8))
     x = eng.get_state().copy()
     with pytest.raises(N.NativeError) as ei:
-        eng.control_ticks(3, 16)  # RQL: the critic is refitted between ticks
+        eng.control_ticks(3, 16)
     assert ei.value.code == N.ERR_UNSUPPORTED
     mpc, _ = both("3wrobot", 8, "f32", n_actor=4)
     for T, K in ((0, 16), (2, 50), (2, 0)):
@@ -258,3 +259,72 @@ def test_streamed_small_batch_is_no_longer_launch_bound():
         rates[tag] = 3 * T * B / (time.perf_counter() - t0)
     print(f"\nstreamed B={B} K={K}: {rates}")
     assert rates["one_launch"] > 2.0 * rates["per_tick_launches"]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name,mode,cs,K,B,kw", [
+    ("2tank", "RQL", "quadratic", 256, 300, dict(n_critic=4, buffer_size=10)),       # configs[2]'s controller
+    ("2tank", "SQL", "quad-lin", 64, 1024, dict(n_critic=3, buffer_size=5, critic_every_ticks=3)),
+    ("3wrobot", "RQL", "quad-nomix", 64, 515, dict(n_critic=4, buffer_size=6, ref_lag=True)),
+    ("3wrobot", "SQL", "quad-mix", 16, 130, dict(n_critic=6, buffer_size=8)),          # 4 envs per wave, 5 TD rows
+    ("3wrobotNI", "RQL", "quad-lin", 100, 77, dict(n_critic=4, buffer_size=6, gamma=0.95, substeps_per_tick=2)),
+    ("3wrobotNI", "SQL", "quadratic", 256, 64, dict(n_critic=4, buffer_size=10)),
+])
+def test_T_critic_mode_ticks_in_one_launch_equal_T_single_ticks(name, mode, cs, K, B, kw, dtype):
+    """RQL / SQL: rcg_control_ticks runs env step + buffer push + critic fit and the decision of every tick as phases of ONE
+    launch (k_ticks_mem: the bodies of k_critic_fit and k_actor on the same memory).  Every field - critic weights and
+    both buffers included - ends bit-identical to T single ticks, across the critic period's phase and an episode reset."""
+    from rcognita_amd import _native as N
+    from tests.helpers import assert_kernel
+
+    rng = np.random.default_rng(K + B)
+    T = 9
+    one, many, cfg = _pair(name, B, dtype, n_actor=5, mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs], **kw)
+    x0 = rand_states(rng, name, B) * 0.5
+    one.set_state(x0)
+    many.set_state(x0)
+    fields = FIELDS + ["FIELD_W_CRITIC", "FIELD_W_PREV", "FIELD_OBS_BUF", "FIELD_ACT_BUF"]
+    for _ in range(T):
+        one.control_tick(None, K=K)
+    many.control_ticks(T, K)
+    ll = assert_kernel(many, "k_ticks")
+    assert ll["variant"] & 16, ll
+    assert_kernel(one, "k_critic_fit", kind=N.KERNEL_CRITIC)
+    for f in fields:
+        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+    assert not np.allclose(many.get_field(N.FIELD_W_CRITIC), 1.0)  # the critic was fitted
+    # continues identically in two pieces (the critic period's phase travels with the handle's tick counter), then an
+    # episode reset, then rcg_control_tick_n's route to the same kernel
+    for _ in range(5):
+        one.control_tick(None, K=K)
+    many.control_ticks(2, K)
+    many.control_ticks(3, K)
+    for e in (one, many):
+        e.episode_reset()
+    for _ in range(4):
+        one.control_tick(None, K=K)
+    many.control_tick(None, K=K, T=4)
+    assert_kernel(many, "k_ticks")
+    for f in fields + ["FIELD_RETURNS", "FIELD_EPISODE_IDX"]:
+        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+    assert N.lib().rcg_tick_count(many._h) == N.lib().rcg_tick_count(one._h) == 4
+
+
+def test_critic_mode_small_batch_rate():
+    """configs[2]'s controller at B = 1024 (launch-bound under two launches per tick): T ticks per launch against the loop
+    of single ticks issued from one native call."""
+    B, K, T = 1024, 64, 128
+    rates = {}
+    for tag in ("per_tick_launches", "one_launch"):
+        eng, _ = both("2tank", B, "f32", n_actor=10, mode=O.MODE_RQL, critic_struct=O.CRITIC_QUADRATIC, n_critic=4, buffer_size=10)
+        eng.set_state(rand_states(np.random.default_rng(1), "2tank", B))
+        step = (lambda: [eng.control_tick(None, K=K) for _ in range(T)]) if tag == "per_tick_launches" else (lambda: eng.control_ticks(T, K))
+        step()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        eng.synchronize()
+        rates[tag] = 3 * T * B / (time.perf_counter() - t0)
+    print(f"\nRQL B={B} K={K}: {rates}")
+    assert rates["one_launch"] > 1.2 * rates["per_tick_launches"]
