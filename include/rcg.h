@@ -282,8 +282,10 @@ int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);
  * structure) 30 iterations end within 0.5 % of SLSQP's cost. */
 int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
                        void* u_opt, void* action, void* best_J, int32_t* n_iter);
-/* Curvature pairs rcg_actor_optimize keeps per env: 0 (projected steepest descent, round 3's optimiser) .. 8; default 4.
- * Each pair costs 2 * N * du reals of LDS per env. */
+/* Curvature pairs rcg_actor_optimize keeps per env: 0 (projected steepest descent, round 3's optimiser) .. 8, or -1 for the
+ * default: 4 for RQL / SQL and for non-diagonal stage costs, 0 for MPC with a diagonal R1 (steepest descent reaches SLSQP's
+ * optimum on every MPC decision of the reference's loops; the pairs cost 2.4 x the time).  Each pair costs 2 * N * du reals
+ * of LDS per env. */
 int rcg_set_optimizer(rcg_handle* h, int32_t memory);
 /* rcg_control_tick with rcg_actor_optimize as the decision: sim_step -> [RQL/SQL: buffer push + critic fit] -> optimise ->
  * ACTION, ACTION_SQN, BEST_J -> ACCUM, STEP_IDX.  warm_start != 0: start from the previous tick's optimum shifted by one

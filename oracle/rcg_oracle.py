@@ -601,7 +601,17 @@ def actor_grad(u, obs, state_sys, cfg: OracleCfg, pars=None, w_critic=None):
     return J, g
 
 
-OPT_MEMORY = 4  # curvature pairs kept by the limited-memory quasi-Newton direction (0: projected steepest descent)
+OPT_MEMORY = None  # None: the library's default (opt_memory_default); an int: that many curvature pairs (0: steepest descent)
+
+
+def opt_memory_default(cfg: "OracleCfg") -> int:
+    """Curvature pairs rcg_actor_optimize keeps by default (rcg_handle.hpp::opt_memory_of): 4 for the critic modes and the
+    non-diagonal stage costs, 0 for MPC with a diagonal quadratic stage cost."""
+    diag = np.count_nonzero(cfg.R1 - np.diag(np.diag(cfg.R1))) == 0 and (
+        cfg.stage_obj_struct == STAGE_QUADRATIC or np.count_nonzero(cfg.R2 - np.diag(np.diag(cfg.R2))) == 0)
+    generic = not (cfg.mode == MODE_MPC and cfg.stage_obj_struct == STAGE_QUADRATIC and diag)
+    return 4 if generic else 0
+
 
 
 def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY):
@@ -628,7 +638,7 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
     wbox = np.tile(hi - lo, N)
     lo_f, hi_f = np.tile(lo, N), np.tile(hi, N)
     h0 = wbox * wbox
-    M = int(memory)
+    M = opt_memory_default(cfg) if memory is None else int(memory)
     u = np.array(u_init, dtype=np.float64).reshape(N, du)
     J = float(actor_cost(u, obs, state_sys, cfg, pars=pars, w_critic=w_critic))
     S = np.zeros((max(M, 1), R))

@@ -212,7 +212,7 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->prof_stride = 1;
   memset(h->prof_seen, 0, sizeof h->prof_seen);
   h->tick_count = 0;
-  h->opt_memory = 4;
+  h->opt_memory = -1;  // auto: 4 pairs for the generic instance, none for MPC with a diagonal R1 (rcg_set_optimizer)
   h->cur_a = h->cur_b = nullptr;
   h->scope_due = false;
   h->order_ev = nullptr;
@@ -681,8 +681,8 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K) {
 
 int rcg_set_optimizer(rcg_handle* h, int32_t memory) {
   if (!h) return RCG_ERR_BAD_ARG;
-  if (memory < 0 || memory > OPT_MAXM)
-    return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_optimizer: memory must be in [0, %d]", OPT_MAXM);
+  if (memory < -1 || memory > OPT_MAXM)
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_optimizer: memory must be in [0, %d], or -1 for the default", OPT_MAXM);
   h->opt_memory = memory;
   return RCG_OK;
 }
@@ -694,7 +694,7 @@ static int check_optimizer(rcg_handle* h, const char* who) {
   const size_t lds = opt_wave_lds_bytes(h);
   if (lds > (size_t)160 * 1024)
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "%s: horizon %d with %d curvature pairs needs %zu B of LDS per wave (rcg_set_optimizer)",
-                    who, h->cfg.n_actor, h->opt_memory, lds);
+                    who, h->cfg.n_actor, opt_memory_of(h), lds);
   return RCG_OK;
 }
 

@@ -26,7 +26,7 @@ struct rcg_handle {
   size_t fbytes[RCG_FIELD_COUNT_];
   double* d_summary;
   long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
-  int opt_memory;   // curvature pairs of k_actor_opt (rcg_set_optimizer), default 4
+  int opt_memory;   // curvature pairs of k_actor_opt (rcg_set_optimizer); -1: the default of opt_memory_of()
   void* d_const;    // constant block in HBM, layout kConst* below
   rcg::KParams<float> p32;
   rcg::KParams<double> p64;
@@ -177,9 +177,19 @@ inline const rcg::KParams<double>& params<double>(const rcg_handle* h) {
 
 // LDS bytes one wave of k_actor_opt needs for this handle (the launcher sizes its blocks with it; rcg_control_tick_opt
 // refuses a tick whose optimiser cannot be launched BEFORE it steps the env)
+// Curvature pairs k_actor_opt keeps for this handle.  Default: 4 where the problem needs them - the critic modes and the
+// non-diagonal stage costs, whose terminal / coupled terms carry 1e4 times the curvature of the rest (steepest descent
+// stalls 3-14 % above SLSQP there, fixtures F8c) - and none for MPC with a diagonal R1, where box-scaled steepest descent
+// reaches SLSQP's optimum on every decision of the reference's own loops (fixtures F8, mpc_tick_* of F7c: <= 3.5e-4 after
+// 10 iterations, 0 after 30) and the pairs would cost 2.4 x the time (LDS footprint: 77 KB per block instead of 26).
+static inline int opt_memory_of(const rcg_handle* h) {
+  if (h->opt_memory >= 0) return h->opt_memory;
+  const bool generic = !(h->cfg.mode == RCG_MODE_MPC && h->p32.stage_kind == 0);
+  return generic ? 4 : 0;
+}
 static inline size_t opt_wave_lds_bytes(const rcg_handle* h) {
   const int dcw = h->cfg.mode != RCG_MODE_MPC ? h->dc : 0;
-  return (size_t)rcg::opt_lds_reals(h->cfg.n_actor, h->ds, h->du, h->np, dcw, h->opt_memory) * h->esz;
+  return (size_t)rcg::opt_lds_reals(h->cfg.n_actor, h->ds, h->du, h->np, dcw, opt_memory_of(h)) * h->esz;
 }
 
 static inline unsigned blocks_for(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }

@@ -524,7 +524,7 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
     for (int i = 0; i < Sys::DU; ++i) A.u0[i] = (real)c.action_init[i];
     A.iters = iters;
     A.shift = shift;
-    A.memory = h->opt_memory;
+    A.memory = opt_memory_of(h);
     const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
     A.dcw = c.mode != RCG_MODE_MPC ? h->dc : 0;
     // waves per block: 4 (one per SIMD) while the block's LDS fits the CU's 160 KB, else 2 or 1 (long horizons in f64
@@ -536,7 +536,7 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
     if (lds > (size_t)160 * 1024)
       return rcg_fail(h, RCG_ERR_UNSUPPORTED,
                       "rcg_actor_optimize: horizon %d with %d curvature pairs needs %zu B of LDS per wave (rcg_set_optimizer)",
-                      c.n_actor, h->opt_memory, lds_wave);
+                      c.n_actor, opt_memory_of(h), lds_wave);
     const dim3 grid(blocks_for(c.batch, wpb * OPT_G)), block(64 * wpb);  // a wave owns OPT_G envs
     const bool tgt = c.flags & RCG_FLAG_HAS_TARGET;
     if (tick && sim_first) {  // rcg_control_tick_opt (MPC): the env step of the tick, once every argument check has passed

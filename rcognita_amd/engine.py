@@ -666,8 +666,9 @@ class Engine:
         N.check(N.lib().rcg_candidates_sample(self._h, C.c_void_p(d.ptr), int(K), int(round), pc), self._h)
         return d.to_host()
 
-    def set_optimizer(self, memory=4):
-        """Curvature pairs the optimiser keeps per env (rcg_set_optimizer): 0 = projected steepest descent .. 8."""
+    def set_optimizer(self, memory=-1):
+        """Curvature pairs the optimiser keeps per env (rcg_set_optimizer): 0 = projected steepest descent .. 8; -1 = the
+        default (4 for RQL / SQL and non-diagonal stage costs, 0 for MPC with a diagonal R1)."""
         N.check(N.lib().rcg_set_optimizer(self._h, int(memory)), self._h)
 
     @staticmethod
