@@ -267,7 +267,7 @@ def test_optimizer_memory_setting_and_refusals():
     eng, cfg = both("3wrobot", B, "f64", n_actor=7)
     x = rand_states(rng, "3wrobot", B)
     eng.set_state(x)
-    for bad in (-1, 9):
+    for bad in (-2, 9):
         with pytest.raises(Nn.NativeError) as ei:
             eng.set_optimizer(bad)
         assert ei.value.code == Nn.ERR_BAD_ARG
