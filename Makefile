@@ -20,7 +20,7 @@ HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-functi
 # the C ABI + one unit per environment (every system-templated kernel except k_actor_dma)
 UNITS   := rcg_api rcg_sys_3wrobot rcg_sys_3wrobotni rcg_sys_2tank
 # k_actor_dma instances: rcg_dma_inst.hip compiled once per (system, element type, group), see that file
-DMA     := $(foreach s,Sys3WRobot Sys3WRobotNI Sys2Tank,$(foreach r,float double,$(foreach g,0 1 2 3,$(s).$(r).$(g))))
+DMA     := $(foreach s,Sys3WRobot Sys3WRobotNI Sys2Tank,$(foreach r,float double,$(foreach g,0 1 2 3 4 5,$(s).$(r).$(g))))
 DMAFLAGS = -DRCG_INST_SYS=$(word 1,$(subst ., ,$*)) -DRCG_INST_REAL=$(word 2,$(subst ., ,$*)) \
            -DRCG_INST_GROUP=$(word 3,$(subst ., ,$*))
 objs     = $(addprefix $(1)/,$(addsuffix .o,$(UNITS))) $(addprefix $(1)/rcg_dma.,$(addsuffix .o,$(DMA)))

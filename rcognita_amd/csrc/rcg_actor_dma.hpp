@@ -1,7 +1,7 @@
 // rcg_actor_dma.hpp - k_actor_dma: the production kernel of the streamed rollout
 // (CtrlOptPred._actor_cost for K candidates per env + argmin + tick epilogue; controllers.py:1273-1427).
 //
-// Shape it serves: diagonal quadratic stage cost (every reference preset), K >= 40 with K * R * esz a multiple of 16 (an env's last
+// Shape it serves: diagonal quadratic stage cost (every reference preset), K >= 33 with K * R * esz a multiple of 16 (an env's last
 // tile may be ragged: its direct-to-LDS loads are masked per lane, so not a byte beyond the env's rows is read, and the lanes
 // without a row sit out the argmin), the observation target as
 // the system's preset has it; the rollout starts from `state_sys` with `obs` as y_0 (controllers.py:1286-1296) - the same

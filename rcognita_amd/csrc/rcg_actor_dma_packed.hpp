@@ -13,9 +13,15 @@
 //     winner's lane with ds_bpermute;
 //   * a wave owns gpw = G * 2^n <= 64 consecutive envs and parks env (env0 + i)'s results in lane i; one coalesced store
 //     per field when the wave is done.
+//   * RQL / SQL (round 4): the critic weights of the lane's env are per-lane loads as well ([dc][B]: the lanes of one env
+//     read one address), requested when the tile's rows have been read - BEFORE the next tile's DMA, so that waiting for
+//     them does not drain the tile - and first used at the last step of the rollout (RQL: Q_w of the last step; SQL: the
+//     regressor summed over the horizon, dotted with the weights once), so their latency hides behind the rollout.
+//     Instances exist for <= 36 dwords of weights (every structure in f32; f64: up to 18 weights - the robots'
+//     quad-lin / quadratic structures in f64 stay on k_actor_dma's ragged tile / k_actor).
 // Shapes: streamed candidates, 4 <= K <= 32 with K * R * esz % 16 == 0 (whole 16-byte pieces per env), MPC (gamma == 1 per-component
-// instance, discounted instance), diagonal quadratic stage cost, the preset's observation target, rows of <= 40 reals, f32
-// and f64.  RQL / SQL with K < 40 stay on k_actor (the critic weights would be per-lane data as well).
+// instance, discounted instance), RQL and SQL x 4 critic structures, diagonal quadratic stage cost, the preset's observation
+// target, rows of <= 40 reals, f32 and f64.
 // Until round 3 these shapes ran on k_actor (tile HBM -> VGPR -> LDS, row walked from LDS with a runtime horizon):
 // 3.4-3.7 TB/s at K = 16 / 32 (B = 65536, Nactor = 10).
 #pragma once
@@ -59,12 +65,18 @@ __device__ __forceinline__ void seg_argmin_pow2(double& J, int& I, int K) {
   }
 }
 
+// critic variants with per-lane weights exist for at most 36 dwords of them (a second copy of the SQL regressor sums sits
+// next to them in registers)
+__host__ __device__ constexpr bool packed_critic_ok(int dc, int esz) { return dc * esz <= 144; }
+
 template <typename Sys, typename real, int R, bool TGT, int V>
 __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
-  constexpr bool G1 = V == DMA_MPC_G1;
-  static_assert(V == DMA_MPC_G1 || V == DMA_MPC, "packed tiles serve the two MPC variants");
+  constexpr bool G1 = V == DMA_MPC_G1, SQL = V >= DMA_SQL_0, RQL = V >= DMA_RQL_0 && !SQL, CRIT = RQL || SQL;
+  constexpr int CS = SQL ? V - DMA_SQL_0 : (RQL ? V - DMA_RQL_0 : 0);  // compile-time critic structure
+  constexpr int DC = CRIT ? dma_dc(CS, DS, DU) : 1;
   constexpr int ESZ = (int)sizeof(real);
+  static_assert(!CRIT || packed_critic_ok(DC, ESZ), "per-lane critic weights: at most 36 dwords");
   static_assert(R % DU == 0 && R >= DU && R <= 40, "row = N*du reals, at most 40");
   constexpr int N = R / DU;
   constexpr int TILE = 64 * R * ESZ;                               // bytes of a full tile
@@ -159,6 +171,12 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    real wc[DC];  // (RQL / SQL) the critic weights of MY env: requested here, first read at the end of the rollout
+    if constexpr (CRIT) {
+      const long bw = env0 + (long)j * G + (le < ne ? le : 0);
+#pragma unroll
+      for (int i = 0; i < DC; ++i) wc[i] = A.w[(long)i * B + bw];
+    }
     if (j + 1 < n_tiles) {  // the LDS tile is free: next env states first, then the next tile
       fetch_env(j + 1);
       issue_tile(j + 1);
@@ -175,6 +193,10 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
     real S[NCHI];
 #pragma unroll
     for (int i = 0; i < NCHI; ++i) S[i] = 0;
+    real Phi[SQL ? DC : 1];  // SQL: the regressor summed over the horizon (J = sum_k w . phi_k = w . sum_k phi_k)
+#pragma unroll
+    for (int i = 0; i < (SQL ? DC : 1); ++i) Phi[i] = 0;
+    auto wget = [&](int i) -> real { return wc[CRIT ? i : 0]; };
 #pragma unroll
     for (int kk = 0; kk < N; ++kk) {
       if (kk > 0) {
@@ -194,6 +216,10 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
       if (G1) {
 #pragma unroll
         for (int i = 0; i < NCHI; ++i) S[i] = fma_r(chi[i], chi[i], S[i]);
+      } else if (SQL) {
+        critic_phi_accum<DS, DU, real>(chi, y, &cur[kk * DU], Phi, CS);
+      } else if (RQL && kk == N - 1) {
+        J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], wget, CS);
       } else {
         J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
         gk *= P.gamma;
@@ -202,6 +228,10 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
     if (G1) {
 #pragma unroll
       for (int i = 0; i < NCHI; ++i) J = fma_r(P.R1d[i], S[i], J);
+    }
+    if (SQL) {  // J = w . sum_k phi(chi_k)
+#pragma unroll
+      for (int i = 0; i < DC; ++i) J = fma_r(wget(i), Phi[i], J);
     }
 
     const bool has_row = le < ne;
@@ -275,8 +305,8 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
   }
 }
 
-// instances: rcg_dma_inst.hip, group 3 (one object per system x element type)
-template <typename Sys, typename real>
+// instances: rcg_dma_inst.hip, groups 3 (MPC), 4 (SQL), 5 (RQL) - one object per system x element type x group
+template <typename Sys, typename real, int GROUP>
 bool launch_dma_packed(int r, int variant, dim3 grid, dim3 block, size_t lds, hipStream_t s, const ActorArgs<real>& A,
                        const KParams<real>& P, hipEvent_t ev_a, hipEvent_t ev_b);
 

@@ -225,6 +225,7 @@ struct DevKnobs {
   bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL and SQL go to k_actor (A/B against the critic instances)
   bool no_gen_multi = false;  // RCG_NO_GEN_MULTI=1: generated tiles one at a time (no shared sub-trajectory)
   bool no_pack = false;
+  int dma_min_k = 33;  // RCG_DMA_MINK=<k>: fewest candidates per env served by k_actor_dma (one ragged tile below 64)
   bool no_tick_fuse = false;  // RCG_NO_TICK_FUSE=1: generated-grid tick as k_sim + k_actor (packed instance) instead of k_ticks_pk
   bool no_pk = false;  // RCG_NO_PK=1: generated grid on the instances that carry every variant (A/B of the packed rollout)
 };
@@ -244,6 +245,7 @@ static inline const DevKnobs& dev_knobs() {
     v.no_pack = getenv("RCG_NO_PACK") != nullptr;
     v.no_pk = getenv("RCG_NO_PK") != nullptr;
     v.no_tick_fuse = getenv("RCG_NO_TICK_FUSE") != nullptr;
+    if (const char* e = getenv("RCG_DMA_MINK")) v.dma_min_k = atoi(e);
 #endif
     return v;
   }();
@@ -321,8 +323,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
   const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
 
-  // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K >= 40 with K * R * esz % 16 == 0 (40 .. 60: one
-  // ragged tile per env - K = 48: 4.6 TB/s against 2.9 on k_actor; at K <= 32 k_actor, which packs 64 / K envs into a tile,
+  // Production shape -> k_actor_dma (rcg_actor_dma.hpp): streamed candidates, K >= 33 with K * R * esz % 16 == 0 (33 .. 63: one
+  // ragged tile per env - K = 48: 4.6 TB/s against 2.9 on k_actor, K = 36: 3.6 against 2.3 (RQL: 3.1 x, profiles/r04_ab_min_k.txt); at K <= 32 k_actor, which packs 64 / K envs into a tile,
   // is faster: 3.7 against 3.4 TB/s at K = 32, 3.4 against 1.75 at K = 16), diagonal quadratic
   // stage cost, the preset's observation target (an instance that subtracts a target also serves a handle without one: its
   // target is all zeros, y - 0 = y exactly); rows of <= 40 reals; MPC / RQL / SQL in f32 and f64.
@@ -342,16 +344,19 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   // (an env's rows must be a whole number of 16-byte pieces, K * R * esz % 16 == 0 - any K for rows of 16 n bytes such as C2's
   // 80, every 4th K for the shortest rows: then every env starts 16-B aligned and a ragged last tile ends on a piece)
   const bool slab16 = ((size_t)K * row_bytes) % 16 == 0;
-  const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= 40 && slab16 && R <= dma_max_row<real>() &&
+  // (RQL / SQL without a packed instance - f64 with more than 18 weights: one ragged tile already from K = 20, where it
+  // overtakes k_actor: 66 against 105 us at K = 24, 65 against 50 at K = 16; profiles/r04_ab_min_k.txt)
+  const int dma_min_k = (c.mode != RCG_MODE_MPC && knobs.dma_min_k > 20) ? 20 : knobs.dma_min_k;
+  const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= dma_min_k && slab16 && R <= dma_max_row<real>() &&
                       P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
                       // J staging must fit next to the tiles (one block per CU then)
                       !(A.J && 4 * tile + wslot + 4 * esz * K > (size_t)160 * 1024);
-  // Few candidates per env (4 <= K <= 32, whole 16-byte pieces per env), MPC -> k_actor_dma_packed (rcg_actor_dma_packed.hpp): 64 / K envs
-  // share a DMA tile.  J staging (operator mode) must fit next to the four tiles.
+  // Few candidates per env (4 <= K <= 32, whole 16-byte pieces per env) -> k_actor_dma_packed (rcg_actor_dma_packed.hpp): 64 / K envs
+  // share a DMA tile (MPC; RQL / SQL with at most 36 dwords of critic weights - otherwise the launcher below finds no
+  // instance and the tick goes on to k_actor_dma / k_actor).  J staging (operator mode) must fit next to the four tiles.
   const int pack_g = (K >= 4 && K <= 32) ? 64 / K : 0;  // envs per tile
   const bool pack_ok = cand && ((uintptr_t)cand % 16) == 0 && pack_g >= 2 && slab16 && R <= dma_max_row<real>() &&
-                       P.stage_kind == 0 && c.mode == RCG_MODE_MPC && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
-                       !knobs.no_pack;
+                       P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain && !knobs.no_pack;
   // rcg_control_tick with the generated grid in the regime of the hand-packed rollout: env step and decision in ONE launch
   // (k_ticks_pk with T = 1 - what rcg_control_ticks runs, so the two entry points cannot differ by a bit)
   if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported) {
@@ -385,9 +390,12 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     Ap.G = pack_g;
     Ap.gpw = (int)gpw;
     Ap.jwave = 1;
-    // (an instance exists for every row the conditions above admit; should one ever be missing the tick is NOT refused
-    // half-way - the env step has been issued - but served by k_actor below)
-    if (launch_dma_packed<Sys, real>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b)) {
+    // (no instance - RQL / SQL with more than 36 dwords of weights: the tick is served by k_actor_dma / k_actor below)
+    const bool launched =
+        variant < DMA_RQL_0    ? launch_dma_packed<Sys, real, 3>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b)
+        : variant >= DMA_SQL_0 ? launch_dma_packed<Sys, real, 4>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b)
+                               : launch_dma_packed<Sys, real, 5>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b);
+    if (launched) {
       note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA_PACKED, variant, (int)gpw);
       HIPCHK(h, hipGetLastError());
       return RCG_OK;

@@ -605,7 +605,8 @@ class Engine:
 
     def control_ticks(self, T, K):
         """``T`` env.control-steps with the generated candidate grid in ONE launch (rcg_control_ticks): bit-identical
-        to ``T`` calls of ``control_tick(None, K)``; MPC handles without the disturbance model."""
+        to ``T`` calls of ``control_tick(None, K)``.  MPC with any stage cost, with or without the disturbance model; RQL /
+        SQL whose tick fits k_ticks_mem (rcg.h); other handles are refused (RCG_ERR_UNSUPPORTED) and loop control_tick."""
         N.check(N.lib().rcg_control_ticks(self._h, int(T), int(K)), self._h)
 
     def actor_optimize(self, iters=10, obs=None, state_sys=None, u_init=None):

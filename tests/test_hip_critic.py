@@ -168,6 +168,82 @@ def test_streamed_rql_sql_on_the_production_kernel(name, mode, cs, dtype, tol):
     np.testing.assert_array_equal(a[~flipped], cand[np.arange(B), ref_i, 0, :][~flipped])
 
 
+def _dc_of(name, cs):
+    n = {"3wrobot": 5 + 2, "3wrobotNI": 3 + 2, "2tank": 2 + 1}[name]
+    ds, du = {"3wrobot": (5, 2), "3wrobotNI": (3, 2), "2tank": (2, 1)}[name]
+    return {O.CRITIC_QUAD_LIN: n * (n + 1) // 2 + n, O.CRITIC_QUADRATIC: n * (n + 1) // 2, O.CRITIC_QUAD_NOMIX: n,
+            O.CRITIC_QUAD_MIX: ds + ds * du + du}[cs]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-5), ("f64", 1e-11)])
+@pytest.mark.parametrize("cs", [O.CRITIC_QUAD_LIN, O.CRITIC_QUADRATIC, O.CRITIC_QUAD_NOMIX, O.CRITIC_QUAD_MIX])
+@pytest.mark.parametrize("mode", [O.MODE_RQL, O.MODE_SQL])
+@pytest.mark.parametrize("name,K", [("3wrobot", 16), ("3wrobot", 24), ("3wrobotNI", 8), ("3wrobotNI", 20), ("2tank", 32),
+                                    ("2tank", 12)])
+def test_few_candidates_rql_sql_on_packed_tiles(name, K, mode, cs, dtype, tol):
+    """Streamed RQL / SQL with 4 <= K <= 32: k_actor_dma_packed's critic instances (64 / K envs per DMA tile, the critic
+    weights of a lane's env are per-lane loads) wherever the weights fit 36 dwords - every structure in f32, up to 18
+    weights in f64; beyond that one ragged tile per env on k_actor_dma from K = 20, k_actor below.  _actor_cost of every
+    candidate against the float64 oracle with per-env weights that differ between the envs of ONE tile, the argmin on the
+    kernel's own costs bit for bit, a ragged last wave and tile, then three closed-loop ticks (critic fit in between)
+    checked tick by tick."""
+    from oracle import parity as PAR
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(7000 + 100 * mode + 10 * cs + K)
+    B, Nh = 1000 + 7, 6
+    eng, cfg = both(name, B, dtype, n_actor=Nh, mode=mode, critic_struct=cs, gamma=0.9, n_critic=4, buffer_size=6)
+    real = eng.real
+    x0 = rand_states(rng, name, B).astype(real)
+    eng.set_state(x0)
+    lo, hi = O.critic_bounds(cs, cfg.dc)
+    w = rng.uniform(np.maximum(lo, -2.0), np.minimum(hi, 2.0), (B, cfg.dc)).astype(real)
+    eng.set_field(N.FIELD_W_CRITIC, w)
+    cand = rand_actions(rng, name, (B, K, Nh)).astype(real)
+    clean = cand.copy()
+    cand[6, 1, 0, 0] = np.nan  # a NaN candidate is never selected
+    x64, w64, c64 = x0.astype(np.float64), w.astype(np.float64), cand.astype(np.float64)
+    J_or = O.actor_cost(c64, x64[:, None, :], x64[:, None, :], cfg, w_critic=w64[:, None, :])
+    dcand = eng.to_device(cand)
+    J = eng.actor_cost(dcand)
+    variant = (N.DMA_RQL_0 if mode == O.MODE_RQL else N.DMA_SQL_0) + cs
+    assert cfg.dc == _dc_of(name, cs)
+    slab16 = (K * Nh * cfg.du * real().itemsize) % 16 == 0
+    if slab16 and cfg.dc * real().itemsize <= 144:
+        kernel = "k_actor_dma_packed"
+    elif slab16 and K >= 20:
+        kernel = "k_actor_dma"
+    else:
+        kernel = "k_actor"
+    assert_kernel(eng, kernel, variant if kernel != "k_actor" else None)
+    fin = np.isfinite(J_or)
+    assert np.array_equal(np.isnan(J), ~fin)
+    scale = np.max(np.abs(np.where(fin, J_or, 0.0)), axis=1, keepdims=True)
+    assert np.max(np.abs(np.where(fin, J - J_or, 0.0)) / scale) < tol
+    a, bj, bi = eng.actor_argmin(dcand)
+    assert_kernel(eng, kernel)
+    Jc = np.where(np.isnan(J), np.inf, J)
+    np.testing.assert_array_equal(bi, np.argmin(Jc, axis=1).astype(np.int32))
+    np.testing.assert_array_equal(bj, Jc[np.arange(B), bi])
+    np.testing.assert_array_equal(a, cand[np.arange(B), bi, 0, :])
+    assert bi[6] != 1
+    # closed loop: env step + push + fit (k_critic_fit), then the packed decision; every env, every tick
+    dclean = eng.to_device(clean)
+    env = O.new_batch(cfg, x64)
+    env.w_critic = w64.copy()
+    env.w_prev = w64.copy()
+    eng.set_field(N.FIELD_W_PREV, w)
+    rep = PAR.TickReport()
+    for t in range(3):
+        eng.control_tick(dclean, K=K)
+        env = PAR.check_tick(cfg, env, clean.astype(np.float64), PAR.device_fields(eng, N, critic=True),
+                             tol=1e-9 if dtype == "f64" else 1e-5,
+                             tol_over={"w_critic": 1e-6, "best_J": 1e-7} if dtype == "f64" else None, report=rep,
+                             what=f"{name} K={K} mode {mode} cs {cs} {dtype} t={t}")
+    assert_kernel(eng, kernel)
+    assert rep.ticks == 3
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("mode", ["RQL", "SQL"])
 @pytest.mark.parametrize("name,cs", [("3wrobotNI", "quad-nomix"), ("3wrobotNI", "quad-mix"), ("3wrobot", "quad-nomix"),

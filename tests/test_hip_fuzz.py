@@ -25,7 +25,7 @@ def test_streamed_decision_of_a_random_shape(seed):
     cs = int(rng.integers(0, 4))
     du = 1 if name == "2tank" else 2
     Nh = int(rng.integers(1, 40 // du + 1))
-    K = int(rng.choice([2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 31, 32, 36, 40, 44, 63, 64, 65, 100, 128, 130, 192, 256, 300]))
+    K = int(rng.choice([2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 31, 32, 33, 35, 36, 38, 39, 40, 44, 52, 63, 64, 65, 100, 128, 130, 192, 256, 300]))
     B = int(rng.choice([1, 2, 5, 17, 64, 65, 129, 300]))
     gamma = float(rng.choice([1.0, 0.9]))
     lag = bool(rng.integers(0, 2))

@@ -295,6 +295,46 @@ def test_argmin_ties_and_nan(dtype, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["MPC", "RQL", "SQL"])
+@pytest.mark.parametrize("K", [33, 34, 35, 36, 37, 38, 39])
+def test_one_ragged_tile_below_64(K, mode, dtype):
+    """33 <= K <= 63 is ONE ragged tile of k_actor_dma (K lanes of 64 hold a row; profiles/r04_ab_min_k.txt: 1.5 - 3.1 x
+    k_actor at K = 33 .. 39), for every K whose env slab K * R * esz is a whole number of 16-byte pieces; the others stay on
+    k_actor.  Costs against the oracle, the argmin exact, the winner in the LAST row of the LAST env (the tile that ends at
+    the allocation's end), NaN rows never selected."""
+    from rcognita_amd import _native as N
+
+    name, Nh, B = "3wrobot", 5, 67
+    rng = np.random.default_rng(330 + K)
+    kw = dict(n_actor=Nh, mode=O.MODE_IDS[mode])
+    if mode != "MPC":
+        kw.update(critic_struct=O.CRITIC_IDS["quad-nomix"], n_critic=3, buffer_size=5, gamma=0.95)
+    eng, cfg = both(name, B, dtype, **kw)
+    x = rand_states(rng, name, B)
+    cand = rand_actions(rng, name, (B, K, Nh))
+    cand[B - 1, K - 1] = 0.0
+    cand[1, 5, 2, 0] = np.nan
+    w = None
+    eng.set_state(x)
+    if mode != "MPC":
+        w = rng.uniform(0.1, 2.0, (B, cfg.dc))
+        eng.set_field(N.FIELD_W_CRITIC, w)
+    J = eng.actor_cost(cand)
+    assert_kernel(eng, "k_actor_dma" if (K * Nh * 2 * eng.real().itemsize) % 16 == 0 else "k_actor")
+    J_or = O.actor_cost(cand, x[:, None, :], x[:, None, :], cfg, w_critic=None if w is None else w[:, None, :])
+    ok = ~np.isnan(J_or)
+    assert np.array_equal(np.isnan(J), ~ok)
+    scale = np.max(np.abs(np.where(ok, J_or, 0)), axis=1, keepdims=True)
+    assert float(np.max(np.abs(np.where(ok, J - J_or, 0)) / scale)) <= TOL[dtype]
+    act, bj, bi = eng.actor_argmin(cand)
+    Jc = np.where(np.isnan(J), np.inf, J)
+    np.testing.assert_array_equal(bi, np.argmin(Jc, axis=1).astype(np.int32))
+    np.testing.assert_array_equal(bj, Jc[np.arange(B), bi])
+    np.testing.assert_array_equal(act, cand[np.arange(B), bi, 0, :].astype(eng.real))
+    assert bi[1] != 5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name", SYSTEMS)
 @pytest.mark.parametrize("K", [1, 9, 64, 256, 1024])
 def test_generated_grid_vs_oracle(name, K, dtype):
@@ -576,7 +616,7 @@ def test_few_candidates_per_env_on_packed_tiles(name, Nh, K, dtype):
     """Streamed candidates with 4 <= K <= 32 (an env's rows a whole number of 16-byte pieces): k_actor_dma_packed - 64 / K envs share one DMA tile, the env state is
     per-lane, the argmin segmented (rcg_actor_dma_packed.hpp).  Operator (J of every row), argmin (ties -> lower index, NaN =
     +inf, all-NaN -> 0) and a three-tick closed loop against the oracle on a batch whose last wave and last tile are ragged;
-    gamma != 1 takes the discounted instance.  K = 36 (one env per tile would be mostly empty, no packing) stays on k_actor."""
+    gamma != 1 takes the discounted instance.  K = 36: no packing, one ragged tile per env on k_actor_dma."""
     from oracle import parity as PAR
     from rcognita_amd import _native as N
 
@@ -593,9 +633,10 @@ def test_few_candidates_per_env_on_packed_tiles(name, Nh, K, dtype):
     eng.set_state(x)
     dc = eng.to_device(cand)
     J = eng.actor_cost(dc)
-    packed = K <= 32 and (K * Nh * cfg.du * eng.real().itemsize) % 16 == 0  # an env's rows = whole 16-byte pieces
-    kernel = "k_actor_dma_packed" if packed else "k_actor"
-    assert_kernel(eng, kernel, (N.DMA_MPC_G1 if gamma == 1.0 else N.DMA_MPC) if packed else None)
+    slab16 = (K * Nh * cfg.du * eng.real().itemsize) % 16 == 0  # an env's rows = whole 16-byte pieces
+    packed = K <= 32 and slab16
+    kernel = "k_actor_dma_packed" if packed else ("k_actor_dma" if slab16 and K >= 33 else "k_actor")
+    assert_kernel(eng, kernel, (N.DMA_MPC_G1 if gamma == 1.0 else N.DMA_MPC) if slab16 else None)
     x64, c64 = x.astype(np.float64), cand.astype(np.float64)
     J_or = O.actor_cost(c64, x64[:, None, :], x64[:, None, :], cfg)
     fin = np.isfinite(J_or)

@@ -41,11 +41,13 @@ def child(lib, workload):
         return np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-np.pi, np.pi, n),
                          rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], -1)
 
-    B, K, Nh = 65536, 256, 10
+    B, K, Nh = 65536, int(os.environ.get("AB_K", "256")), 10
     if workload in ("gen", "opt0", "opt4", "search", "stream", "sql"):
         kw = {}
         if workload == "sql":
             kw = dict(mode="SQL", critic_struct="quad-lin", buffer_size=10)
+        if os.environ.get("AB_MODE"):  # e.g. AB_MODE=RQL AB_K=36 ... stream
+            kw = dict(mode=os.environ["AB_MODE"], critic_struct=os.environ.get("AB_CS", "quad-nomix"), buffer_size=10)
         eng = Engine(preset_engine_config("3wrobot", B, Nactor=Nh, **kw))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.set_state(st3(B))
@@ -99,7 +101,7 @@ def main():
     a = p.parse_args()
     if a.child:
         return child(*a.child)
-    env = {k: v for k, v in os.environ.items() if not k.startswith("RCG_")}
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RCG_")}  # (AB_K / AB_MODE / AB_CS pass through)
     for w in (ALL if a.workloads == ["all"] else a.workloads):
         res = {"A": [], "B": []}
         for _ in range(a.rounds):
