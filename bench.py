@@ -1013,14 +1013,19 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
     eng2.set_state(x0)
     for _ in range(5):
         eng2.control_tick(None, K=K)
-    eng2.profile((N.KERNEL_ACTOR,), stride=1)
+    # wall rate first, un-sampled (a launch that carries start / stop events costs the stream ~7 us: 10 % of this tick),
+    # then the kernel's own duration on every launch of a second loop
+    n2 = max(100, args.steps // 4)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    n2 = max(10, args.steps // 4)
     for _ in range(n2):
         eng2.control_tick(None, K=K)
     torch.cuda.synchronize()
     d2 = time.perf_counter() - t1
+    eng2.profile((N.KERNEL_ACTOR,), stride=1)
+    for _ in range(max(10, args.steps // 4)):
+        eng2.control_tick(None, K=K)
+    torch.cuda.synchronize()
     ms2, c2 = eng2.profile_read(N.KERNEL_ACTOR)
     eng2.profile(False)
     evals_kernel = B * K / max(ms2 / max(c2, 1) * 1e-3, 1e-12)

@@ -770,7 +770,7 @@ int rcg_candidates_sample(rcg_handle* h, void* cand, int32_t K, int32_t round, c
   const int R = h->cfg.n_actor * h->du;
   const int32_t* ep = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
   const int32_t* st = (const int32_t*)h->f[RCG_FIELD_STEP_IDX];
-  const dim3 grid(blocks_for(rows)), block(256);
+  const dim3 grid(blocks_for(rows * ((R + 3) / 4))), block(256);  // one thread per 4-element chunk of a row
 #define RCG_SAMPLE(DU, real, P)                                                                                          \
   hipLaunchKernelGGL((k_cand_sample<DU, real>), grid, block, 0, h->stream, (real*)cand, (const real*)centre, ep, st, (int)K, \
                      (int)round, R, (uint64_t)h->cfg.seed, (int64_t)h->cfg.env_id_base, (real)h->cfg.action_init[0],     \

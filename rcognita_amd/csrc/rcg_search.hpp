@@ -241,34 +241,52 @@ __global__ __launch_bounds__(256) void k_actor_search(const SearchArgs<real> A, 
 // The producer alone (rcg_candidates_sample): one thread per candidate row of `round` around `centre` [B][N][du] (nullptr:
 // u0 tiled) -> cand [B][K][N][du].  The rows k_actor_search evaluates in that round, for inspection, tests, and callers that
 // want to stream them through rcg_actor_cost / rcg_actor_argmin.
+// One thread per 4-element chunk of a row (16 bytes in f32): consecutive threads write consecutive chunks, so a wave's store
+// is one contiguous 1-KiB piece of the tensor (round 4's first version gave a thread a whole row - 80-byte strides between
+// lanes, 1.3 ms for C2's 1.34 GB; this one is bound by the write stream).
 template <int DU, typename real>
 __global__ __launch_bounds__(256) void k_cand_sample(real* cand, const real* centre_in, const int32_t* episode_idx,
                                                      const int32_t* step_idx, int K, int round, int R, uint64_t seed,
                                                      int64_t env_id_base, real u00, real u01, const KParams<real> P) {
-  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_chunks = (R + 3) / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long B = P.B;
-  if (row >= B * K) return;
+  if (idx >= B * K * n_chunks) return;
+  const long row = idx / n_chunks;
+  const int j = (int)(idx - row * n_chunks);
   const long b = row / K;
   const int k = (int)(row - b * K);
   const CandKey key = cand_subkey(seed, env_id_base + b, episode_idx[b], step_idx[b]);
   real sigma[DU], u0[RCG_MAX_DU] = {u00, u01};
 #pragma unroll
   for (int c = 0; c < DU; ++c) sigma[c] = ((real)0.5 * (P.hi[c] - P.lo[c])) * (real)exp2(-(double)round);
-  float xi0[4];
-  cand_normals4(key, k, 0, round, xi0);
-  real* const out = cand + row * R;
-  const int n_chunks = (R + 3) / 4;
-  for (int j = 0; j < n_chunks; ++j) {
-    real ce[4], v[4];
+  float xi0[4] = {0, 0, 0, 0};
+  if (!(k >= (K >> 1) && k > 0 && j > 0)) cand_normals4(key, k, 0, round, xi0);  // (a per-step row draws chunk j itself)
+  real ce[4], v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = 4 * j + e;
-      ce[e] = i < R ? (centre_in ? centre_in[b * R + i] : u0[e % DU]) : (real)0;
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * j + e;
+    ce[e] = i < R ? (centre_in ? centre_in[b * R + i] : u0[e % DU]) : (real)0;
+  }
+  cand_chunk<DU, real>(P, key, k, K, j, round, ce, R - 4 * j, sigma, u0, xi0, v);
+  real* const out = cand + row * R + 4 * j;
+  if ((R & 3) == 0 && (reinterpret_cast<uintptr_t>(cand) & 15) == 0) {  // whole, 16-byte aligned chunks: vector stores
+    if constexpr (sizeof(real) == 4) {
+      typedef real vec4 __attribute__((ext_vector_type(4)));
+      vec4 q;
+      q.x = v[0], q.y = v[1], q.z = v[2], q.w = v[3];
+      __builtin_nontemporal_store(q, reinterpret_cast<vec4*>(out));
+    } else {
+      typedef real vec2 __attribute__((ext_vector_type(2)));
+      vec2 a, c;
+      a.x = v[0], a.y = v[1], c.x = v[2], c.y = v[3];
+      __builtin_nontemporal_store(a, reinterpret_cast<vec2*>(out));
+      __builtin_nontemporal_store(c, reinterpret_cast<vec2*>(out + 2));
     }
-    cand_chunk<DU, real>(P, key, k, K, j, round, ce, R - 4 * j, sigma, u0, xi0, v);
+  } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (4 * j + e < R) out[4 * j + e] = v[e];
+      if (4 * j + e < R) out[e] = v[e];
   }
 }
 

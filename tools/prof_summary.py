@@ -155,11 +155,21 @@ def valu_summary(a):
     # instructions per evaluation for the generated-grid rollout of the bench workload (k_actor, Sys3WRobot, f32, GENERIC=0)
     vi = os.path.join(ROOT, "profiles", "valu_instr.json")
     t = json.load(open(vi)) if os.path.exists(vi) else {}
+    def gen_kernel(sysname, tgt):
+        """The kernel a generated-grid tick of this system runs (round 4: the fused k_ticks_pk for the robots' preset
+        weights, else the hand-packed k_actor instance, else the general one): first prefix that has launches."""
+        for pre in (f"rcg::k_ticks_pk<rcg::{sysname}>", f"rcg::k_actor<rcg::{sysname}, float, false, {tgt}, false, true>",
+                    f"rcg::k_actor<rcg::{sysname}, float, false, {tgt}, false"):
+            hh = [(k, d) for k, d in per.items() if k.startswith(pre) and d.get("SQ_INSTS_VALU_per_launch")]
+            if hh:
+                return hh
+        return []
+
     # the mixed pool of configs[4] (valu_probe.py pool): one generated-grid kernel per system type, K = 256, N = 15
     for sysname, tgt in (("Sys3WRobot", "false"), ("Sys3WRobotNI", "false"), ("Sys2Tank", "true")):
         key = {"Sys3WRobot": "3wrobot", "Sys3WRobotNI": "3wrobotNI", "Sys2Tank": "2tank"}[sysname]
         uu = units.get(f"k_actor_generated_{key}_N15_f32_C5")
-        hh = [(k, d) for k, d in per.items() if k.startswith(f"rcg::k_actor<rcg::{sysname}, float, false, {tgt}, false>")]
+        hh = gen_kernel(sysname, tgt)
         if uu and hh:
             k, d = hh[0]
             t[f"k_actor_generated_{key}_N15_f32_C5"] = {
@@ -175,12 +185,12 @@ def valu_summary(a):
     for mode, gen in (("MPC", "false"), ("RQL", "true"), ("SQL", "true")):
         key = f"k_actor_generated_2tank_N20_{mode}_f32"
         uu = units.get(key)
-        hh = [(k, d) for k, d in per.items() if k.startswith(f"rcg::k_actor<rcg::Sys2Tank, float, {gen}, true, false>")]
+        hh = [(k, d) for k, d in per.items() if k.startswith(f"rcg::k_actor<rcg::Sys2Tank, float, {gen}, true, false")]
         if uu and hh and hh[0][1]["launches"] == launches_each:
             k, d = hh[0]
             t[key] = {"valu_instr_per_eval": d["SQ_INSTS_VALU_per_launch"] * 64 / uu["evals"], "round": a.round, "kernel": k,
                       "launches": d["launches"]}
-    hit = [(k, d) for k, d in per.items() if k.startswith("rcg::k_actor<rcg::Sys3WRobot, float, false, false, false>")]
+    hit = [(k, d) for k, d in gen_kernel("Sys3WRobot", "false") if d["launches"] == launches_each] if launches_each else []
     u = units.get("k_actor_generated_3wrobot_N10_f32")
     if t:
         json.dump(t, open(vi, "w"), indent=1, sort_keys=True)

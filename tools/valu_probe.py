@@ -11,7 +11,8 @@ the units one launch processes - the denominators of "instructions per evaluatio
 
 Workloads: generated-grid rollout (k_actor, C2 shape and configs[2] shape, MPC / RQL / SQL), the on-device optimiser
 (k_actor_opt), the critic fit (k_critic_fit), the nominal controllers (k_nominal), the persistent multi-tick kernel
-(k_ticks), the per-GPU shard of configs[4].
+(k_ticks, k_ticks_pk), the device-side search (k_actor_search), the streamed SQL instance with 35 features, the per-GPU
+shard of configs[4].
 """
 import json
 import os
@@ -33,12 +34,14 @@ def states(rng, name, n):
 
 
 def main():
+    import torch  # noqa: F401  (before the first Engine: torch's HIP runtime must be the one that initialises the GPU)
+
     from rcognita_amd import Engine
     from rcognita_amd.pool import MixedPool, preset_engine_config
 
     rng = np.random.default_rng(1234)
     n = int(os.environ.get("VALU_PROBE_LAUNCHES", "6"))
-    part = sys.argv[1] if len(sys.argv) > 1 else "main"  # "pool": configs[4] alone (it re-uses kernel instances of "main"); "c3rql" / "c3sql"
+    part = sys.argv[1] if len(sys.argv) > 1 else "main"  # "ticks": B = 1024 persistent kernels; "pool": configs[4] alone (it re-uses kernel instances of "main"); "c3rql" / "c3sql"
     units = {}
     if part == "pool":
         total = 65536
@@ -75,6 +78,18 @@ def main():
         units[key] = per_launch
         eng.close()
 
+    if part == "ticks":  # the persistent kernels at a small batch, alone (k_ticks_pk also serves the C2 tick of "main")
+        Bs, T = 1024, 64
+        e = Engine(preset_engine_config("3wrobot", Bs, Nactor=10))
+        e.set_state(states(rng, "3wrobot", Bs))
+        run("k_ticks_3wrobot_B1024_K64_T64_f32", e, lambda: e.control_ticks(T, 64), {"evals": Bs * 64 * T, "envs": Bs, "ticks": T})
+        e = Engine(preset_engine_config("3wrobot", Bs, Nactor=10))
+        e.set_state(states(rng, "3wrobot", Bs))
+        run("k_ticks_pk_3wrobot_B1024_K256_T64_f32", e, lambda: e.control_ticks(T, 256),
+            {"evals": Bs * 256 * T, "envs": Bs, "ticks": T})
+        print(json.dumps({"launches_each": n, "units_per_launch": units}))
+        return
+
     B, K = 65536, 256
     e = Engine(preset_engine_config("3wrobot", B, Nactor=10))
     e.set_state(states(rng, "3wrobot", B))
@@ -98,10 +113,22 @@ def main():
         e.set_state(states(rng, name, B))
         run(f"k_nominal_{name}_f32", e, lambda: e.control_tick_nominal(gain), {"envs": B})
 
-    Bs, T = 1024, 64
-    e = Engine(preset_engine_config("3wrobot", Bs, Nactor=10))
-    e.set_state(states(rng, "3wrobot", Bs))
-    run("k_ticks_3wrobot_B1024_K64_T64_f32", e, lambda: e.control_ticks(T, 64), {"evals": Bs * 64 * T, "envs": Bs, "ticks": T})
+    # round 4: the device-side candidate search (one round of K = 256 Philox rows per env), the quasi-Newton optimiser in
+    # a critic mode (memory 4), the streamed SQL instance with 35 features (VALU-bound although it streams)
+    e = Engine(preset_engine_config("3wrobot", B, Nactor=10))
+    e.set_state(states(rng, "3wrobot", B))
+    run("k_actor_search_3wrobot_N10_K256_f32", e, lambda: e.control_tick_search(K=K, rounds=1, warm_start=True),
+        {"evals": B * K, "envs": B})
+    e = Engine(preset_engine_config("3wrobot", B, Nactor=10, mode="RQL", critic_struct="quad-nomix", buffer_size=10))
+    e.set_state(states(rng, "3wrobot", B))
+    run("k_actor_opt_3wrobot_N10_RQL_iters5_m4_f32", e, lambda: e.control_tick_opt(iters=5),
+        {"evals": B * 5 * 17, "envs": B, "iters": 5})
+    e = Engine(preset_engine_config("3wrobot", B, Nactor=10, mode="SQL", critic_struct="quad-lin", buffer_size=10))
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.set_state(states(rng, "3wrobot", B))
+    cand = (torch.rand((B, K, 10, 2), device="cuda") * torch.tensor([600.0, 200.0], device="cuda")
+            - torch.tensor([300.0, 100.0], device="cuda")).contiguous()
+    run("k_actor_dma_sql_quadlin_3wrobot_N10_K256_f32", e, lambda: e.control_tick(cand, K=K), {"evals": B * K, "envs": B})
 
     print(json.dumps({"launches_each": n, "units_per_launch": units}))
 
