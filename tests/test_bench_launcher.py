@@ -20,7 +20,11 @@ def _run(argv, env_extra=None, timeout=300):
 
 
 @pytest.mark.parametrize("n,extra,total", [(2, [], 2 * 65536), (3, ["--scaling", "strong", "--batch", "100"], 100),
-                                           (2, ["--config", "C4"], 524288), (2, ["--config", "C3"], 2 * 131072)])
+                                           (2, ["--config", "C4"], 524288), (2, ["--config", "C3"], 2 * 131072),
+                                           # the driver's N = 8 forms: C2 weak, and configs[4] strong with a ragged total
+                                           (8, [], 8 * 65536),
+                                           (8, ["--config", "C5", "--scaling", "strong", "--batch", str(8 * 65536 + 5)],
+                                            8 * 65536 + 5)])
 def test_gpus_n_spawns_n_ranks_that_tile_the_job(n, extra, total):
     out = _run(["--gpus", str(n), "--dry-launch"] + extra)
     assert out.returncode == 0, out.stderr[-2000:]
