@@ -2,7 +2,8 @@
 """Streamed RQL / SQL decisions of the robots and the tank in both element types: kernel that ran (rcg_last_launch), time per
 launch from the dispatch's own stamps, algorithmic TB/s.  GPU box only.
 
-    python tools/critic_stream_probe.py [f64|f32] [B]
+    python tools/critic_stream_probe.py [f64|f32] [B] [all]
+    PROBE_LIB=rcognita_amd/lib/librcg_dev.so RCG_PER_CU=4 python tools/critic_stream_probe.py f32 65536 all   # a dev-build knob
 """
 import os
 import sys
@@ -12,8 +13,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from rcognita_amd import Engine  # noqa: E402
 from rcognita_amd import _native as N  # noqa: E402
+
+if os.environ.get("PROBE_LIB"):
+    N.use_library(os.path.join(ROOT, os.environ["PROBE_LIB"]))
+from rcognita_amd import Engine  # noqa: E402
 from rcognita_amd.pool import PRESETS, preset_engine_config  # noqa: E402
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f64"
@@ -22,7 +26,10 @@ K, Nh = 256, 10
 td = torch.float64 if dtype == "f64" else torch.float32
 esz = 8 if dtype == "f64" else 4
 rng = np.random.default_rng(0)
-for name, mode, cs in (("3wrobot", "MPC", "quad-nomix"), ("3wrobot", "RQL", "quad-nomix"), ("3wrobot", "RQL", "quad-lin"),
+ALL = [(n, "MPC", "quad-nomix") for n in ("3wrobot", "3wrobotNI", "2tank")] + [
+    (n, m, c) for n in ("3wrobot", "3wrobotNI", "2tank") for m in ("RQL", "SQL")
+    for c in ("quad-lin", "quadratic", "quad-nomix", "quad-mix")]
+for name, mode, cs in ALL if (len(sys.argv) > 3 and sys.argv[3] == "all") else (("3wrobot", "MPC", "quad-nomix"), ("3wrobot", "RQL", "quad-nomix"), ("3wrobot", "RQL", "quad-lin"),
                        ("3wrobot", "SQL", "quad-nomix"), ("3wrobot", "SQL", "quadratic"), ("3wrobot", "SQL", "quad-lin"),
                        ("3wrobotNI", "RQL", "quadratic"), ("3wrobotNI", "SQL", "quad-mix"), ("2tank", "RQL", "quadratic"),
                        ("2tank", "SQL", "quad-lin")):
