@@ -17,13 +17,16 @@ ORACLE  := $(ROOT)oracle
 
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -ffp-contract=fast \
             -I$(ROOT)include
-# the C ABI + one unit per environment (every system-templated kernel except k_actor_dma)
-UNITS   := rcg_api rcg_sys_3wrobot rcg_sys_3wrobotni rcg_sys_2tank
+# the C ABI; the system-templated launchers and kernels: rcg_sys_inst.hip compiled once per (system, part), see that file
+UNITS   := rcg_api
+SYSP    := $(foreach s,Sys3WRobot.kVt3WRobot Sys3WRobotNI.kVt3WRobotNI Sys2Tank.kVt2Tank,$(foreach p,0 1 2 3 4,$(s).$(p)))
+SYSFLAGS = -DRCG_SYS=$(word 1,$(subst ., ,$*)) -DRCG_SYS_VT=$(word 2,$(subst ., ,$*)) -DRCG_SYS_PART=$(word 3,$(subst ., ,$*))
 # k_actor_dma instances: rcg_dma_inst.hip compiled once per (system, element type, group), see that file
 DMA     := $(foreach s,Sys3WRobot Sys3WRobotNI Sys2Tank,$(foreach r,float double,$(foreach g,0 1 2 3 4 5,$(s).$(r).$(g))))
 DMAFLAGS = -DRCG_INST_SYS=$(word 1,$(subst ., ,$*)) -DRCG_INST_REAL=$(word 2,$(subst ., ,$*)) \
            -DRCG_INST_GROUP=$(word 3,$(subst ., ,$*))
-objs     = $(addprefix $(1)/,$(addsuffix .o,$(UNITS))) $(addprefix $(1)/rcg_dma.,$(addsuffix .o,$(DMA)))
+objs     = $(addprefix $(1)/rcg_sys.,$(addsuffix .o,$(SYSP))) $(addprefix $(1)/,$(addsuffix .o,$(UNITS))) \
+           $(addprefix $(1)/rcg_dma.,$(addsuffix .o,$(DMA)))
 OBJS    := $(call objs,$(OBJDIR))
 HDRS    := $(wildcard $(CSRC)/*.hpp) $(ROOT)include/rcg.h
 
@@ -43,6 +46,10 @@ $(OBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(DMAFLAGS) -c $< -o $@
 
+$(OBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(SYSFLAGS) -c $< -o $@
+
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -61,6 +68,10 @@ $(DEVOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
 	@mkdir -p $(DEVOBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRCG_DEV $(DMAFLAGS) -c $< -o $@
 
+$(DEVOBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+	@mkdir -p $(DEVOBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DRCG_DEV $(SYSFLAGS) -c $< -o $@
+
 $(DEVOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(DEVOBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRCG_DEV -c $< -o $@
@@ -77,6 +88,10 @@ ABOBJS   := $(call objs,$(ABOBJDIR))
 $(ABOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
 	@mkdir -p $(ABOBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) $(DMAFLAGS) -c $< -o $@
+
+$(ABOBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+	@mkdir -p $(ABOBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) $(SYSFLAGS) -c $< -o $@
 
 $(ABOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(ABOBJDIR)
@@ -95,6 +110,10 @@ ASANHIP := -std=c++17 --offload-arch=$(ARCH) --offload-host-only $(SANFLAGS) -fP
 $(ASANDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
 	@mkdir -p $(ASANDIR)
 	$(HIPCC) $(ASANHIP) $(DMAFLAGS) -c $< -o $@
+
+$(ASANDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+	@mkdir -p $(ASANDIR)
+	$(HIPCC) $(ASANHIP) $(SYSFLAGS) -c $< -o $@
 
 $(ASANDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(ASANDIR)

@@ -1,5 +1,5 @@
 // rcg_api.hip - C ABI (include/rcg.h) of librcg.so: handle life cycle, per-env tensors, dispatch to the
-// per-system launchers (rcg_sys_*.hip via SysVTable) and the system-independent kernels.
+// per-system launchers (rcg_sys_inst.hip via SysVTable) and the system-independent kernels.
 //
 // There is no CPU fallback in this library: without a HIP device rcg_create fails with RCG_ERR_NO_DEVICE.
 #include <cstdarg>

@@ -194,7 +194,7 @@ static inline size_t opt_wave_lds_bytes(const rcg_handle* h) {
 
 static inline unsigned blocks_for(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
-// Everything that depends on the system type, one table per environment (rcg_sys_*.hip).
+// Everything that depends on the system type, one table per environment (rcg_sys_inst.hip, part 0).
 struct SysVTable {
   int (*rhs)(rcg_handle*, const void* state, const void* action, void* dstate, void* clipped, int32_t n, int32_t clip);
   int (*stage_obj)(rcg_handle*, const void* obs, const void* act, void* out, int32_t n);

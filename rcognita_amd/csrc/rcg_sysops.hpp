@@ -100,7 +100,7 @@ static int op_critic_cost(rcg_handle* h, const void* w, void* Jc) {
 }
 
 template <typename Sys>
-static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
+int op_sim_step(rcg_handle* h, int32_t n_substeps) {
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
     SimArgs<real> A;
@@ -153,7 +153,7 @@ static int op_sim_step(rcg_handle* h, int32_t n_substeps) {
 }
 
 template <typename Sys>
-static int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t do_fit) {
+int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t do_fit) {
   const int m = h->cfg.n_critic - 1;
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
@@ -253,7 +253,7 @@ static inline const DevKnobs& dev_knobs() {
 }
 
 template <typename Sys>
-static int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand);
+int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand);
 
 // ---- k_actor / k_actor_dma ---------------------------------------------------------------------
 // `sim_first`: rcg_control_tick (MPC) - run the env step of the tick before the decision.
@@ -425,7 +425,13 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     // ... and 4 as well when a wave's whole slab is short (< 64 KB: K = 64 at Nactor = 10 is 8 tiles per wave - the launch
     // is ramp-up and tail, more resident waves fill it better: 5.15 -> 5.57 TB/s)
     const bool long_slab = (size_t)gpw * K * row_bytes >= (size_t)64 * 1024;
-    const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 80 && long_slab) ? 2 : 4);
+    // ... and 4 for the critic instances with many weights (>= 68 bytes of them: the robots' quad-lin / quadratic / quad-mix
+    // structures in f32, 2tank quad-lin in f64), which are bound by VALU issue, not by the stream: more resident waves hide
+    // more of it - 4-5 % on random weights, 8-11 % inside a closed loop (profiles/r04_per_cu_matrix.txt, r04_ab_per_cu.txt:
+    // SQL quad-lin 307 -> 280 us, SQL quadratic 261 -> 232); MPC and the small structures lose 1-2 % with 4
+    const bool valu_heavy = variant >= DMA_RQL_0 &&
+                            (size_t)dma_dc(variant >= DMA_SQL_0 ? variant - DMA_SQL_0 : variant - DMA_RQL_0, Sys::DS, DU) * esz >= 68;
+    const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 80 && long_slab && !valu_heavy) ? 2 : 4);
     // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
     Ad.jwave = (A.J && 4 * tile + wslot + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
     size_t lds_req = 4 * tile + wslot + (A.J ? 4 * esz * K * (Ad.jwave ? gpw : 1) : 0);
@@ -494,7 +500,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
 }
 
 template <typename Sys>
-static int op_actor(rcg_handle* h, const char* who, const void* cand, int K, const void* obs, const void* state_sys,
+int op_actor(rcg_handle* h, const char* who, const void* cand, int K, const void* obs, const void* state_sys,
                     const void* w, void* J, void* action, void* best_J, int32_t* best_idx, bool tick, bool sim_first) {
   return by_dtype(h, [&](auto r) {
     return launch_actor<Sys, decltype(r)>(h, who, cand, K, obs, state_sys, w, J, action, best_J, best_idx, tick,
@@ -503,7 +509,7 @@ static int op_actor(rcg_handle* h, const char* who, const void* cand, int K, con
 }
 
 template <typename Sys>
-static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
+int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state_sys, const void* u_init,
                        int shift, void* u_opt, void* action, void* best_J, int32_t* n_iter, bool tick, bool sim_first) {
   const rcg_cfg& c = h->cfg;
   return by_dtype(h, [&](auto r) {
@@ -573,7 +579,7 @@ static int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
 // rcg_actor_search / rcg_control_tick_search: `rounds` rounds of K generated candidates per env, evaluated where they are
 // generated (k_actor_search, rcg_search.hpp).  The caller (rcg_api.hip) has checked K and the critic weights.
 template <typename Sys>
-static int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, const void* obs, const void* state_sys,
+int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, const void* obs, const void* state_sys,
                      const void* centre, int shift, void* u_best, void* action, void* best_J, int32_t* best_idx, bool tick,
                      bool sim_first) {
   const rcg_cfg& c = h->cfg;
@@ -638,7 +644,7 @@ static int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, c
 // (cand == nullptr) or the caller's candidate tensor, with or without the disturbance model.  The caller has checked
 // mode / K.
 template <typename Sys>
-static int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
+int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
   constexpr int DU = Sys::DU;
   const rcg_cfg& c = h->cfg;
   return by_dtype(h, [&](auto r) {
@@ -754,7 +760,7 @@ static bool ticks_mem_ok(const rcg_handle* h) {
 }
 
 template <typename Sys>
-static int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
+int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
   constexpr int DU = Sys::DU;
   const rcg_cfg& c = h->cfg;
   if (!ticks_mem_ok<Sys>(h)) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: no persistent RQL/SQL instance for this observation target");
@@ -862,8 +868,10 @@ static int op_nominal(rcg_handle* h, const void* obs, void* action, void* lyap, 
   }
 }
 
-// Explicitly instantiated once per environment (rcg_sys_*.hip): pulls in every launcher above and,
-// through their launch expressions, every kernel.
+// The launchers above are instantiated per environment by rcg_sys_inst.hip, which is compiled once per (system, part): the
+// heavy ones (op_actor, op_ticks, op_ticks_mem, op_optimize + op_search, op_sim_step + op_critic_update) each in a part of
+// their own - `extern template` everywhere else - so that no object takes more than about a minute to build; part 0 holds
+// the table below and the light launchers.  Through their launch expressions the launchers pull in every kernel.
 template <typename Sys>
 struct SysInstances {
   static SysVTable table() {

@@ -48,12 +48,20 @@ def child(lib, workload):
             kw = dict(mode="SQL", critic_struct="quad-lin", buffer_size=10)
         if os.environ.get("AB_MODE"):  # e.g. AB_MODE=RQL AB_K=36 ... stream
             kw = dict(mode=os.environ["AB_MODE"], critic_struct=os.environ.get("AB_CS", "quad-nomix"), buffer_size=10)
-        eng = Engine(preset_engine_config("3wrobot", B, Nactor=Nh, **kw))
+        name = os.environ.get("AB_SYS", "3wrobot") if workload == "stream" else "3wrobot"  # AB_SYS / AB_B / AB_N: stream only
+        if workload == "stream":
+            B, Nh = int(os.environ.get("AB_B", B)), int(os.environ.get("AB_N", Nh))
+            if name == "2tank" and "Ncritic" not in kw and kw:
+                kw["Ncritic"] = 4
+        eng = Engine(preset_engine_config(name, B, Nactor=Nh, **kw))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        eng.set_state(st3(B))
+        eng.set_state({"3wrobot": st3(B), "3wrobotNI": st3(B)[:, :3],
+                       "2tank": np.stack([rng.uniform(0, 2, B), rng.uniform(-2, 2, B)], -1)}[name])
         if workload in ("stream", "sql"):
-            cand = (torch.rand((B, K, Nh, 2), device="cuda") * torch.tensor([600.0, 200.0], device="cuda")
-                    - torch.tensor([300.0, 100.0], device="cuda")).contiguous()
+            from rcognita_amd.pool import PRESETS
+
+            bnd = torch.tensor(np.array(PRESETS[name]["ctrl_bnds"]), device="cuda", dtype=torch.float32)
+            cand = (torch.rand((B, K, Nh, eng.du), device="cuda") * (bnd[:, 1] - bnd[:, 0]) + bnd[:, 0]).contiguous()
             step = lambda: eng.control_tick(cand, K=K)
         elif workload == "gen":
             step = lambda: eng.control_tick(None, K=K)
