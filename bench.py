@@ -1104,6 +1104,31 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
     except Exception as e:  # never let a secondary figure take the bench line down
         sec["device_search"] = {"error": str(e)[:300]}
     eng2.close()
+    # (2c) small batches: T ticks per launch (rcg_control_tick_n / rcg_control_ticks) against the loop of single ticks, the
+    #   regime where two launches per tick (~8 us) dwarf ~1 us of work: B = 1024, K = 64 of the same workload
+    try:
+        Bs, Ks, Ts = 1024, 64, 256
+        sb = {}
+        for tag in ("streamed", "generated"):
+            ecs, _ = c2_engine_config(args, device, Bs)
+            es = Engine(ecs)
+            es.set_stream(stream_ptr)
+            es.set_state(x0[:Bs])
+            cs = None
+            if tag == "streamed":
+                blo32 = torch.tensor(bnds[:, 0], device="cuda", dtype=torch.float32 if args.dtype == "f32" else torch.float64)
+                bhi32 = torch.tensor(bnds[:, 1], device="cuda", dtype=blo32.dtype)
+                cs = (torch.rand((Bs, Ks, Nh, du), device="cuda", dtype=blo32.dtype) * (bhi32 - blo32) + blo32).contiguous()
+            per = timed(lambda: [es.control_tick(cs, K=Ks) for _ in range(Ts)], 2) / Ts
+            k_per = es.last_launch(N.KERNEL_ACTOR)["kernel"]
+            one = timed(lambda: es.control_tick(cs, K=Ks, T=Ts), 4) / Ts
+            sb[tag] = {"one_launch_steps_per_s": Bs / one, "per_tick_launches_steps_per_s": Bs / per, "speedup": per / one,
+                       "kernel_one_launch": es.last_launch(N.KERNEL_ACTOR)["kernel"], "kernel_per_tick": "k_sim + " + k_per}
+            es.close()
+        sb["shape"] = f"B={Bs}, K={Ks}, Nactor={Nh}, T={Ts} ticks per call"
+        sec["small_batch_ticks"] = sb
+    except Exception as e:  # never let a secondary figure take the bench line down
+        sec["small_batch_ticks"] = {"error": str(e)[:300]}
     # (3) the reference's own arithmetic width: the same tick in float64 (streamed candidates, 2 x the bytes)
     if args.dtype == "f32" and args.regime == "streamed":
         try:

@@ -1,7 +1,7 @@
 // rcg_actor_dma_packed.hpp - k_actor_dma_packed: k_actor_dma's data path for FEW candidates per env
 // (CtrlOptPred._actor_cost for K candidates per env + argmin + tick epilogue; controllers.py:1273-1427).
 //
-// k_actor_dma gives every env tiles of its own: at K < 40 a tile would be mostly empty (K = 16: a quarter of the lanes
+// k_actor_dma gives every env tiles of its own: at K <= 32 a tile would be at least half empty (K = 16: a quarter of the lanes
 // work, the wave moves 1.3 KB per round trip to HBM).  Here a tile of 64 rows holds G = 64 / K consecutive envs - their
 // rows are contiguous in the [B][K][N][du] tensor - so the DMA, the row read and the rollout are exactly k_actor_dma's,
 // and what changes is per-lane bookkeeping:

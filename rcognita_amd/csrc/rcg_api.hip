@@ -766,11 +766,12 @@ int rcg_candidates_sample(rcg_handle* h, void* cand, int32_t K, int32_t round, c
   DeviceGuard dev_guard(h);
   if (!h || !cand) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_candidates_sample: cand is required");
   if (K < 1 || round < 0 || round > 63) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_candidates_sample: need K >= 1 and 0 <= round <= 63");
-  const long rows = (long)h->cfg.batch * K;
   const int R = h->cfg.n_actor * h->du;
   const int32_t* ep = (const int32_t*)h->f[RCG_FIELD_EPISODE_IDX];
   const int32_t* st = (const int32_t*)h->f[RCG_FIELD_STEP_IDX];
-  const dim3 grid(blocks_for(rows * ((R + 3) / 4))), block(256);  // one thread per 4-element chunk of a row
+  const long chunks_per_env = (long)K * ((R + 3) / 4);  // one thread per 4-element chunk of a row, a block inside one env
+  if ((chunks_per_env + 255) / 256 > 65535) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_candidates_sample: K * Nactor * du too large");
+  const dim3 grid((unsigned)h->cfg.batch, (unsigned)((chunks_per_env + 255) / 256)), block(256);
 #define RCG_SAMPLE(DU, real, P)                                                                                          \
   hipLaunchKernelGGL((k_cand_sample<DU, real>), grid, block, 0, h->stream, (real*)cand, (const real*)centre, ep, st, (int)K, \
                      (int)round, R, (uint64_t)h->cfg.seed, (int64_t)h->cfg.env_id_base, (real)h->cfg.action_init[0],     \

@@ -706,6 +706,14 @@ __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const ty
                                                 const real* y0, real& bestJ, int& bestI, real* bestU) {
   const int k0 = t * 64 + lane;
   real ua[NC][2], u0v[NC], J[NC];
+#ifdef RCG_AB_DIV
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ua[c][0] = ua[c][1] = 0;
+    gen_candidate<2, real>(P, g, k0 + 64 * c, ua[c]);
+    u0v[c] = ua[c][0];
+  }
+#else
   {
     // gen_candidate's levels without its integer divisions: 64 % g == 0 makes g a power of two, so candidate k0 + 64 c has
     // first level (k0 >> lg) + c (64 >> lg) and second level k0 & (g - 1) - the same integers, fed to the same arithmetic
@@ -722,6 +730,7 @@ __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const ty
       u0v[c] = ua[c][0];
     }
   }
+#endif
   if constexpr (PKONLY) {
     static_assert(std::is_same<real, float>::value && !TGT && NC == 4 && GenPk<Sys>::supported, "see GenPk");
     GenPk<Sys>::run(P, pre, N, xs, y0, u0v, ua[0][1], J);  // the same bits, two candidates per instruction

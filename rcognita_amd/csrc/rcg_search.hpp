@@ -238,28 +238,30 @@ __global__ __launch_bounds__(256) void k_actor_search(const SearchArgs<real> A, 
   }
 }
 
-// The producer alone (rcg_candidates_sample): one thread per candidate row of `round` around `centre` [B][N][du] (nullptr:
-// u0 tiled) -> cand [B][K][N][du].  The rows k_actor_search evaluates in that round, for inspection, tests, and callers that
-// want to stream them through rcg_actor_cost / rcg_actor_argmin.
-// One thread per 4-element chunk of a row (16 bytes in f32): consecutive threads write consecutive chunks, so a wave's store
-// is one contiguous 1-KiB piece of the tensor (round 4's first version gave a thread a whole row - 80-byte strides between
-// lanes, 1.3 ms for C2's 1.34 GB; this one is bound by the write stream).
+// The producer alone (rcg_candidates_sample): the rows k_actor_search evaluates in `round` around `centre` [B][N][du] (nullptr:
+// u0 tiled) -> cand [B][K][N][du], for inspection, tests, and callers that want to stream them through rcg_actor_cost /
+// rcg_actor_argmin.  Grid (B, ceil(K * chunks / 256)): a block works inside ONE env - its key (one Philox call) is drawn once
+// per block - and a thread produces one 4-element chunk of a row (16 bytes in f32), so a wave's store is one contiguous 1-KiB
+// piece of the tensor.  History (C2: 1.34 GB): one thread per row, 80-byte strides between lanes: 1.3 ms; one thread per
+// chunk on a flat 64-bit index (two 64-bit integer divisions and a double-precision exp2 per thread): 0.72 ms; this form:
+// see DESIGN.md 5 - what remains is the generator (Philox's 32-bit multiplies, the Box-Muller transcendentals).
 template <int DU, typename real>
 __global__ __launch_bounds__(256) void k_cand_sample(real* cand, const real* centre_in, const int32_t* episode_idx,
                                                      const int32_t* step_idx, int K, int round, int R, uint64_t seed,
                                                      int64_t env_id_base, real u00, real u01, const KParams<real> P) {
-  const int n_chunks = (R + 3) / 4;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long B = P.B;
-  if (idx >= B * K * n_chunks) return;
-  const long row = idx / n_chunks;
-  const int j = (int)(idx - row * n_chunks);
-  const long b = row / K;
-  const int k = (int)(row - b * K);
-  const CandKey key = cand_subkey(seed, env_id_base + b, episode_idx[b], step_idx[b]);
+  const unsigned n_chunks = (unsigned)(R + 3) / 4u;
+  const long b = blockIdx.x;
+  const unsigned t = blockIdx.y * blockDim.x + threadIdx.x;  // chunk (k, j) of env b
+  __shared__ CandKey skey;
+  if (threadIdx.x == 0) skey = cand_subkey(seed, env_id_base + b, episode_idx[b], step_idx[b]);
+  __syncthreads();
+  if (t >= (unsigned)K * n_chunks) return;
+  const int k = (int)(t / n_chunks), j = (int)(t - (unsigned)k * n_chunks);
+  const long row = b * K + k;
+  const CandKey key = skey;
   real sigma[DU], u0[RCG_MAX_DU] = {u00, u01};
 #pragma unroll
-  for (int c = 0; c < DU; ++c) sigma[c] = ((real)0.5 * (P.hi[c] - P.lo[c])) * (real)exp2(-(double)round);
+  for (int c = 0; c < DU; ++c) sigma[c] = ((real)0.5 * (P.hi[c] - P.lo[c])) * (real)__builtin_ldexp(1.0, -round);  // 2^-round, exact
   float xi0[4] = {0, 0, 0, 0};
   if (!(k >= (K >> 1) && k > 0 && j > 0)) cand_normals4(key, k, 0, round, xi0);  // (a per-step row draws chunk j itself)
   real ce[4], v[4];

@@ -208,7 +208,8 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
 //   RCG_NO_G1=1             no gamma == 1 specialisation               RCG_DMA_MPC_ONLY=1  RQL / SQL on k_actor
 //   RCG_PER_CU=2|4|8, RCG_LDS_PAD=<bytes>|-1   resident blocks per CU of k_actor_dma (via its LDS request)
 //   RCG_PLAIN_LDS=<bytes>   residency cap for the streamed k_actor      RCG_NO_GEN_MULTI=1  generated tiles one at a time
-//   RCG_NO_PACK=1           streamed K < 40 on k_actor instead of the packed-tile k_actor_dma instances
+//   RCG_NO_PACK=1           streamed K <= 32 without the packed-tile instances (k_actor_dma from RCG_DMA_MINK on, else k_actor)
+//   RCG_DMA_MINK=<k>        fewest candidates per env k_actor_dma serves as one ragged tile (default 33; RQL / SQL: min(k, 20))
 //   RCG_NO_PK=1             generated grid / k_ticks without the hand-packed instances (scalar-form rollouts, same bits)
 // tests/test_hip_knobs.py checks (on librcg_dev.so) that the scheduling variants reproduce the default launch bit for
 // bit, and that the production library ignores every one of them; bench.py refuses to run with any RCG_* variable set.
@@ -709,11 +710,15 @@ int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
                          (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 &&
                          (64 % A.grid_g) == 0 && !A.no_multi && !dev_knobs().no_pk;
       if (pk_ok) {  // the kernel around the hand-packed rollout (k_ticks_pk): several envs per wave
-        // envs per wave: a power of two <= 8 that leaves >= 8192 waves, so that a wave's loads, the env step (one RK4 for
-        // all of its envs) and its stores are amortised without unbalancing the launch (65 536 envs, one tick, us per
-        // launch by envs per wave: 1: 93.5, 2: 75.6, 4: 67.0, 8: 63.8, 16: 65.1 - profiles/r04_ab_ticks_pk.txt)
+        // envs per wave: a power of two <= 8 that leaves >= 2048 waves (two per SIMD), so that a wave's loads, the env step
+        // (one RK4 for all of its envs) and its stores are amortised without unbalancing the launch (65 536 envs, one tick, us
+        // per launch by envs per wave: 1: 93.5, 2: 75.6, 4: 67.0, 8: 63.8, 16: 65.1 - profiles/r04_ab_ticks_pk.txt).  Alone, a
+        // launch of 8192 .. 32768 envs lasts the same within 2-4 % for 2, 4 or 8 envs per wave; next to OTHER handles' kernels
+        // (configs[4]'s pool: three handles of 21 846 envs on three streams) fewer, longer waves leave the co-running kernels
+        // room: 93 us per pool tick at 2 envs per wave (the former rule: >= 8192 waves), 76 at 4, 67 at 8
+        // (profiles/r04_ab_pool_gpw.txt)
         int gpw = 1;
-        while (gpw < 8 && c.batch / (gpw * 2) >= 8192) gpw *= 2;
+        while (gpw < 8 && c.batch / (gpw * 2) >= 2048) gpw *= 2;
         if (dev_knobs().gpw > 0 && dev_knobs().gpw <= 64) gpw = (int)dev_knobs().gpw;
         A.gpw = gpw;
         const long pw = ((long)c.batch + gpw - 1) / gpw;

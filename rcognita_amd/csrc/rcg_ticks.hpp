@@ -234,12 +234,16 @@ __global__ __launch_bounds__(256, 4) void k_ticks_pk(const TicksArgs<float> A, c
       if (lane == e) {  // receive_action (held until the next tick), upd_accum_obj, the tick counter: in the env's lane
         myJ = float_from_order_key((unsigned)(key >> 32));
         myI = (int)(unsigned)key;
+#ifdef RCG_AB_DIV
+        gen_candidate<DU, float>(P, A.grid_g, myI, u);
+#else
         {  // gen_candidate(myI) with shifts: g is a power of two in this regime (64 % g == 0)
           const int lg = 31 - __builtin_clz((unsigned)A.grid_g);
           const float den = (float)(A.grid_g > 1 ? A.grid_g - 1 : 1);
           u[0] = fma_r((float)(myI >> lg), (P.hi[0] - P.lo[0]) / den, P.lo[0]);
           u[1] = fma_r((float)(myI & (A.grid_g - 1)), (P.hi[1] - P.lo[1]) / den, P.lo[1]);
         }
+#endif
         if (!P.accum_every_substep) accum = accum_update<Sys, false, float>(P, x, u, accum);
         steps += 1;
       }

@@ -42,6 +42,8 @@ def child(lib, workload):
                          rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], -1)
 
     B, K, Nh = 65536, int(os.environ.get("AB_K", "256")), 10
+    if workload == "gen":
+        B = int(os.environ.get("AB_B", B))
     if workload in ("gen", "opt0", "opt4", "search", "stream", "sql"):
         kw = {}
         if workload == "sql":
@@ -85,6 +87,30 @@ def child(lib, workload):
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.set_state(st3(B))
         step = lambda: eng.control_ticks(T=64, K=256 if workload == "ticks256" else 64)
+    elif workload == "pool":  # configs[4]'s per-GPU shard: three handles on three streams, WALL time per tick (overlap included)
+        import time
+
+        from rcognita_amd.pool import MixedPool
+
+        total = 65536
+        counts = {"3wrobot": total // 3 + total % 3, "3wrobotNI": total // 3, "2tank": total // 3}
+        pool = MixedPool(counts, Nactor=15, dtype="f32")
+        pool.set_states({sg.name: {"3wrobot": st3, "3wrobotNI": lambda n: st3(n)[:, :3],
+                                   "2tank": lambda n: np.stack([rng.uniform(0, 2, n), rng.uniform(-2, 2, n)], -1)}[sg.name](sg.hi - sg.lo)
+                         for sg in pool.segments})
+        for _ in range(300):
+            pool.control_tick(256)
+        pool.synchronize()
+        meds = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(400):
+                pool.control_tick(256)
+            pool.synchronize()
+            meds.append((time.perf_counter() - t0) / 400 * 1e6)
+        print("RES " + json.dumps({"workload": workload, "kernel": "pool tick (wall)", "median_us": float(np.median(meds)),
+                                   "min_us": float(min(meds)), "n": 5}))
+        return
     else:
         raise SystemExit(f"unknown workload {workload}")
     for _ in range(150):
