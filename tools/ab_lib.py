@@ -55,6 +55,8 @@ def child(lib, workload):
             B, Nh = int(os.environ.get("AB_B", B)), int(os.environ.get("AB_N", Nh))
             if name == "2tank" and "Ncritic" not in kw and kw:
                 kw["Ncritic"] = 4
+        if workload == "stream" and os.environ.get("AB_DTYPE"):  # AB_DTYPE=f64: the reference's width
+            kw["dtype"] = os.environ["AB_DTYPE"]
         eng = Engine(preset_engine_config(name, B, Nactor=Nh, **kw))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.set_state({"3wrobot": st3(B), "3wrobotNI": st3(B)[:, :3],
@@ -62,8 +64,9 @@ def child(lib, workload):
         if workload in ("stream", "sql"):
             from rcognita_amd.pool import PRESETS
 
-            bnd = torch.tensor(np.array(PRESETS[name]["ctrl_bnds"]), device="cuda", dtype=torch.float32)
-            cand = (torch.rand((B, K, Nh, eng.du), device="cuda") * (bnd[:, 1] - bnd[:, 0]) + bnd[:, 0]).contiguous()
+            td = torch.float64 if kw.get("dtype") == "f64" else torch.float32
+            bnd = torch.tensor(np.array(PRESETS[name]["ctrl_bnds"]), device="cuda", dtype=td)
+            cand = (torch.rand((B, K, Nh, eng.du), device="cuda", dtype=td) * (bnd[:, 1] - bnd[:, 0]) + bnd[:, 0]).contiguous()
             step = lambda: eng.control_tick(cand, K=K)
         elif workload == "gen":
             step = lambda: eng.control_tick(None, K=K)
