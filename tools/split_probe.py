@@ -10,6 +10,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from rcognita_amd import _native as N  # noqa: E402
+
+if os.environ.get("PROBE_LIB"):  # a dev-build knob: PROBE_LIB=rcognita_amd/lib/librcg_dev.so RCG_GPW=16 SPLITS=2,2 python tools/split_probe.py
+    N.use_library(os.path.join(ROOT, os.environ["PROBE_LIB"]))
 from rcognita_amd import Engine  # noqa: E402
 from rcognita_amd.pool import preset_engine_config  # noqa: E402
 
@@ -18,7 +22,7 @@ rng = np.random.default_rng(1)
 x0 = np.stack([rng.uniform(0, 2, B), rng.uniform(-2, 2, B)], -1)
 cand = torch.rand((B, K, Nh, 1), device="cuda").contiguous()
 torch.cuda.synchronize()
-for S in (1, 2, 4, 1, 2):
+for S in [int(v) for v in os.environ.get("SPLITS", "1,2,4,1,2").split(",")]:
     n = B // S
     engs, streams = [], []
     for i in range(S):
