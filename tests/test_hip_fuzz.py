@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 SEEN = set()
 
 
-@pytest.mark.parametrize("seed", range(72))
+@pytest.mark.parametrize("seed", range(144))
 def test_streamed_decision_of_a_random_shape(seed):
     from rcognita_amd import _native as N
 
