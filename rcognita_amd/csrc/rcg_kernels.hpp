@@ -590,10 +590,14 @@ __device__ __forceinline__ void rollout_mpc_gen_multi(const KParams<real>& P, co
 template <typename Sys>
 struct GenPk {
   static constexpr bool supported = false;
+  static constexpr bool fuse_tick = false;
 };
 template <>
 struct GenPk<Sys3WRobot> {  // state (x, y, alpha, v, omega), inputs (F, M); candidates share M, hence alpha and omega
   static constexpr bool supported = true;
+  // rcg_control_tick as ONE launch of k_ticks_pk (env step + decision): 5-8 % shorter than k_sim + k_actor's packed instance
+  // from 8192 to 65536 envs, equal at configs[4]'s 21 846 (profiles/r04_ab_pool_gpw.txt)
+  static constexpr bool fuse_tick = true;
   __device__ __forceinline__ static void run(const KParams<float>& P, const Sys3WRobot::Pre<float>& pre, int N,
                                              const float* xs, const float* y0, const float* u0v, float u1, float* Jout) {
     const float h = P.h_pred;
@@ -652,6 +656,10 @@ struct GenPk<Sys3WRobot> {  // state (x, y, alpha, v, omega), inputs (F, M); can
 template <>
 struct GenPk<Sys3WRobotNI> {  // state (x, y, alpha), inputs (v, omega); candidates share omega, hence alpha
   static constexpr bool supported = true;
+  // the kinematic robot's tick stays two launches: its k_ticks_pk lasts 40 us at 21 845 envs and 60.5 at 65 536, k_sim +
+  // k_actor's packed instance 25 + 4.5 and 50 + 4.5 (profiles/r04_ab_pool_gpw.txt); rcg_control_ticks (T ticks in one launch,
+  // small batches) still uses k_ticks_pk
+  static constexpr bool fuse_tick = false;
   __device__ __forceinline__ static void run(const KParams<float>& P, const Sys3WRobotNI::Pre<float>&, int N,
                                              const float* xs, const float* y0, const float* u0v, float u1, float* Jout) {
     const float h = P.h_pred;

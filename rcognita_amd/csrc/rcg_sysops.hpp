@@ -360,7 +360,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
                        P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain && !knobs.no_pack;
   // rcg_control_tick with the generated grid in the regime of the hand-packed rollout: env step and decision in ONE launch
   // (k_ticks_pk with T = 1 - what rcg_control_ticks runs, so the two entry points cannot differ by a bit)
-  if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported) {
+  if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported && GenPk<Sys>::fuse_tick) {
     if (tick && sim_first && !cand && !generic && !tgt && c.gamma == 1.0 && Sys::ZW_PRESET != 0u &&
         (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 && A.grid_g > 0 &&
         (64 % A.grid_g) == 0 && !A.no_multi && !knobs.no_pk && !knobs.no_tick_fuse && !(c.flags & RCG_FLAG_DISTURB) && !obs &&

@@ -50,7 +50,9 @@ def child(lib, workload):
             kw = dict(mode="SQL", critic_struct="quad-lin", buffer_size=10)
         if os.environ.get("AB_MODE"):  # e.g. AB_MODE=RQL AB_K=36 ... stream
             kw = dict(mode=os.environ["AB_MODE"], critic_struct=os.environ.get("AB_CS", "quad-nomix"), buffer_size=10)
-        name = os.environ.get("AB_SYS", "3wrobot") if workload == "stream" else "3wrobot"  # AB_SYS / AB_B / AB_N: stream only
+        name = os.environ.get("AB_SYS", "3wrobot") if workload in ("stream", "gen") else "3wrobot"  # AB_SYS / AB_B / AB_N: stream, gen
+        if workload == "gen":
+            Nh = int(os.environ.get("AB_N", Nh))
         if workload == "stream":
             B, Nh = int(os.environ.get("AB_B", B)), int(os.environ.get("AB_N", Nh))
             if name == "2tank" and "Ncritic" not in kw and kw:
