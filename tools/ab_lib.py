@@ -87,10 +87,11 @@ def child(lib, workload):
         if workload == "fit":
             kind = N.KERNEL_CRITIC
     elif workload in ("ticks", "ticks256"):
-        B = 1024
-        eng = Engine(preset_engine_config("3wrobot", B, Nactor=Nh))
+        B = int(os.environ.get("AB_B", 1024))
+        name = os.environ.get("AB_SYS", "3wrobot")  # (a robot)
+        eng = Engine(preset_engine_config(name, B, Nactor=Nh))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        eng.set_state(st3(B))
+        eng.set_state(st3(B)[:, :eng.ds])
         step = lambda: eng.control_ticks(T=64, K=256 if workload == "ticks256" else 64)
     elif workload == "pool":  # configs[4]'s per-GPU shard: three handles on three streams, WALL time per tick (overlap included)
         import time
