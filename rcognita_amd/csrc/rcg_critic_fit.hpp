@@ -90,11 +90,16 @@ struct FitArgs {
   const real* action;     // [du][B] do_push: the held action (action_curr)
 };
 
-// Everything of one env, lane-private: [env step] -> [push] -> [fit], in and out through the handle's tensors.  The body of
-// k_critic_fit (lane == env) and of the critic phase of k_ticks_mem (rcg_ticks.hpp: the lanes that stand for the wave's envs).
+// The part of an env's critic update that precedes the solver: [env step] -> [push] -> TD stack (A, b) and the box.  `store`:
+// this lane writes the env's state / buffers back (false for the lanes that only help with the env's solve, k_critic_fit_ml).
+// Returns false when there is nothing to fit (F.do_fit == 0).
 template <typename Sys, typename real, int CS, int MAXM>
-__device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const KParams<double>& P, const KParams<real>& Pr,
-                                                  const long b) {
+__device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KParams<double>& P, const KParams<real>& Pr,
+                                                const long b, const bool store,
+                                                double (&A)[MAXM][CriticDim<CS, Sys::DS, Sys::DU>::value], double (&bv)[MAXM],
+                                                double (&w0)[CriticDim<CS, Sys::DS, Sys::DU>::value],
+                                                double (&lo)[CriticDim<CS, Sys::DS, Sys::DU>::value],
+                                                double (&hi)[CriticDim<CS, Sys::DS, Sys::DU>::value]) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, DC = CriticDim<CS, DS, DU>::value;
   // rows of the shifted buffers that stay in registers for the TD stack: new row r = old row r + 1, r = 0 .. KEEP - 1
   constexpr int KEEP = MAXM + 1 <= 4 ? MAXM + 1 : 4;
@@ -136,14 +141,14 @@ __device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const 
         const bool ok = tgt ? env_substeps<Sys, real, true>(Pr, pre, F.sim.n_sub, xs, xp, ua, st, accum)
                             : env_substeps<Sys, real, false>(Pr, pre, F.sim.n_sub, xs, xp, ua, st, accum);
         if (!ok) {
-          F.sim.status[b] = st;  // became non-finite: frozen at its last finite state
+          if (store) F.sim.status[b] = st;  // became non-finite: frozen at its last finite state
         } else {
 #pragma unroll
           for (int c = 0; c < DS; ++c) {
-            F.sim.state[(long)c * B + b] = xs[c];
-            F.sim.state_prev[(long)c * B + b] = xp[c];
+            if (store) F.sim.state[(long)c * B + b] = xs[c];
+            if (store) F.sim.state_prev[(long)c * B + b] = xp[c];
           }
-          if (Pr.accum_every_substep) F.sim.accum[b] = accum;
+          if (store) if (Pr.accum_every_substep) F.sim.accum[b] = accum;
         }
       }
     }
@@ -152,9 +157,9 @@ __device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const 
       for (int k = 0; k < KEEP; ++k)
         if (k + 1 < bs) {
 #pragma unroll
-          for (int c = 0; c < DS; ++c) F.obs_buf[((long)k * DS + c) * B + b] = ko[k][c];
+          for (int c = 0; c < DS; ++c) if (store) F.obs_buf[((long)k * DS + c) * B + b] = ko[k][c];
 #pragma unroll
-          for (int c = 0; c < DU; ++c) F.act_buf[((long)k * DU + c) * B + b] = ka[k][c];
+          for (int c = 0; c < DU; ++c) if (store) F.act_buf[((long)k * DU + c) * B + b] = ka[k][c];
         }
       // the rest of the shift four rows at a time, all loads of a pass before its stores
       constexpr int CH = 4;
@@ -172,15 +177,15 @@ __device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const 
         for (int k = 0; k < CH; ++k)
           if (r0 + k < bs - 1) {
 #pragma unroll
-            for (int c = 0; c < DS; ++c) F.obs_buf[((long)(r0 + k) * DS + c) * B + b] = ro[k][c];
+            for (int c = 0; c < DS; ++c) if (store) F.obs_buf[((long)(r0 + k) * DS + c) * B + b] = ro[k][c];
 #pragma unroll
-            for (int c = 0; c < DU; ++c) F.act_buf[((long)(r0 + k) * DU + c) * B + b] = ra[k][c];
+            for (int c = 0; c < DU; ++c) if (store) F.act_buf[((long)(r0 + k) * DU + c) * B + b] = ra[k][c];
           }
       }
 #pragma unroll
-      for (int c = 0; c < DS; ++c) F.obs_buf[((long)(bs - 1) * DS + c) * B + b] = xs[c];
+      for (int c = 0; c < DS; ++c) if (store) F.obs_buf[((long)(bs - 1) * DS + c) * B + b] = xs[c];
 #pragma unroll
-      for (int c = 0; c < DU; ++c) F.act_buf[((long)(bs - 1) * DU + c) * B + b] = ua[c];
+      for (int c = 0; c < DU; ++c) if (store) F.act_buf[((long)(bs - 1) * DU + c) * B + b] = ua[c];
 #pragma unroll
       for (int k = 0; k < KEEP; ++k)
         if (k == bs - 1) {  // (buffer_size <= KEEP: the row just pushed is one of the kept rows)
@@ -190,10 +195,10 @@ __device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const 
           for (int c = 0; c < DU; ++c) ka[k][c] = ua[c];
         }
     }
-    if (!F.do_fit) return;
+    if (!F.do_fit) return false;
   }
 
-  double A[MAXM][DC], bv[MAXM], wp[DC], w0[DC], lo[DC], hi[DC];
+  double wp[DC];
 #pragma unroll
   for (int i = 0; i < DC; ++i) {
     wp[i] = (double)wpr[i];
@@ -241,6 +246,20 @@ __device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const 
       }
     }
   }
+
+  return true;
+}
+
+// Everything of one env, lane-private: [env step] -> [push] -> [fit], in and out through the handle's tensors.  The body of
+// k_critic_fit (lane == env) and of the critic phase of k_ticks_mem (rcg_ticks.hpp: the lanes that stand for the wave's envs).
+template <typename Sys, typename real, int CS, int MAXM>
+__device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const KParams<double>& P, const KParams<real>& Pr,
+                                                  const long b) {
+  constexpr int DC = CriticDim<CS, Sys::DS, Sys::DU>::value;
+  const long B = P.B;
+  const int m = P.n_critic - 1;  // rows of the TD stack, 1 <= m <= MAXM (checked on the host)
+  double A[MAXM][DC], bv[MAXM], w0[DC], lo[DC], hi[DC];
+  if (!critic_prologue<Sys, real, CS, MAXM>(F, P, Pr, b, true, A, bv, w0, lo, hi)) return;
 
   double tr = 0.0;
 #pragma unroll

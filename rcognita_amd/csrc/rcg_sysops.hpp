@@ -8,6 +8,9 @@
 
 #include "rcg_actor_dma.hpp"
 #include "rcg_actor_dma_packed.hpp"
+#ifdef RCG_DEV
+#include "rcg_critic_fit_ml.hpp"  // the four-lanes-per-env experiment: dev build only, RCG_FIT_LANES=4
+#endif
 #include "rcg_actor_opt.hpp"
 #include "rcg_critic_fit.hpp"
 #include "rcg_disturb.hpp"
@@ -152,6 +155,10 @@ int op_sim_step(rcg_handle* h, int32_t n_substeps) {
   });
 }
 
+#ifdef RCG_DEV
+static int fit_lanes_knob();  // (DevKnobs, below)
+#endif
+
 template <typename Sys>
 int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t do_fit) {
   const int m = h->cfg.n_critic - 1;
@@ -178,9 +185,19 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
     F.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
     F.sim.n_sub = n_substeps;
     const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
+#ifdef RCG_DEV
+    const bool fit_ml = m <= 3 && fit_lanes_knob() == FIT_L;
+    const dim3 grid_ml(blocks_for(h->cfg.batch, 64 / FIT_L));
+#define RCG_FIT_ML(CS) RCG_LAUNCH(h, (k_critic_fit_ml<Sys, real, CS, 3>), grid_ml, block, 0, F, h->p64, params<real>(h))
+#else
+    const bool fit_ml = false;
+#define RCG_FIT_ML(CS) (void)0
+#endif
 #define RCG_FIT(CS)                                                                                                    \
   do {                                                                                                                 \
-    if (m <= 3)                                                                                                        \
+    if (fit_ml)                                                                                                        \
+      RCG_FIT_ML(CS);                                                                                                  \
+    else if (m <= 3)                                                                                                   \
       RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, 3>), grid, block, 0, F, h->p64, params<real>(h));     \
     else                                                                                                               \
       RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, F, h->p64,             \
@@ -193,8 +210,11 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
       default: RCG_FIT(RCG_CRITIC_QUAD_MIX); break;
     }
 #undef RCG_FIT
+#undef RCG_FIT_ML
     note_launch(h, RCG_KERNEL_CRITIC, RCG_KID_CRITIC_FIT,
-                h->cfg.critic_struct + 16 * (m <= 3 ? 3 : kFitMaxRows) + (F.do_sim ? 256 : 0) + (do_fit ? 512 : 0), 64);
+                h->cfg.critic_struct + 16 * (m <= 3 ? 3 : kFitMaxRows) + (F.do_sim ? 256 : 0) + (do_fit ? 512 : 0) +
+                    (fit_ml ? 1024 : 0),
+                fit_ml ? 16 : 64);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
@@ -226,6 +246,7 @@ struct DevKnobs {
   bool mpc_only = false;  // RCG_DMA_MPC_ONLY=1: RQL and SQL go to k_actor (A/B against the critic instances)
   bool no_gen_multi = false;  // RCG_NO_GEN_MULTI=1: generated tiles one at a time (no shared sub-trajectory)
   bool no_pack = false;
+  int fit_lanes = 0;  // RCG_FIT_LANES=4: the critic fit with four lanes per env (k_critic_fit_ml), m <= 3
   int dma_min_k = 33;  // RCG_DMA_MINK=<k>: fewest candidates per env served by k_actor_dma (one ragged tile below 64)
   bool no_tick_fuse = false;  // RCG_NO_TICK_FUSE=1: generated-grid tick as k_sim + k_actor (packed instance) instead of k_ticks_pk
   bool no_pk = false;  // RCG_NO_PK=1: generated grid on the instances that carry every variant (A/B of the packed rollout)
@@ -247,11 +268,15 @@ static inline const DevKnobs& dev_knobs() {
     v.no_pk = getenv("RCG_NO_PK") != nullptr;
     v.no_tick_fuse = getenv("RCG_NO_TICK_FUSE") != nullptr;
     if (const char* e = getenv("RCG_DMA_MINK")) v.dma_min_k = atoi(e);
+    if (const char* e = getenv("RCG_FIT_LANES")) v.fit_lanes = atoi(e);
 #endif
     return v;
   }();
   return k;
 }
+#ifdef RCG_DEV
+static int fit_lanes_knob() { return dev_knobs().fit_lanes; }
+#endif
 
 template <typename Sys>
 int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand);
