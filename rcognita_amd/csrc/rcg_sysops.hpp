@@ -231,6 +231,8 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
 //   RCG_NO_PACK=1           streamed K <= 32 without the packed-tile instances (k_actor_dma from RCG_DMA_MINK on, else k_actor)
 //   RCG_DMA_MINK=<k>        fewest candidates per env k_actor_dma serves as one ragged tile (default 33; RQL / SQL: min(k, 20))
 //   RCG_NO_PK=1             generated grid / k_ticks without the hand-packed instances (scalar-form rollouts, same bits)
+//   RCG_NO_TICK_FUSE=1      generated-grid tick as k_sim + k_actor's packed instance instead of k_ticks_pk
+//   RCG_FIT_LANES=4         the critic fit with four lanes per env (k_critic_fit_ml; results differ on degenerate stacks: an experiment)
 // tests/test_hip_knobs.py checks (on librcg_dev.so) that the scheduling variants reproduce the default launch bit for
 // bit, and that the production library ignores every one of them; bench.py refuses to run with any RCG_* variable set.
 struct DevKnobs {

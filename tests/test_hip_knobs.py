@@ -52,6 +52,7 @@ def test_the_production_library_ignores_every_knob():
     (rcg_last_launch) nor a single output bit."""
     prod = _run({}, dev=False)
     loud = _run({"RCG_ACTOR_KERNEL": "plain", "RCG_GPW": "3", "RCG_PER_CU": "8", "RCG_NO_G1": "1", "RCG_DBG": "7",
-                 "RCG_LDS_PAD": "-1", "RCG_DMA_MPC_ONLY": "1", "RCG_NO_GEN_MULTI": "1", "RCG_PLAIN_LDS": "65536", "RCG_NO_PK": "1"},
+                 "RCG_LDS_PAD": "-1", "RCG_DMA_MPC_ONLY": "1", "RCG_NO_GEN_MULTI": "1", "RCG_PLAIN_LDS": "65536", "RCG_NO_PK": "1",
+                 "RCG_NO_TICK_FUSE": "1", "RCG_NO_PACK": "1", "RCG_DMA_MINK": "64", "RCG_FIT_LANES": "4"},
                 dev=False)
     assert loud == prod
