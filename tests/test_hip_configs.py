@@ -99,6 +99,16 @@ def test_mixed_pool_C5_shard(world, rank):
             envs[s.name] = PAR.check_tick(cfgs[s.name], envs[s.name], grids[s.name], dev, tol=1e-5,
                                           what=f"C5 {s.name} t={t}")
     pool.synchronize()
+    # the launch decisions behind the pool's rate (profiles/r04_ab_pool_gpw.txt): the 3-wheel robot's tick is ONE launch of the
+    # hand-packed persistent kernel, 8 envs per wave at this size; the kinematic robot's stays two launches (its fused kernel
+    # is slower), the decision on k_actor's packed instance; the tank has no packed rollout
+    expect = {"3wrobot": ("k_ticks", 8, 8), "3wrobotNI": ("k_actor", 8, 1), "2tank": ("k_actor", 2, None)}
+    for s in pool.segments:
+        ll = s.engine.last_launch(N.KERNEL_ACTOR)
+        kernel, variant, epw = expect[s.name]
+        assert ll["kernel"] == kernel and ll["variant"] == variant, (s.name, ll)
+        if epw is not None:
+            assert ll["envs_per_wave"] == epw, (s.name, ll)
     total_summ, per = pool.episode_stats(from_accum=True)
     assert total_summ["count"] == pool.n_envs and total_summ["n_failed"] == 0
     for s in pool.segments:
