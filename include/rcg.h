@@ -257,7 +257,8 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
  * under the other inherits the same caveat.  BEST_J / BEST_IDX are the last tick's.  MPC handles: any stage-cost structure,
  * with or without RCG_FLAG_DISTURB.  RQL / SQL handles (1 <= Ncritic - 1 <= 8, no disturbance model, the preset's observation
  * target setting): the two launches of a tick - env step + buffer push + critic fit, then the decision - run as phases of
- * one persistent launch (k_ticks_mem), same functions on the same memory, bit-identical as well; other RQL / SQL handles get
+ * one persistent launch (k_ticks_mem), same functions on the same memory, bit-identical as well; other RQL / SQL handles (and
+ * critic structures with 20 or more weights, whose single ticks fit with four lanes per env) get
  * RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of small batches. */
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* T consecutive rcg_control_tick(h, cand, K) issued by ONE call: the loop of presets/main_3wrobot.py:415-468 for T sampling
@@ -391,7 +392,7 @@ typedef enum rcg_kernel_id {
 } rcg_kernel_id;
 /* variant: k_actor_dma, k_actor_dma_packed: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL; k_actor / k_ticks: bit 0 generic
  * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates, bit 3 the hand-packed generated-grid instance; k_critic_fit: critic_struct + 16 * (rows
- * the instance is compiled for) + 256 * do_sim + 512 * do_fit; others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
+ * the instance is compiled for) + 256 * do_sim + 512 * do_fit + 1024 * (the four-lanes-per-env form, structures with >= 20 weights); others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
  * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Each out pointer may be NULL. */
 int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave);
 /* "k_actor_dma", ... ; "?" for an unknown id.  Never NULL. */

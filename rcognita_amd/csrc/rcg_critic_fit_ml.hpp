@@ -12,9 +12,15 @@
 // tie rules (smallest ratio / largest score, then lowest index).  A wave holds 16 envs instead of 64: four times the
 // waves, each a quarter as long and with the maximum walk of 16 envs instead of 64.
 // The TD stack (A, b) is built by critic_prologue exactly as for k_critic_fit - all four lanes run it, lane 0 of the quad
-// stores - so the problem instance is the same bits; what differs is the ASSOCIATION of the sums over variables, i.e. the
-// weights agree with k_critic_fit and with the oracle within the conditioning of the fit (tests/test_hip_critic.py), not
-// bit for bit.  Rows: m <= 3 (the exact-m instance; every preset).
+// stores - so the problem instance is the same bits; what differs is the ASSOCIATION of the sums over variables: the weights
+// agree with k_critic_fit and with the float64 oracle to the tolerances of the parity tests on the same inputs (the whole
+// critic test set passes with this form forced for every structure: 324 tests, RCG_TEST_LIB / RCG_FIT_LANES=4), not bit for
+// bit; on rank-deficient stacks a last-bit difference can end the walk on another vertex of equal cost, which 40 free-running
+// ticks amplify (profiles/r04_fit_four_lanes.txt).
+// Where it runs: the structures with >= 20 weights (rcg_sysops.hpp::launch_fit3) - there the one-lane walk, up to 3 dc + 10
+// iterations of ~2000 instructions for the slowest lane of a wave, takes 2.3 ms for 32 768 envs and this form 0.41 ms; with
+// few weights the redundant solve and the quad reductions make it the slower form (configs[2], 6 weights: 65 -> 88 us).
+// Rows: m <= 3 (the exact-m instance; every preset).
 #pragma once
 #include "rcg_critic_fit.hpp"
 

