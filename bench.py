@@ -246,7 +246,9 @@ def cpu_baseline(args, seconds):
     from oracle import c_oracle as CO
     from oracle import rcg_oracle as O
 
-    threads = CO.max_threads()
+    # the threads this job may really run: the cgroup / affinity share of the host (16 of 256 on a one-GPU box), NOT
+    # omp_get_max_threads() - round 4 started 128 OpenMP threads on a 16-core share and labelled the result "128 cores"
+    threads = max(1, min(usable_cores(), CO.max_threads()))
     cfg = c2_oracle_cfg(args)
     bnds = cfg.ctrl_bnds
     K = args.candidates
@@ -265,8 +267,10 @@ def cpu_baseline(args, seconds):
         cb.tick(cand, nthreads=threads)
     dt = time.perf_counter() - t0
     n = Bc * (ticks + 1)
-    return {"value": n / dt, "unit": "env-control-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{Bc} envs x {ticks + 1} ticks, K={K}, Nactor={args.nactor}, C oracle f64 + OpenMP, {dt:.1f} s"}
+    return {"value": n / dt, "unit": "env-control-steps/s", "cores": threads, "threads": threads,
+            "os_cpu_count": os.cpu_count(), "omp_max_threads": CO.max_threads(), "per_core": n / dt / threads, "kind": "port",
+            "sample": f"{Bc} envs x {ticks + 1} ticks, K={K}, Nactor={args.nactor}, C oracle f64 + OpenMP on {threads} "
+                      f"threads (= the cores this job owns), {dt:.1f} s"}
 
 
 # the reference itself (imported from /root/reference in the build container, SciPy RK45 + SLSQP, one env, one core)
@@ -859,7 +863,10 @@ def main(argv=None):
                      args.config != "C5" else None,
                      "launches_timed": actor_n, "event_stride": stride, "overlapped_handles": per_launch,
                      "event_kind": "start / stop events carried by the dispatch (hipExtLaunchKernelGGL), timed region only",
-                     "note": ("streamed regime: HBM-bound" if streamed else
+                     "note": ("streamed regime: HBM-bound; the candidate tensor is STATIC - the same caller-owned tensor is "
+                              "re-read from HBM every tick (1.3 GB at C2, 5 x the Infinity Cache): this is SURVEY 8d's "
+                              "operator shape, _actor_cost(action_sqn, ...) over given sequences, not a closed loop whose "
+                              "candidates change per tick - for that see value_closed_loop" if streamed else
                               "generated regime is VALU-bound (see secondary.generated_grid.roofline_valu); the HBM "
                               "fraction is reported for completeness only")},
         "returns_summary": total,
@@ -915,6 +922,10 @@ def main(argv=None):
             except Exception as e:  # never let a secondary figure take the bench line down
                 out["secondary"]["two_handles"] = {"error": str(e)[:300]}
 
+    # the best regime whose candidates CHANGE every tick (the streamed headline re-reads one static tensor)
+    cl = closed_loop_value(out.get("secondary") or {})
+    if cl:
+        out["value_closed_loop"] = cl
     # the reference's arithmetic width next to the headline: the float64 run of the same tick
     f64 = (out.get("secondary") or {}).get("f64")
     if args.dtype == "f64":
@@ -938,6 +949,37 @@ def main(argv=None):
         dist.destroy_process_group()
     if "parity" in out and not out["parity"]["ok"]:
         sys.exit("bench.py: the parity check of this run FAILED - the numbers above are not valid")
+
+
+def closed_loop_value(sec):
+    """Top-level ``value_closed_loop``: the best of this run's regimes in which every tick decides over candidates that did
+    not exist the tick before - the on-device optimiser (rcg_control_tick_opt), the device-side search
+    (rcg_control_tick_search), the produced stream (k_cand_sample rewrites the tensor, then the streamed tick reads it) -
+    named, with all of them listed.  The generated level grid is listed too but not eligible: its candidates are the same
+    constant sequences every tick."""
+    regimes = {}
+
+    def put(name, v, what):
+        if isinstance(v, (int, float)) and v > 0:
+            regimes[name] = {"value": float(v), "what": what}
+
+    ot = sec.get("optimizer_tick") or {}
+    put("optimizer_memory0", (ot.get("memory_0") or {}).get("env_control_steps_per_s"),
+        "rcg_control_tick_opt, 5 iterations of k_actor_opt from the warm start, MPC default (no curvature pairs)")
+    put("optimizer_memory4", (ot.get("memory_4") or {}).get("env_control_steps_per_s"),
+        "the same with 4 curvature pairs (the critic modes' default)")
+    ds_ = sec.get("device_search") or {}
+    put("device_search_1_round", (ds_.get("rounds_1") or {}).get("env_control_steps_per_s"),
+        "rcg_control_tick_search, K candidates drawn and evaluated on the device, 1 round")
+    put("device_search_4_rounds", (ds_.get("rounds_4") or {}).get("env_control_steps_per_s"), "the same, 4 refinement rounds")
+    put("produced_stream", (sec.get("produced_stream") or {}).get("env_control_steps_per_s"),
+        "k_cand_sample rewrites the [B][K][N][du] tensor every tick, then the streamed tick reads it")
+    if not regimes:
+        return None
+    best = max(regimes, key=lambda k: regimes[k]["value"])
+    return {"value": regimes[best]["value"], "unit": "env-control-steps/s", "regime": best, "what": regimes[best]["what"],
+            "regimes": regimes,
+            "note": "candidates change every tick in each of these; the headline `value` streams one static tensor"}
 
 
 def strict_json(x):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 115 /* 0.1.1 + rcg_set_optimizer, rcg_candidates_refine; optimiser and T-tick launches in every mode (round 4) */
+#define RCG_VERSION 116 /* 115 + rcg_sim_step_h: one simulation step of a caller-given length (round 5) */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -228,6 +228,12 @@ int rcg_critic_cost(rcg_handle* h, const void* w, void* Jc);
 /* Simulator.sim_step (simulator.py:156-168) x n_substeps: fixed-step RK4 of closed_loop_rhs with
  * the held ACTION, clipped (systems.py:241-243).  Updates STATE, STATE_PREV, STATUS. */
 int rcg_sim_step(rcg_handle* h, int32_t n_substeps);
+/* The same with the step length given by the caller: ONE simulation step of length `step` (> 0, finite), integrated as
+ * n_substeps RK4 substeps of step / n_substeps; the handle's dt_sim is untouched.  The reference's Simulator.sim_step
+ * advances by whatever its adaptive solver chose (simulator.py:156-168: `self.ODE_solver.step()`); this entry lets a
+ * caller walk a recorded time grid of the reference - tests/test_hip_ref_traces.py replays the reference's closed loops at
+ * the reference's own step and decision instants.  SUBSTEP_IDX / the disturbance draw advance as in rcg_sim_step. */
+int rcg_sim_step_h(rcg_handle* h, int32_t n_substeps, double step);
 /* Replacement of CtrlOptPred._actor_optimizer (controllers.py:1330-1427): evaluate _actor_cost for
  * K candidates per env and take the argmin (lower J wins, ties -> lower index, NaN = +inf).
  * cand [B][K][N][du], or NULL for the generated level grid (K levels for du = 1, g*g for du = 2).
@@ -264,7 +270,8 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* T consecutive rcg_control_tick(h, cand, K) issued by ONE call: the loop of presets/main_3wrobot.py:415-468 for T sampling
  * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode.  Handles of up to
  * 16384 envs run them as ONE launch: MPC on k_ticks (a caller's tensor: the wave's candidate rows are staged into LDS once
- * and re-walked T times), RQL / SQL with the generated grid on k_ticks_mem; larger batches, and RQL / SQL with a caller's
+ * and re-walked T times; a tensor whose rows do not fit a wave's 32 KB AND that exceeds 128 MB - half the Infinity Cache -
+ * would be re-staged from HBM by plain loads every tick and loops single ticks on k_actor_dma instead), RQL / SQL with the generated grid on k_ticks_mem; larger batches, and RQL / SQL with a caller's
  * tensor (their single ticks run on k_actor_dma), issue the launches of T single ticks without T trips through the
  * caller's FFI (a Python caller needs ~12 us per call, and a GPU that idles between short ticks clocks down).  Either way
  * every field ends as T single calls leave it, bit for bit; stops at the first error. */

@@ -1,27 +1,45 @@
 #!/usr/bin/env python3
-"""Round-4 golden vectors: the reference's closed loop in the CRITIC modes, from starts where the critic steers.
+"""Golden vectors of the reference's closed loop in the CRITIC modes, from starts where the critic steers - with
+everything every decision saw and returned, so that the loop can be replayed teacher-forced, tick by tick.
 
-    python oracle/gen_critic_fixtures.py     # writes tests/golden/F7c_trace_*.npz, F8c_slsqp_actor_*.npz
+    python oracle/gen_critic_fixtures.py             # writes tests/golden/F7c_trace_*.npz, F8c_slsqp_actor_*.npz
+    python oracle/gen_critic_fixtures.py --explore   # prints the acceptance table of every candidate start, writes nothing
 
 Why a second generator.  ``F7_trace_2tank_RQL`` (oracle/gen_fixtures.py) starts at the preset's ``x0 = [2, -2]``, where
 the input sits on its lower bound for the whole run: that trace equals the MPC trace to 5e-11 and says nothing about
-the critic.  The traces written here start where RQL / SQL decide differently from MPC, and the generator REFUSES to
-write a trace whose actions stay within 1e-2 of the MPC run from the same start (``assert_discriminating``), so a
-saturated critic-mode trace can never be committed again.
+the critic.  The traces written here start where RQL / SQL decide differently from MPC.
+
+Which trace is a fixture (round 5).  A closed-loop trace can tell "the critic steers" from "MPC" only if the two runs
+are further apart than the band a different optimiser is held to.  That band is max(6 %, 2 x the distance the
+reference's OWN loop moves when only SLSQP's tolerance changes) (oracle/gen_trace_sensitivity.py).  So, per (system, mode,
+critic structure), the generator walks a fixed list of candidate (start, horizon, run length) and keeps the FIRST whose
+  * actions leave the MPC run's by more than 1e-2 (round 4's bar), critic weights leave w_init, and
+  * running cost over [2 dt, t1] differs from the reference's MPC run from the same start by at least TWICE that band.
+Both numbers come from the reference and from oracle/ref_loop.py (which reproduces the reference's traces bit for bit);
+nothing of the HIP build enters the choice.  A (system, mode, structure) none of whose candidates qualifies aborts the run.
 
 F7c_trace_<system>_<mode>_<critic_struct>  the loop body of presets/main_3wrobot.py:419-446 on the imported reference
     rows      [n_steps, 1 + ds + du + 2]   t, state, action, stage_obj, accum_obj per simulation step (as F7)
     rows_mpc  the same loop in MPC mode from the same start (what the critic modes are told apart from)
     tick_*    one entry per control tick (controllers.py:1440-1444), everything the decision of that tick saw:
               tick_t, tick_obs [dy], tick_state_sys [ds] (the state BEFORE receive_sys_state: App. A-2 lag),
+              tick_action_prev [du] (action_curr: the row pushed into the action buffer, controllers.py:1463),
               tick_w [dc] (w_critic the actor used), tick_w_prev [dc] (w_critic_prev the critic fit used),
+              tick_fitted (1 if controllers.py:1466 refitted on this tick), tick_critic_status (SciPy's SLSQP exit mode of
+              that fit, re-run on the same inputs and asserted to return the same weights: 0 = converged; 8 = "positive
+              directional derivative for linesearch", 4 = "inequality constraints incompatible": the reference keeps
+              whatever iterate SLSQP stopped on - often w_init itself - and carries on),
               tick_obs_buf / tick_act_buf [buffer_size, d] (after the push, as the fit saw them),
               tick_action_sqn [N * du], tick_J (SLSQP's result, recomputed with the reference's own call and
               asserted bit-identical to the action the reference returned), tick_J_init (J at action_sqn_init),
-              tick_nfev, tick_Jc (the reference's _critic_cost at the fitted weights), tick_Jc_init.
-    mpc_tick_*  the same per-tick record (t, obs, state_sys, action_sqn, J, J_init, nfev) of the MPC run: SLSQP's decisions
-              on the states the reference's own MPC loop visits (a tighter anchor for the optimiser than the closed-loop
-              bands of the MPC traces).
+              tick_nfev, tick_Jc (the reference's _critic_cost at the fitted weights), tick_Jc_init,
+              tick_first_rise [du, len(FIRST_FRACS)]: how much the reference's own _actor_cost rises when component i of the
+              FIRST action is moved by tau = FIRST_FRACS[j] x (bound width) away from SLSQP's optimum and everything else is
+              re-optimised by the same SLSQP call (min over the two signs, those that stay inside the bounds; relative to
+              tick_J).  A flat direction - the 3-wheel robot's preset puts no weight on the inputs - shows as a rise
+              near 0; the teacher-forced replay (tests/test_hip_teacher_forced.py) asserts the device's first action
+              only where this measured rise exceeds the cost tolerance it grants the optimiser.
+    mpc_tick_*  the same per-tick record (t, obs, state_sys, action_sqn, J, J_init, nfev) of the MPC run.
 F8c_slsqp_actor_<system>_<mode>_<critic_struct>  a subsample of those ticks as an optimiser-quality fixture in F8's layout
     (state = state_sys, obs, w, J_opt, action_sqn_opt, J_init, nfev) - the bar for rcg_actor_optimize in RQL / SQL.
 
@@ -33,23 +51,77 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import rcg_oracle as O  # noqa: E402
 from oracle.gen_fixtures import PRESETS, import_reference, make_ctrl, make_sys, save  # noqa: E402
+from oracle.gen_trace_sensitivity import band_of, sensitivity_of, window  # noqa: E402
 
-# (system, start state, t1, Nactor, critic structure); None = the preset's x0
-CASES = [
-    ("3wrobotNI", None, 0.3, 3, "quad-nomix"),
-    ("3wrobotNI", None, 0.3, 3, "quad-mix"),
-    ("3wrobot", None, 0.2, 5, "quad-nomix"),
-    ("2tank", [0.2, 0.3], 3.0, 10, "quad-nomix"),
-    ("2tank", [0.2, 0.3], 3.0, 10, "quadratic"),  # BASELINE configs[2]'s critic structure
-    ("2tank", [0.2, 0.3], 3.0, 10, "quad-lin"),
-]
+PI = np.pi
+# candidate (start state, t1, Nactor) per system, tried in this order for every (mode, critic structure); None = the
+# preset's x0.  The first entry of each list is round 4's choice.
+STARTS = {
+    "3wrobotNI": [(None, 0.3, 3), (None, 0.3, 2), ([-3.0, 4.0, 1.0], 0.3, 2), ([-3.0, 4.0, 1.0], 0.3, 3)],
+    "3wrobot": [(None, 0.2, 5), (None, 0.5, 5)],
+    "2tank": [([0.2, 0.3], 3.0, 10), ([0.2, 0.3], 3.0, 5), ([0.2, 0.3], 3.0, 3), ([0.0, 0.5], 3.0, 10), ([0.1, 0.6], 3.0, 10)],
+}
+# `--explore` walks these as well (the table it printed in round 5 is kept as profiles/r05_critic_trace_exploration.txt: 10 starts
+# per robot, 47 for the tank); they change no choice above - every accepted start is the first accepted one of the longer list too
+EXPLORE_STARTS = {
+    "3wrobotNI": [(None, 0.3, 1), ([2.0, 2.0, 0.0], 0.3, 2), ([1.0, -2.0, PI / 2], 0.3, 2), ([1.0, -2.0, PI / 2], 0.3, 1),
+                  ([2.0, 2.0, 0.0], 0.3, 1), ([-3.0, 4.0, 1.0], 0.3, 1)],
+    "3wrobot": [(None, 0.5, 3), (None, 1.0, 5), (None, 1.0, 3), ([2.0, 2.0, 0.0, 1.0, 0.0], 0.5, 3),
+                ([2.0, 2.0, 0.0, 1.0, 0.0], 0.5, 5), ([-3.0, 4.0, 1.0, 0.0, 0.5], 0.5, 3), ([-3.0, 4.0, 1.0, 0.0, 0.5], 0.5, 5),
+                ([-3.0, 4.0, 1.0, 0.0, 0.5], 1.0, 3)],
+    "2tank": [([0.1, 0.1], 3.0, 10), ([0.1, 0.1], 3.0, 5), ([0.8, 0.2], 3.0, 5), ([0.1, 0.1], 3.0, 3), ([0.8, 0.2], 3.0, 3),
+              ([0.2, 0.3], 3.0, 2), ([0.1, 0.1], 3.0, 2), ([0.2, 0.3], 2.0, 10), ([0.2, 0.3], 2.0, 5), ([0.3, 0.1], 3.0, 10),
+              ([0.3, 0.1], 3.0, 5), ([0.3, 0.1], 2.0, 10), ([0.4, 0.0], 3.0, 10), ([0.4, 0.0], 3.0, 5), ([0.05, 0.4], 3.0, 10),
+              ([0.05, 0.4], 3.0, 5), ([0.3, 0.3], 3.0, 10), ([0.3, 0.3], 3.0, 5), ([0.3, 0.3], 2.0, 10), ([0.2, 0.3], 3.0, 20),
+              ([0.2, 0.3], 3.0, 1), ([0.0, 0.0], 3.0, 10), ([0.0, 0.0], 3.0, 20), ([1.0, 1.0], 3.0, 10), ([1.0, 1.0], 5.0, 10),
+              ([0.2, 0.3], 5.0, 10), ([0.05, 0.4], 3.0, 20), ([0.05, 0.4], 5.0, 10), ([0.0, 0.5], 3.0, 20), ([0.6, 0.0], 3.0, 10),
+              ([0.1, 0.3], 3.0, 10), ([0.15, 0.5], 3.0, 10), ([0.0, 0.3], 3.0, 10), ([0.3, 0.5], 3.0, 10), ([0.0, 0.5], 4.0, 10),
+              ([0.1, 0.3], 4.0, 10), ([0.0, 0.3], 3.0, 5), ([0.1, 0.6], 3.0, 5), ([0.25, 0.2], 3.0, 10), ([0.15, 0.35], 3.0, 10)],
+}
+# (system, critic structure); both critic modes of each
+CASES = [("3wrobotNI", "quad-nomix"), ("3wrobotNI", "quad-mix"), ("3wrobot", "quad-nomix"), ("2tank", "quad-nomix"),
+         ("2tank", "quadratic"), ("2tank", "quad-lin")]  # "quadratic": BASELINE configs[2]'s critic structure
 DISCRIMINATION = 1e-2  # min over the run of max |action - MPC action| a critic-mode trace must exceed
+FIRST_FRACS = [0.01, 0.02, 0.05, 0.1, 0.2]  # first-action displacements, in bound widths
+MPC_GAP_BANDS = 2.0  # the reference's MPC run must lie at least this many bands away
+# combinations for which every start of STARTS and EXPLORE_STARTS was refused (47 for the tank, see the table `--explore`
+# prints): on Sys2Tank the RQL cost is the MPC cost with the last stage replaced by Q_w, and with the 9-weight quad-lin critic
+# the reference's own loop moves by 1 - 19 % under SLSQP's tolerance while its distance to the MPC run stays below 17 %
+NOT_SEPARABLE = {"2tank_RQL_quad-lin"}
 
 
-def run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, critic_struct, capture):
+def slsqp(fun, x0, lo, hi, maxiter):
     from scipy.optimize import Bounds, minimize
 
+    return minimize(fun, x0, method="SLSQP", tol=1e-7, bounds=Bounds(lo, hi, keep_feasible=True),
+                    options={"maxiter": maxiter, "disp": False})
+
+
+def first_action_profile(ctrl, obs, u_star, J_star, du):
+    """rise[i, j]: min over the feasible signs of J(first action component i pinned at u*_i +- tau_j, rest re-optimised
+    by SLSQP from u*) / J* - 1, on the reference's own _actor_cost."""
+    lo, hi = np.array(ctrl.action_sqn_min, dtype=float), np.array(ctrl.action_sqn_max, dtype=float)
+    rise = np.full((du, len(FIRST_FRACS)), np.inf)
+    for i in range(du):
+        for j, fr in enumerate(FIRST_FRACS):
+            tau = fr * (hi[i] - lo[i])
+            for sgn in (-1.0, 1.0):
+                v = u_star[i] + sgn * tau
+                if v < lo[i] or v > hi[i]:
+                    continue
+                l2, h2, x0 = lo.copy(), hi.copy(), np.array(u_star, dtype=float)
+                l2[i] = h2[i] = x0[i] = v
+                try:
+                    Jp = float(slsqp(lambda a: ctrl._actor_cost(a, obs), x0, l2, h2, 300).fun)
+                except ValueError:
+                    Jp = float(ctrl._actor_cost(x0, obs))
+                rise[i, j] = min(rise[i, j], (Jp - J_star) / abs(J_star) if J_star != 0 else np.inf)
+    return rise
+
+
+def run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, critic_struct, capture, profile=False):
     p = PRESETS[name]
     sys_obj = make_sys(systems, name)
     x0 = np.asarray(p["x0"] if x0 is None else x0, dtype=float)
@@ -63,29 +135,37 @@ def run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, critic
     while True:  # presets/main_3wrobot.py:419-446
         sim.sim_step()
         t, state, obs, full = sim.get_sim_step_data()
-        clock_before = ctrl.ctrl_clock
+        clock_before, critic_clock_before = ctrl.ctrl_clock, ctrl.critic_clock
         state_sys_before = np.array(ctrl.state_sys, dtype=float)
         w_prev_before = np.array(ctrl.w_critic_prev, dtype=float)
+        action_prev = np.array(ctrl.action_curr, dtype=float)
         action = controllers.ctrl_selector(t, obs, np.zeros(p["du"]), None, ctrl, mode)
         if capture and ctrl.ctrl_clock != clock_before:  # a control tick happened at this step
             # the same call as controllers.py:1393-1398, on the reference's own _actor_cost, before state_sys moves
             init = np.reshape(ctrl.action_sqn_init, [Nactor * p["du"]])
-            res = minimize(lambda a: ctrl._actor_cost(a, obs), init, method="SLSQP", tol=1e-7,
-                           bounds=Bounds(ctrl.action_sqn_min, ctrl.action_sqn_max, keep_feasible=True),
-                           options={"maxiter": 300, "disp": False})
+            res = slsqp(lambda a: ctrl._actor_cost(a, obs), init, ctrl.action_sqn_min, ctrl.action_sqn_max, 300)
             assert np.array_equal(res.x[: p["du"]], np.asarray(action)), "recomputed SLSQP differs from the reference's"
-            tk = dict(t=float(t), obs=np.array(obs, dtype=float), state_sys=state_sys_before,
+            tk = dict(t=float(t), obs=np.array(obs, dtype=float), state_sys=state_sys_before, action_prev=action_prev,
                       w=np.array(getattr(ctrl, "w_critic", ctrl.w_critic_init), dtype=float), w_prev=w_prev_before,
                       obs_buf=np.array(ctrl.observation_buffer, dtype=float),
                       act_buf=np.array(ctrl.action_buffer, dtype=float), action_sqn=np.array(res.x, dtype=float),
                       J=float(res.fun), J_init=float(ctrl._actor_cost(init, obs)), nfev=int(res.nfev))
             if mode != "MPC":
+                fitted = ctrl.critic_clock != critic_clock_before
                 # _critic_cost reads self.w_critic_prev, which the fit has already overwritten: put the old one back
                 keep = ctrl.w_critic_prev
                 ctrl.w_critic_prev = w_prev_before
                 tk["Jc"] = float(ctrl._critic_cost(tk["w"]))
                 tk["Jc_init"] = float(ctrl._critic_cost(ctrl.w_critic_init))
+                tk["fitted"], tk["critic_status"] = int(fitted), -1
+                if fitted:  # the same call as controllers.py:1262-1264, for SLSQP's exit mode
+                    rc = slsqp(lambda w: ctrl._critic_cost(w), ctrl.w_critic_init, ctrl.Wmin, ctrl.Wmax, 200)
+                    assert np.array_equal(rc.x, tk["w"]), "recomputed critic SLSQP differs from the reference's"
+                    tk["critic_status"] = int(rc.status)
                 ctrl.w_critic_prev = keep
+                assert np.array_equal(tk["act_buf"][-1], action_prev)
+                if profile:
+                    tk["first_rise"] = first_action_profile(ctrl, obs, tk["action_sqn"], tk["J"], p["du"])
             ticks.append(tk)
         sys_obj.receive_action(action)
         ctrl.receive_sys_state(sys_obj._state)
@@ -97,46 +177,104 @@ def run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, critic
     return np.stack(rows), ticks
 
 
-def assert_discriminating(rows, rows_mpc, ds, du, what):
+def action_gap(rows, rows_mpc, ds, du):
     n = min(len(rows), len(rows_mpc))
-    gap = float(np.max(np.abs(rows[:n, 1 + ds:1 + ds + du] - rows_mpc[:n, 1 + ds:1 + ds + du])))
-    assert gap > DISCRIMINATION, (f"{what}: the critic never steers (max |action - MPC action| = {gap:.3g}); "
-                                  "a saturated trace is not a fixture of the critic modes")
-    return gap
+    return float(np.max(np.abs(rows[:n, 1 + ds:1 + ds + du] - rows_mpc[:n, 1 + ds:1 + ds + du])))
+
+
+def oracle_cfg_of(name, mode, cs, Nactor):
+    from tests.helpers import oracle_cfg
+
+    return oracle_cfg(name, n_actor=Nactor, mode=O.MODE_IDS[mode], gamma=1.0, critic_struct=O.CRITIC_IDS[cs], n_critic=4,
+                      buffer_size=10)
+
+
+def judge(ref_mods, name, mode, cs, x0, t1, Nactor, mpc_cache):
+    """Runs the reference from one candidate start; returns (accepted, record)."""
+    systems, simulator, controllers = ref_mods
+    p = PRESETS[name]
+    k = (name, None if x0 is None else tuple(x0), t1, Nactor)
+    if k not in mpc_cache:
+        mpc_cache[k] = run_loop(systems, simulator, controllers, name, "MPC", x0, t1, Nactor, cs, capture=True)
+    rows_mpc, ticks_mpc = mpc_cache[k]
+    rows, ticks = run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, cs, capture=True)
+    gap = action_gap(rows, rows_mpc, p["ds"], p["du"])
+    w_all = np.stack([tk["w"] for tk in ticks])
+    x0v = [float(v) for v in (p["x0"] if x0 is None else x0)]
+    sens = sensitivity_of(oracle_cfg_of(name, mode, cs, Nactor), x0v, t1, p["dt"], rows, p["action_init"])
+    band = band_of(sens["sensitivity"])
+    ref, mpc = window(rows, p["dt"]), window(rows_mpc, p["dt"])
+    mpc_gap = abs(mpc - ref) / abs(ref)
+    n_failed = sum(1 for tk in ticks if tk["fitted"] and tk["critic_status"] != 0)
+    ok = gap > DISCRIMINATION and np.max(np.abs(w_all - 1.0)) > 1e-3 and mpc_gap >= MPC_GAP_BANDS * band
+    rec = dict(x0=x0v, t1=t1, Nactor=Nactor, action_gap=gap, window=ref, window_mpc=mpc, mpc_gap=mpc_gap,
+               sensitivity=sens["sensitivity"], band=band, critic_fits_not_converged=n_failed, n_ticks=len(ticks))
+    return ok, rec, (rows, ticks, rows_mpc, ticks_mpc)
 
 
 def main():
-    systems, simulator, controllers = import_reference()
-    for name, x0, t1, Nactor, cs in CASES:
+    explore = "--explore" in sys.argv
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    ref_mods = import_reference()
+    systems, simulator, controllers = ref_mods
+    mpc_cache = {}
+    for name, cs in CASES:
         p = PRESETS[name]
         ds, du = p["ds"], p["du"]
-        rows_mpc, ticks_mpc = run_loop(systems, simulator, controllers, name, "MPC", x0, t1, Nactor, cs, capture=True)
-        mpc_arrays = {f"mpc_tick_{k}": np.stack([np.asarray(tk[k]) for tk in ticks_mpc])
-                      for k in ("t", "obs", "state_sys", "action_sqn", "J", "J_init", "nfev")}
         for mode in ("RQL", "SQL"):
-            rows, ticks = run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, cs, capture=True)
-            gap = assert_discriminating(rows, rows_mpc, ds, du, f"{name} {mode}")
-            w_all = np.stack([tk["w"] for tk in ticks])
-            assert np.max(np.abs(w_all - 1.0)) > 1e-3, f"{name} {mode}: the critic weights never left w_init"
+            key = f"{name}_{mode}_{cs}"
+            if only and key not in only:
+                continue
+            chosen, tried = None, []
+            for x0, t1, Nactor in STARTS[name] + (EXPLORE_STARTS[name] if explore else []):
+                ok, rec, data = judge(ref_mods, name, mode, cs, x0, t1, Nactor, mpc_cache)
+                print(f"  {key}: x0 {rec['x0']} t1 {t1} N {Nactor}: action gap {rec['action_gap']:.3g}, window "
+                      f"{rec['window']:.4f} (MPC {rec['window_mpc']:.4f}: {rec['mpc_gap']:.2%} away), sensitivity "
+                      f"{rec['sensitivity']:.2%} -> band {rec['band']:.2%}; critic fits SLSQP left unconverged "
+                      f"{rec['critic_fits_not_converged']}/{rec['n_ticks']}  {'ACCEPT' if ok else 'refuse'}", flush=True)
+                tried.append((rec, x0, t1, Nactor))
+                if ok and chosen is None:
+                    chosen = (rec, x0, t1, Nactor)
+                    if not explore:
+                        break
+            if explore:
+                continue
+            if chosen is None:
+                # refused everywhere: allowed only for the combinations listed in NOT_SEPARABLE (with the count of starts
+                # tried); the fixture is then written from the candidate with the largest gap / band ratio and marked
+                # ``discriminating: false`` - it feeds the teacher-forced replay and the per-tick tests, and the
+                # free-running test holds it to its band without claiming that it tells the critic from MPC
+                assert key in NOT_SEPARABLE, (f"{key}: no candidate start separates the critic run from the MPC run by "
+                                              f"{MPC_GAP_BANDS} bands")
+                best = max(tried, key=lambda r: (r[0]["action_gap"] > DISCRIMINATION) * r[0]["mpc_gap"] / r[0]["band"])
+                chosen = best
+            rec, x0, t1, Nactor = chosen
+            # the accepted start once more, now with the first-action profile of every tick (the expensive part)
+            rows, ticks = run_loop(systems, simulator, controllers, name, mode, x0, t1, Nactor, cs, capture=True, profile=True)
+            rows_mpc, ticks_mpc = mpc_cache[(name, None if x0 is None else tuple(x0), t1, Nactor)]
+            assert abs(window(rows, p["dt"]) - rec["window"]) == 0.0  # the reference's loop is deterministic
+            mpc_arrays = {f"mpc_tick_{k}": np.stack([np.asarray(tk[k]) for tk in ticks_mpc])
+                          for k in ("t", "obs", "state_sys", "action_sqn", "J", "J_init", "nfev")}
             meta = dict(system=name, mode=mode, t1=t1, Nactor=Nactor, dt=p["dt"], critic_struct=cs, gamma=1.0,
-                        Ncritic=4, buffer_size=10, x0=[float(v) for v in (p["x0"] if x0 is None else x0)],
-                        pred_step_size=p["dt"] * p["mult"], max_action_gap_to_mpc=gap,
-                        accum_obj=float(rows[-1, -1]), accum_obj_mpc=float(rows_mpc[-1, -1]),
+                        Ncritic=4, buffer_size=10, x0=rec["x0"], pred_step_size=p["dt"] * p["mult"],
+                        max_action_gap_to_mpc=rec["action_gap"], accum_obj=float(rows[-1, -1]),
+                        accum_obj_mpc=float(rows_mpc[-1, -1]), window=rec["window"], window_mpc=rec["window_mpc"],
+                        mpc_gap=rec["mpc_gap"], sensitivity=rec["sensitivity"], band=rec["band"],
+                        discriminating=bool(rec["mpc_gap"] >= MPC_GAP_BANDS * rec["band"]), starts_tried=len(tried),
+                        critic_fits_not_converged=rec["critic_fits_not_converged"], first_fracs=FIRST_FRACS,
                         columns="t,state...,action...,stage_obj,accum_obj")
             tick_arrays = {f"tick_{k}": np.stack([np.asarray(tk[k]) for tk in ticks]) for k in ticks[0]}
-            save(f"F7c_trace_{name}_{mode}_{cs}", meta, rows=rows, rows_mpc=rows_mpc, **tick_arrays, **mpc_arrays)
+            save(f"F7c_trace_{key}", meta, rows=rows, rows_mpc=rows_mpc, **tick_arrays, **mpc_arrays)
             # optimiser-quality subsample: every tick of the short runs, every 3rd of the long one, at most 32
             step = max(1, len(ticks) // 32)
             sel = ticks[::step][:32]
-            save(f"F8c_slsqp_actor_{name}_{mode}_{cs}",
+            save(f"F8c_slsqp_actor_{key}",
                  dict(system=name, mode=mode, N=Nactor, gamma=1.0, critic_struct=cs, pred_step_size=p["dt"] * p["mult"],
                       note="ticks of F7c_trace: SLSQP from action_sqn_init on the reference's _actor_cost"),
                  state=np.stack([tk["state_sys"] for tk in sel]), obs=np.stack([tk["obs"] for tk in sel]),
                  w=np.stack([tk["w"] for tk in sel]), J_opt=np.array([tk["J"] for tk in sel]),
                  action_sqn_opt=np.stack([tk["action_sqn"] for tk in sel]),
                  J_init=np.array([tk["J_init"] for tk in sel]), nfev=np.array([tk["nfev"] for tk in sel]))
-            print(f"  {name} {mode} {cs}: {len(rows)} sim steps, {len(ticks)} ticks, max action gap to MPC {gap:.3g}, "
-                  f"accum {rows[-1, -1]:.4f} (MPC {rows_mpc[-1, -1]:.4f})")
 
 
 if __name__ == "__main__":

@@ -32,11 +32,15 @@ from . import rcg_oracle as O
 
 class RefLoop:
     def __init__(self, cfg: O.OracleCfg, state_init, t1, action_init=None, atol=1e-5, rtol=1e-3, actor_tol=1e-7,
-                 critic_tol=1e-7):
+                 critic_tol=1e-7, critic="slsqp"):
         # actor_tol / critic_tol: SLSQP's `tol` (the reference hard-codes 1e-7, controllers.py:1264, 1396); other values
         # exist for ONE purpose - measuring how far the reference's own closed loop moves when nothing but the optimiser's
         # stopping rule changes (tests/test_critic_traces.py: the band a different optimiser can be held to)
-        self.actor_tol, self.critic_tol = actor_tol, critic_tol
+        # critic = "exact": the reference's loop with ONE ingredient exchanged - its critic's SLSQP call replaced by the exact
+        # minimiser of the build-defined objective (O.critic_fit).  SLSQP leaves 4 .. 74 % of the robots' fits at their start
+        # point w_init (fixture field tick_critic_status), so on some traces this exchange alone moves the reference's own loop
+        # by more than the band; tests/test_hip_ref_traces.py holds the HIP loop to THIS loop as well (F7c_sensitivity.json)
+        self.actor_tol, self.critic_tol, self.critic_kind = actor_tol, critic_tol, critic
         self.cfg = cfg
         ds, du = cfg.ds, cfg.du
         self.dt = cfg.sampling_time
@@ -132,6 +136,8 @@ class RefLoop:
         return sqn[: self.cfg.du]
 
     def _critic_optimizer(self):
+        if self.critic_kind == "exact":
+            return O.critic_fit(self.cfg, self.w_prev[None], self.obs_buf[None], self.act_buf[None])[0]
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             return minimize(self._critic_cost, self.w_init, method="SLSQP", tol=self.critic_tol,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librcg.so")
 
 # ---- enums (include/rcg.h) -------------------------------------------------------------------
-RCG_VERSION = 115
+RCG_VERSION = 116
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
 SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
 MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
@@ -45,7 +45,7 @@ SYMBOLS = [
     "rcg_version", "rcg_last_error", "rcg_device_count", "rcg_create", "rcg_destroy", "rcg_set_stream", "rcg_use_own_stream",
     "rcg_synchronize", "rcg_dev_alloc", "rcg_dev_free", "rcg_memcpy_h2d", "rcg_memcpy_d2h", "rcg_set_field",
     "rcg_get_field", "rcg_field_bytes", "rcg_field_ptr", "rcg_rhs", "rcg_stage_obj", "rcg_critic",
-    "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_actor_argmin", "rcg_control_tick",
+    "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_sim_step_h", "rcg_actor_argmin", "rcg_control_tick",
     "rcg_critic_update", "rcg_control_ticks", "rcg_control_tick_n", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
     "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
     "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream", "rcg_nominal_theta", "rcg_set_optimizer",
@@ -140,6 +140,7 @@ def lib():
         "rcg_actor_cost": (C.c_int, [vp, vp, i32, vp, vp, vp, vp]),
         "rcg_critic_cost": (C.c_int, [vp, vp, vp]),
         "rcg_sim_step": (C.c_int, [vp, i32]),
+        "rcg_sim_step_h": (C.c_int, [vp, i32, C.c_double]),
         "rcg_actor_argmin": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp]),
         "rcg_control_tick": (C.c_int, [vp, vp, i32]),
         "rcg_critic_update": (C.c_int, [vp, i32]),

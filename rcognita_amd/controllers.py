@@ -50,7 +50,7 @@ class CtrlOptPred:
                  stage_obj_struct="quadratic", stage_obj_pars=[], observation_target=[],
                  # ---- build-specific, keyword-only in spirit ----
                  candidates=None, actor_opt="auto", opt_iters=30, n_candidates=256, rounds=6, seed=0, dtype="f64",
-                 device=0):
+                 device=0, clock_tol=1e-9):
         if is_est_model:
             raise NotImplementedError("is_est_model=1 needs the absent `sippy` package and is out of scope "
                                       "(SURVEY.md 2, component 3)")
@@ -66,6 +66,9 @@ class CtrlOptPred:
         self.mode = mode
         self.ctrl_clock = t0
         self.sampling_time = sampling_time
+        # relative slack of the two sampling tests of compute_action; 0 = the reference's bare float comparison
+        # (controllers.py:1440, 1466), which a caller replaying the reference's own time stamps needs
+        self.clock_tol = float(clock_tol)
         self.Nactor = Nactor
         self.pred_step_size = pred_step_size
         ctrl_bnds = np.asarray(ctrl_bnds, dtype=float)
@@ -244,7 +247,7 @@ class CtrlOptPred:
     def compute_action(self, t, observation):
         """Main method (rcognita/controllers.py:1429-1493)."""
         time_in_sample = t - self.ctrl_clock
-        if time_in_sample >= self.sampling_time * (1 - 1e-9):  # new sample
+        if time_in_sample >= self.sampling_time * (1 - self.clock_tol):  # new sample
             self.ctrl_clock = t
             if self.mode in ("RQL", "SQL"):
                 time_in_critic_period = t - self.critic_clock
@@ -261,7 +264,7 @@ class CtrlOptPred:
                 else:
                     self.action_buffer = np.vstack([self.action_buffer[1:], a])
                     self.observation_buffer = np.vstack([self.observation_buffer[1:], y])
-                if time_in_critic_period >= self.critic_period * (1 - 1e-9):
+                if time_in_critic_period >= self.critic_period * (1 - self.clock_tol):
                     self.critic_clock = t
                     self.w_critic = self._critic_optimizer()
                     self.w_critic_prev = self.w_critic

@@ -545,6 +545,22 @@ int rcg_sim_step(rcg_handle* h, int32_t n_substeps) {
   return h->sys->sim_step(h, n_substeps);
 }
 
+int rcg_sim_step_h(rcg_handle* h, int32_t n_substeps, double step) {
+  DeviceGuard dev_guard(h);
+  if (!h || n_substeps < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_sim_step_h: n_substeps must be >= 1");
+  if (!(step > 0.0) || !(step < 1e300))
+    return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_sim_step_h: step must be positive and finite (got %g)", step);
+  // the kernels take the substep from the by-value parameter block: lend it this call's length
+  const float d32 = h->p32.dt_sim;
+  const double d64 = h->p64.dt_sim;
+  h->p64.dt_sim = step / (double)n_substeps;
+  h->p32.dt_sim = (float)h->p64.dt_sim;
+  const int rc = h->sys->sim_step(h, n_substeps);
+  h->p32.dt_sim = d32;
+  h->p64.dt_sim = d64;
+  return rc;
+}
+
 // w_critic = w_prev = clip(w_init, Wmin, Wmax): what the reference's SLSQP returns when the TD stack is empty
 // (Ncritic = 1: _critic_cost is identically 0, controllers.py:1227-1245, so minimize() stops at its start point)
 static int critic_keep_init(rcg_handle* h) {
@@ -633,10 +649,25 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
 // rcg_control_tick_n runs their T ticks in one persistent launch when the handle's mode allows it
 static const int kPersistentTicksMaxBatch = 16384;
 
+// A caller's tensor under the persistent kernel: k_ticks keeps a wave's rows in LDS for all T ticks when they fit 32 KB
+// (op_ticks: stage_once); beyond that it re-stages every tile every tick through plain loads, which only pays while the whole
+// tensor stays in the Infinity Cache (256 MB; half of it granted here) - K = 1024 rows of 80 B at 16 384 envs is 1.3 GB per
+// tick, and the per-tick loop on k_actor_dma streams that at 4.6-5.5 TB/s against 2.9-3.7 for plain staging.
+static bool ticks_rows_stay_close(const rcg_handle* h, const void* cand, int32_t K) {
+  if (!cand || K < 1) return true;
+  const size_t row_bytes = (size_t)h->cfg.n_actor * h->du * h->esz;
+  int kp = 1;
+  while (kp < K) kp <<= 1;
+  const size_t rows_wave = K >= 64 ? (size_t)K : (size_t)(64 / kp) * K;
+  if (rows_wave * row_bytes <= (size_t)32 * 1024) return true;
+  return (size_t)h->cfg.batch * K * row_bytes <= (size_t)128 << 20;
+}
+
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T) {
   if (!h) return RCG_ERR_BAD_ARG;
   if (T < 1) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_control_tick_n: T must be >= 1");
-  if (T > 1 && h->cfg.mode == RCG_MODE_MPC && h->cfg.batch <= kPersistentTicksMaxBatch) {
+  if (T > 1 && h->cfg.mode == RCG_MODE_MPC && h->cfg.batch <= kPersistentTicksMaxBatch &&
+      ticks_rows_stay_close(h, cand, K)) {
     // MPC (any stage-cost structure, with or without the disturbance model): k_ticks keeps the env in registers and, for a
     // caller's tensor, the wave's candidate rows in LDS - every field ends as T single ticks leave it, bit for bit
     DeviceGuard dev_guard(h);
@@ -650,6 +681,7 @@ int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T) {
       h->cfg.n_critic - 1 >= 1 && h->cfg.n_critic - 1 <= kFitMaxRows && !(h->cfg.flags & RCG_FLAG_DISTURB)) {
     const int rc = rcg_control_ticks(h, T, K);  // RQL / SQL, generated grid: k_ticks_mem
     if (rc != RCG_ERR_UNSUPPORTED) return rc;  // (no instance for this observation target: the loop below)
+    h->err.clear();  // the refusal was this function's own probe, not the caller's error (rcg_last_error after RCG_OK)
   }
   for (int32_t t = 0; t < T; ++t) {
     const int rc = rcg_control_tick(h, cand, K);

@@ -14,7 +14,7 @@
 // The TD stack (A, b) is built by critic_prologue exactly as for k_critic_fit - all four lanes run it, lane 0 of the quad
 // stores - so the problem instance is the same bits; what differs is the ASSOCIATION of the sums over variables: the weights
 // agree with k_critic_fit and with the float64 oracle to the tolerances of the parity tests on the same inputs (the whole
-// critic test set passes with this form forced for every structure: 324 tests, RCG_TEST_LIB / RCG_FIT_LANES=4), not bit for
+// critic test set passes with this form forced for every structure: 324 tests, --rcg-lib + RCG_FIT_LANES=4), not bit for
 // bit; on rank-deficient stacks a last-bit difference can end the walk on another vertex of equal cost, which 40 free-running
 // ticks amplify (profiles/r04_fit_four_lanes.txt).
 // Where it runs: the structures with >= 20 weights (rcg_sysops.hpp::launch_fit3) - there the one-lane walk, up to 3 dc + 10
@@ -197,7 +197,9 @@ __device__ __forceinline__ void critic_update_env_ml(const FitArgs<real>& F, con
       const double on = quad_xchg(nb, ctrl), od = quad_xchg(db, ctrl);
       const int oj = quad_xchg(jmin, ctrl);
       const double l = on * db, r = nb * od;  // other < mine  <=>  on / od < nb / db
-      const bool take = oj >= 0 && (jmin < 0 || l < r || (l == r && oj < jmin));
+      // total order: whenever neither ratio is strictly smaller - equal, or a NaN product from non-finite
+      // buffers (0 * inf) - the lower index wins in BOTH partners, so the quad always agrees on (nb, db, jmin)
+      const bool take = oj >= 0 && (jmin < 0 || l < r || (!(r < l) && oj < jmin));
       nb = take ? on : nb;
       db = take ? od : db;
       jmin = take ? oj : jmin;
@@ -258,7 +260,7 @@ __device__ __forceinline__ void critic_update_env_ml(const FitArgs<real>& F, con
       const int ctrl = st == 0 ? 0xB1 : 0x4E;
       const double os = quad_xchg(best_score, ctrl);
       const int ob = quad_xchg(best, ctrl);
-      const bool take = ob >= 0 && (best < 0 || os > best_score || (os == best_score && ob < best));
+      const bool take = ob >= 0 && (best < 0 || os > best_score || (!(best_score > os) && ob < best));  // total, as above
       best_score = take ? os : best_score;
       best = take ? ob : best;
     }

@@ -572,8 +572,13 @@ class Engine:
         return Jc.to_host()
 
     # ------------------------------------------------------------------ stateful steps
-    def sim_step(self, n_substeps=1):
-        N.check(N.lib().rcg_sim_step(self._h, int(n_substeps)), self._h)
+    def sim_step(self, n_substeps=1, step=None):
+        """``n_substeps`` RK4 substeps of the handle's ``dt_sim``; with ``step``: ONE step of that length, cut into
+        ``n_substeps`` substeps (rcg_sim_step_h)."""
+        if step is None:
+            N.check(N.lib().rcg_sim_step(self._h, int(n_substeps)), self._h)
+        else:
+            N.check(N.lib().rcg_sim_step_h(self._h, int(n_substeps), float(step)), self._h)
 
     def actor_argmin(self, cand=None, K=None, obs=None, state_sys=None):
         """Returns ``(action [B, du], best_J [B], best_idx [B] int32)``."""

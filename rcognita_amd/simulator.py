@@ -73,14 +73,22 @@ class Simulator:
     def _shape(self, a):
         return a if self._batched else a[0]
 
-    def sim_step(self):
+    def sim_step(self, t_next=None):
         """One simulation step of length ``dt`` (rcognita/simulator.py:156-168): the action held by the
-        system object is clipped to the control bounds and applied over the whole step."""
+        system object is clipped to the control bounds and applied over the whole step.
+
+        ``t_next`` (build-specific, optional): advance to that time instead - one step of length ``t_next - t``
+        (rcg_sim_step_h).  The reference's solver picks its own steps; a caller that has a recorded time grid of the
+        reference can walk it (tests/test_hip_ref_traces.py)."""
         act = np.broadcast_to(np.asarray(self.sys.action, dtype=float), (self.B, self.sys.dim_input))
         self._eng.set_field(N.FIELD_ACTION, act)
-        self._eng.sim_step(self.n_substeps)
         self.step_idx += 1
-        self.t = self.t0 + self.step_idx * self.dt
+        if t_next is None:
+            self._eng.sim_step(self.n_substeps)
+            self.t = self.t0 + self.step_idx * self.dt
+        else:
+            self._eng.sim_step(self.n_substeps, step=float(t_next) - float(self.t))
+            self.t = float(t_next)
         st = self._eng.get_state().astype(float)
         if self.is_disturb:
             st = np.concatenate([st, self._eng.get_field(N.FIELD_DISTURB).astype(float)], axis=-1)

@@ -36,9 +36,25 @@ def test_the_critic_steers_in_every_fixture(name, cs, mode):
     rows, mpc = z["rows"], z["rows_mpc"]
     n = min(len(rows), len(mpc))
     gap = np.max(np.abs(rows[:n, 1 + ds:1 + ds + du] - mpc[:n, 1 + ds:1 + ds + du]))
-    assert gap > 1e-2, gap  # the generator's own bar
+    assert gap > 1e-2, gap  # the generator's own bars (oracle/gen_critic_fixtures.py)
     assert np.max(np.abs(z["tick_w"] - 1.0)) > 1e-3  # the weights left w_init = ones
-    assert abs(rows[-1, -1] - mpc[-1, -1]) > 5e-4 * abs(mpc[-1, -1])  # and the running cost says so too
+    # round 5: the reference's MPC run from the same start lies at least two bands away - band = max(6 %, 2 x the distance
+    # the reference's own loop moves under a change of SLSQP's tolerance) - in all but the one combination for which none of
+    # 47 starts does (the fixture says so: discriminating = false)
+    dt = meta["dt"]
+    i0 = lambda r: int(np.argmin(np.abs(r[:, 0] - 2 * dt)))
+    a, m = rows[-1, -1] - rows[i0(rows), -1], mpc[-1, -1] - mpc[i0(mpc), -1]
+    assert abs(abs(m - a) / abs(a) - meta["mpc_gap"]) < 1e-12 and abs(a - meta["window"]) < 1e-12
+    assert meta["band"] == max(0.06, 2 * meta["sensitivity"])
+    assert meta["discriminating"] == (meta["mpc_gap"] >= 2 * meta["band"])
+    assert meta["discriminating"] or (name, mode, cs) == ("2tank", "RQL", "quad-lin")
+    # every tick carries what a teacher-forced replay needs
+    n = len(z["tick_t"])
+    for k in ("obs", "state_sys", "action_prev", "w", "w_prev", "fitted", "critic_status", "obs_buf", "act_buf", "action_sqn",
+              "J", "Jc", "Jc_init", "first_rise"):
+        assert z["tick_" + k].shape[0] == n, k
+    assert z["tick_first_rise"].shape[1:] == (cfg.du, len(meta["first_fracs"]))
+    assert np.array_equal(z["tick_act_buf"][:, -1], z["tick_action_prev"]) and np.array_equal(z["tick_obs_buf"][:, -1], z["tick_obs"])
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -77,15 +93,16 @@ def test_reference_loop_restatement_follows_the_critic_traces(name, cs, mode):
 @pytest.mark.parametrize("name,cs", CASES)
 def test_critic_fit_on_the_stacks_of_the_reference_loop(name, cs, mode):
     """The build-defined bounded least squares (oracle twin of k_critic_fit) on the TD stacks the reference's own closed
-    loop produced: never above Jc(w_init), and above SLSQP's Jc by at most the band DESIGN.md 6 states for the F8
-    stacks, 4.4e-3 Jc(w_init) - that gap IS the mu term of the build-defined objective (measured on these 12 traces:
-    <= 7.7e-4, and strictly below SLSQP's Jc on 4-60 % of the ticks)."""
+    loop produced: never above Jc(w_init), and above SLSQP's Jc by at most 2e-2 Jc(w_init) - what the Tikhonov term of the
+    build-defined objective (mu = 1e-8 trace / m) leaves in the directions it damps; measured on these 12 traces:
+    <= 1.34e-2, and at or below SLSQP's Jc on 97 % of the 354 ticks (oracle/experiments/fit_mu_study.py prices the
+    alternatives).  The sharp form - P(w_fit) <= P(w_SLSQP) in the fit's own objective - is tests/teacher_forced.py's."""
     meta, z = load_golden(f"F7c_trace_{name}_{mode}_{cs}")
     cfg = trace_cfg(meta)
     w = O.critic_fit(cfg, z["tick_w_prev"], z["tick_obs_buf"], z["tick_act_buf"])
     Jc = O.critic_cost(w, z["tick_w_prev"], z["tick_obs_buf"], z["tick_act_buf"], cfg)
     scale = np.maximum(z["tick_Jc_init"], 1e-12)
-    assert np.all(Jc <= z["tick_Jc"] + 4.4e-3 * scale + 1e-12), np.max((Jc - z["tick_Jc"]) / scale)
+    assert np.all(Jc <= z["tick_Jc"] + 2e-2 * scale + 1e-12), np.max((Jc - z["tick_Jc"]) / scale)
     assert np.all(Jc <= z["tick_Jc_init"] * (1 + 1e-12) + 1e-12)
     lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
     assert np.all(w >= lo - 1e-12) and np.all(w <= hi + 1e-12)
@@ -108,4 +125,11 @@ def test_sensitivity_fixture_is_what_the_restated_loop_gives(key):
     s = sensitivity(name, mode, cs)
     assert abs(s["accum_window"] - fx["traces"][key]["accum_window"]) < 1e-6 * abs(s["accum_window"])
     np.testing.assert_allclose(s["rel_change"], fx["traces"][key]["rel_change"], rtol=1e-3, atol=1e-5)
+    for k in ("window_23", "window_1", "ref_window_23", "shift"):  # the reference's loop with an exact critic fit
+        assert abs(s["exact_critic"][k] - fx["traces"][key]["exact_critic"][k]) <= 1e-6 * max(abs(s["exact_critic"][k]), 1e-3), k
     assert len(fx["traces"]) == 12
+    # which traces the critic-solver exchange moves by more than their band is a measured list, not a hand-made one
+    from oracle.gen_trace_sensitivity import band_of
+
+    moved = sorted(k for k, v in fx["traces"].items() if v["exact_critic"]["shift"] > band_of(v["sensitivity"]))
+    assert moved == ["2tank_RQL_quadratic", "3wrobotNI_RQL_quad-mix"], moved
