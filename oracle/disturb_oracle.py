@@ -26,13 +26,14 @@ MASK = np.uint64(0xFFFFFFFF)
 DIM_DISTURB = {O.SYS_3WROBOT: 2, O.SYS_3WROBOT_NI: 2, O.SYS_2TANK: 1}
 
 
-def philox4x32_10(counter, key):
-    """Philox4x32 with 10 rounds.  counter [..., 4] uint32, key [..., 2] uint32 -> [..., 4] uint32."""
+def philox4x32_10(counter, key, rounds=10):
+    """Philox4x32 with 10 rounds (``rounds``: the candidate draws of oracle/search_oracle.py use 7).  counter [..., 4] uint32,
+    key [..., 2] uint32 -> [..., 4] uint32."""
     c = [np.asarray(counter[..., i], dtype=np.uint32).copy() for i in range(4)]
     k0 = np.asarray(key[..., 0], dtype=np.uint32).copy()
     k1 = np.asarray(key[..., 1], dtype=np.uint32).copy()
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(int(rounds)):
             p0 = M0 * c[0].astype(np.uint64)
             p1 = M1 * c[2].astype(np.uint64)
             hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & MASK).astype(np.uint32)

@@ -10,11 +10,14 @@ rcg_search.hpp; this file mirrors it statement by statement:
     centre   round 0: the caller's sequence; later rounds: the previous round's winner
     k = 0    the centre itself;   round 0, k = 1: action_sqn_init
     else     clip(centre + sigma_r xi, lo, hi),  sigma_r = 0.5 (hi - lo) 2^-round
-             k < K // 2: one draw per input held over the horizon;  k >= K // 2: one draw per input and step
-    xi       key of (env, tick) = words 0, 1 of Philox4x32-10(counter = (env id lo, env id hi, episode_idx, step_idx),
-             key = (seed lo ^ 0x43414E44, seed hi));  chunk j of candidate k in round r = Philox(counter = (k, j, r, 0), that
-             key) -> u_i = float32((m_i + 0.5) 2^-24), m_i = word_i >> 8 -> (xi_0, xi_1) = sqrt(-2 ln u_0) (cos, sin)(2 pi u_1),
-             (xi_2, xi_3) likewise from (u_2, u_3): the normals of row elements 4 j .. 4 j + 3.
+             k < K - K // 4: one draw per input held over the horizon;  the last quarter: one draw per input and step
+    xi       key of (env, tick) = words 0, 1 of Philox4x32-7(counter = (env id lo, env id hi, episode_idx, step_idx),
+             key = (seed lo ^ 0x43414E44, seed hi)).  A DRAW = Philox4x32-7(counter = (a, b, r, kind), that key) -> four
+             words -> eight normals: word p gives (n_2p, n_2p+1) = sqrt(-2 ln u_r) (cos, sin)(2 pi u_a) with
+             u_r = float32(((w & 0xffff) + 0.5) 2^-16), u_a = float32(((w >> 16) + 0.5) 2^-16).
+             per-step candidate k (k >= K - K // 4): row element e <- draw (k, e // 8, kind 0), normal e % 8;
+             held candidate k (k < K - K // 4): l = k % 64, t = k // 64, TPC = 8 // du: input c <- draw (l, t // TPC, kind 1),
+             normal (t % TPC) du + c.
 
 The integer stream and the uniforms are bit-exact twins of the kernel's; the kernel evaluates ln / sqrt / sin / cos with the
 hardware's float32 instructions, this file in float64, so a candidate agrees to ~1e-6 sigma (the tests state the tolerance) -
@@ -27,6 +30,7 @@ from . import rcg_oracle as O
 from .disturb_oracle import MASK, philox4x32_10
 
 CAND_DOMAIN = np.uint32(0x43414E44)
+CAND_ROUNDS = 7  # Philox rounds of the candidate stream (key derivation and draws)
 
 
 def cand_subkey(seed, env_id, episode_idx, step_idx):
@@ -37,31 +41,67 @@ def cand_subkey(seed, env_id, episode_idx, step_idx):
     s = np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)
     key = np.broadcast_to(np.array([np.uint32(s & MASK) ^ CAND_DOMAIN, np.uint32(s >> np.uint64(32))], dtype=np.uint32),
                           ctr.shape[:-1] + (2,))
-    return philox4x32_10(ctr, key)[..., :2]
+    return philox4x32_10(ctr, key, rounds=CAND_ROUNDS)[..., :2]
 
 
-def cand_uniforms(key, K, n_chunks, round_):
-    """[B, K, n_chunks, 4] float32 uniforms (bit-exact twin of the kernel's)."""
+def ps_first(K):
+    """Index of the first per-step candidate: the last quarter of the K candidates."""
+    return K - (K >> 2)
+
+
+def cand_draws(key, a, b, round_, kind):
+    """The words of draws (a, b, round, kind) under each env's key: ``a``, ``b`` integer arrays of one shape S -> [B, *S, 4]
+    uint32 (bit-exact twin of the kernel's)."""
+    a, b = np.broadcast_arrays(np.asarray(a, dtype=np.uint32), np.asarray(b, dtype=np.uint32))
+    ctr = np.stack([a, b, np.full_like(a, np.uint32(round_)), np.full_like(a, np.uint32(kind))], axis=-1)
     B = key.shape[0]
-    k, j = np.meshgrid(np.arange(K, dtype=np.uint32), np.arange(n_chunks, dtype=np.uint32), indexing="ij")
-    ctr = np.stack([k, j, np.full_like(k, np.uint32(round_)), np.zeros_like(k)], axis=-1)  # [K, n_chunks, 4]
     ctr = np.broadcast_to(ctr[None], (B,) + ctr.shape)
-    kk = np.broadcast_to(key[:, None, None, :], (B, K, n_chunks, 2))
-    bits = philox4x32_10(ctr, kk)
-    m = (bits >> np.uint32(8)).astype(np.float32)
-    return m * np.float32(2.0 ** -24) + np.float32(2.0 ** -25)  # float32: exact product, one rounding in the sum
+    kk = np.broadcast_to(key.reshape((B,) + (1,) * a.ndim + (2,)), ctr.shape[:-1] + (2,))
+    return philox4x32_10(ctr, kk, rounds=CAND_ROUNDS)
 
 
-def cand_normals(key, K, n_chunks, round_):
-    """[B, K, n_chunks, 4] float64 normals: Box-Muller on the pairs (u0, u1), (u2, u3)."""
-    u = cand_uniforms(key, K, n_chunks, round_).astype(np.float64)
-    out = np.empty_like(u)
-    for p in range(2):
-        r = np.sqrt(-2.0 * np.log(u[..., 2 * p]))
-        th = 2.0 * np.pi * u[..., 2 * p + 1]
-        out[..., 2 * p] = r * np.cos(th)
-        out[..., 2 * p + 1] = r * np.sin(th)
+def uniforms_of(bits):
+    """[..., 4] words -> (u_r, u_a) [..., 4] float32 each: the 16-bit uniforms of the four Box-Muller pairs."""
+    mr = (bits & np.uint32(0xFFFF)).astype(np.float32)
+    ma = (bits >> np.uint32(16)).astype(np.float32)
+    c, h = np.float32(2.0 ** -16), np.float32(2.0 ** -17)
+    return mr * c + h, ma * c + h  # float32: exact products, exact sums (17 significant bits)
+
+
+def normals_of(bits):
+    """[..., 4] words -> [..., 8] float64 normals."""
+    ur, ua = uniforms_of(bits)
+    r = np.sqrt(-2.0 * np.log(ur.astype(np.float64)))
+    th = 2.0 * np.pi * ua.astype(np.float64)
+    out = np.empty(bits.shape[:-1] + (8,))
+    out[..., 0::2] = r * np.cos(th)
+    out[..., 1::2] = r * np.sin(th)
     return out
+
+
+def cand_uniforms(key, K, n_draws, round_):
+    """[B, K, n_draws, 8] float32: the uniforms (u_r, u_a interleaved pair by pair) of the per-step draws (k, j)."""
+    k, j = np.meshgrid(np.arange(K), np.arange(n_draws), indexing="ij")
+    ur, ua = uniforms_of(cand_draws(key, k, j, round_, 0))
+    out = np.empty(ur.shape[:-1] + (8,), dtype=np.float32)
+    out[..., 0::2], out[..., 1::2] = ur, ua
+    return out
+
+
+def cand_normals(key, K, n_draws, round_):
+    """[B, K, n_draws, 8] float64 normals of the per-step draws (k, j)."""
+    k, j = np.meshgrid(np.arange(K), np.arange(n_draws), indexing="ij")
+    return normals_of(cand_draws(key, k, j, round_, 0))
+
+
+def held_normals(key, K, du, round_):
+    """[B, K, du] float64: the normals a HELD candidate k applies at every step (only rows k < ps_first(K) are used)."""
+    tpc = 8 // du
+    k = np.arange(K)
+    lane, t = k % 64, k // 64
+    n8 = normals_of(cand_draws(key, lane, t // tpc, round_, 1))  # [B, K, 8]
+    idx = ((t % tpc) * du)[:, None] + np.arange(du)[None, :]     # [K, du]
+    return np.take_along_axis(n8, np.broadcast_to(idx[None], (n8.shape[0],) + idx.shape), axis=-1)
 
 
 def candidates_sample(cfg: O.OracleCfg, seed, env_id, episode_idx, step_idx, K, round_, centre=None, action_init=None):
@@ -72,12 +112,12 @@ def candidates_sample(cfg: O.OracleCfg, seed, env_id, episode_idx, step_idx, K, 
     lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
     u0 = O.action_sqn_init(cfg, action_init)  # [N, du]
     c = np.broadcast_to(u0, (B, N, du)) if centre is None else np.asarray(centre, dtype=np.float64).reshape(B, N, du)
-    n_chunks = (R + 3) // 4
+    n_draws = (R + 7) // 8
     key = cand_subkey(seed, env_id, episode_idx, step_idx)
-    xi = cand_normals(key, K, n_chunks, round_)  # [B, K, n_chunks, 4]
-    per_step = xi.reshape(B, K, n_chunks * 4)[..., :R].reshape(B, K, N, du)
-    held = np.broadcast_to(xi[:, :, 0, :du][:, :, None, :], (B, K, N, du))  # chunk 0's first du normals at every step
-    noise = np.where((np.arange(K) >= (K >> 1))[None, :, None, None], per_step, held)
+    xi = cand_normals(key, K, n_draws, round_)  # [B, K, n_draws, 8]
+    per_step = xi.reshape(B, K, n_draws * 8)[..., :R].reshape(B, K, N, du)
+    held = np.broadcast_to(held_normals(key, K, du, round_)[:, :, None, :], (B, K, N, du))
+    noise = np.where((np.arange(K) >= ps_first(K))[None, :, None, None], per_step, held)
     sigma = (0.5 * (hi - lo)) * 2.0 ** (-float(round_))
     cand = np.minimum(np.maximum(c[:, None] + sigma * noise, lo), hi)
     cand[:, 0] = c

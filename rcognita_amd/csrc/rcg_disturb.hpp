@@ -19,10 +19,13 @@ struct PhiloxOut {
   uint32_t w[4];
 };
 
-__device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                   uint32_t k1) {
+// ROUNDS = 10: the published generator (its known answers are pinned in tests/test_disturb_oracle.py) - the disturbance model
+// and the per-env key of the candidate stream; ROUNDS = 7: the candidate draws of k_actor_search / k_cand_sample (the least
+// round count Salmon et al. report as passing BigCrush; the integer stream is bit-exact against oracle/search_oracle.py)
+template <int ROUNDS>
+__device__ __forceinline__ PhiloxOut philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
     const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -34,6 +37,10 @@ __device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uin
     k1 += 0xBB67AE85u;
   }
   return PhiloxOut{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ PhiloxOut philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                   uint32_t k1) {
+  return philox4x32<10>(c0, c1, c2, c3, k0, k1);
 }
 
 __device__ __forceinline__ PhiloxOut noise_bits(uint64_t seed, int64_t env_id, int32_t episode, int32_t substep) {

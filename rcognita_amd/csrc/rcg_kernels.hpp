@@ -313,12 +313,15 @@ __device__ __forceinline__ void gen_candidate(const KParams<real>& P, int g, int
 // component, S_i += chi_i^2, and weighted once at the end, J = sum_i R1_ii S_i - 7 fma per 3wrobot step instead of 14
 // ops + the discount bookkeeping, in a rollout of ~33 (the generated-candidate regime is VALU-issue-bound,
 // profiles/r02_*_valu_pmc.json; k_actor_dma has had the same variant since round 1).
+// NC > 0 (k_actor_search): the horizon is the compile-time constant NC and the loop is fully unrolled, so a row handed over as
+// a REGISTER array (urow[kk * DU + c] with static indices) never touches memory.
 template <typename Sys, typename real, bool TGT, bool STREAM, int MODE_C, int SK_C, int CS_C, bool G1 = false, unsigned ZW = 0u,
-          typename WGet>
-__device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
+          int NC = 0, typename WGet>
+__device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N_rt,
                                              const real* xs, const real* y0, const real* urow, const real* ugen,
                                              WGet wget, real* u0) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
+  const int N = NC > 0 ? NC : N_rt;
   const int mode = MODE_C >= 0 ? MODE_C : P.mode;
   const int sk = SK_C >= 0 ? SK_C : P.stage_kind;
   const int cs = CS_C >= 0 ? CS_C : P.critic_struct;
@@ -347,47 +350,65 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
 #pragma unroll
   for (int i = 0; i < DS; ++i)
     if (G1 && ((ZW >> i) & 1u)) zw0 = fma_r(P.R1d[i], y0[i] * y0[i], zw0);
-  for (int kk = 0; kk < N; ++kk) {
+// One step kk of the rollout, expanded below in the runtime-horizon loop and in the fully unrolled compile-time one (a macro,
+// not a lambda: wrapping the body in a lambda changed one fma contraction in one instance, and T ticks in one launch must
+// stay bit-identical to T single ticks).  The Euler step is unclipped, as sys_rhs([], state, u[k-1]); f32: hardware
+// v_sin / v_cos behind the exact reduction, as in k_actor_dma (3.7e-7 max abs error, 7 VALU ops instead of ~25).  G1: per-
+// component sums (ZW: weight exactly zero, term skipped); RQL's last step is Q_w(y_{N-1}, u_{N-1}) (controllers.py:1310); SQL
+// with a compile-time structure sums the regressor per feature (critic_phi_accum).
+#define RCG_ROLLOUT_STEP                                                                                             \
+_Pragma("unroll")                                                                                                        \
+    for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];                                         \
+    if (kk == 0) {                                                                                                    \
+_Pragma("unroll")                                                                                                        \
+      for (int c = 0; c < DU; ++c) u0[c] = u[c];                                                                      \
+    } else {                                                                                                          \
+      real d[DS];                                                                                                     \
+                                                                                                                      \
+                                                                                                                      \
+      Sys::template rhs<real, true>(pre, x, up, d);                                                                   \
+_Pragma("unroll")                                                                                                        \
+      for (int c = 0; c < DS; ++c) {                                                                                  \
+        x[c] = fma_r(h, d[c], x[c]);                                                                                  \
+        y[c] = x[c];                                                                                                  \
+      }                                                                                                               \
+    }                                                                                                                 \
+    real chi[NCHI];                                                                                                   \
+    make_chi<DS, DU, TGT, real>(P, y, u, chi);                                                                        \
+    if (G1 && (MODE_C == RCG_MODE_MPC || kk < N - 1)) {                                                               \
+_Pragma("unroll")                                                                                                        \
+      for (int i = 0; i < NCHI; ++i)                                                                                  \
+        if (!((ZW >> i) & 1u)) S[G1 ? i : 0] = fma_r(chi[i], chi[i], S[G1 ? i : 0]);                                  \
+    } else if (G1) {                                                                                                  \
+      J += critic_with<DS, DU, real>(chi, y, u, wget, cs);                                                            \
+    } else if (mode == RCG_MODE_MPC) {                                                                                \
+      J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);                                                           \
+    } else if (mode == RCG_MODE_RQL) {                                                                                \
+      if (kk < N - 1)                                                                                                 \
+        J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);                                                         \
+      else                                                                                                            \
+        J += critic_with<DS, DU, real>(chi, y, u, wget, cs);                                                          \
+    } else if (SUMF) {                                                                                                \
+      critic_phi_accum<DS, DU, real>(chi, y, u, Phi, CS_C);                                                           \
+    } else {                                                                                                          \
+      J += critic_with<DS, DU, real>(chi, y, u, wget, cs);                                                            \
+    }                                                                                                                 \
+    if (!G1) gk *= P.gamma;                                                                                           \
+_Pragma("unroll")                                                                                                        \
+    for (int c = 0; c < DU; ++c) up[c] = u[c];                                                                        \
+                                                                                                                      \
+  /* end of RCG_ROLLOUT_STEP */
+  if constexpr (NC > 0) {
 #pragma unroll
-    for (int c = 0; c < DU; ++c) u[c] = STREAM ? urow[kk * DU + c] : ugen[c];
-    if (kk == 0) {
-#pragma unroll
-      for (int c = 0; c < DU; ++c) u0[c] = u[c];
-    } else {
-      real d[DS];
-      // unclipped, as sys_rhs([], state, u[k-1]); f32: hardware v_sin/v_cos behind the exact reduction, as in
-      // k_actor_dma (3.7e-7 max abs error, 7 VALU ops instead of ~25: the generated-candidate regime is VALU-bound)
-      Sys::template rhs<real, true>(pre, x, up, d);
-#pragma unroll
-      for (int c = 0; c < DS; ++c) {
-        x[c] = fma_r(h, d[c], x[c]);
-        y[c] = x[c];  // sys_out is the identity
-      }
+    for (int kk = 0; kk < NC; ++kk) {
+      RCG_ROLLOUT_STEP
     }
-    real chi[NCHI];
-    make_chi<DS, DU, TGT, real>(P, y, u, chi);
-    if (G1 && (MODE_C == RCG_MODE_MPC || kk < N - 1)) {
-#pragma unroll
-      for (int i = 0; i < NCHI; ++i)
-        if (!((ZW >> i) & 1u)) S[G1 ? i : 0] = fma_r(chi[i], chi[i], S[G1 ? i : 0]);  // (ZW: weight exactly zero)
-    } else if (G1) {  // RQL, last step: Q_w(y_{N-1}, u_{N-1}) (controllers.py:1310)
-      J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
-    } else if (mode == RCG_MODE_MPC) {
-      J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
-    } else if (mode == RCG_MODE_RQL) {
-      if (kk < N - 1)
-        J = fma_r(gk, stage_with<NCHI, real>(P, chi, sk), J);
-      else
-        J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
-    } else if (SUMF) {  // SQL, compile-time structure
-      critic_phi_accum<DS, DU, real>(chi, y, u, Phi, CS_C);
-    } else {  // SQL
-      J += critic_with<DS, DU, real>(chi, y, u, wget, cs);
+  } else {
+    for (int kk = 0; kk < N; ++kk) {
+      RCG_ROLLOUT_STEP
     }
-    if (!G1) gk *= P.gamma;
-#pragma unroll
-    for (int c = 0; c < DU; ++c) up[c] = u[c];
   }
+#undef RCG_ROLLOUT_STEP
   if (G1) {
 #pragma unroll
     for (int i = 0; i < NCHI; ++i)
@@ -411,22 +432,23 @@ __device__ __forceinline__ real rollout_cost(const KParams<real>& P, const typen
 }
 
 // Once per tile: pick the specialisation of rollout_cost for this handle's (mode, stage structure, critic structure).
-template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, typename WGet>
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, int NC = 0, typename WGet>
 __device__ __forceinline__ real rollout_dispatch(const KParams<real>& P, const typename Sys::template Pre<real>& pre,
                                                  int N, const real* xs, const real* y0, const real* urow,
                                                  const real* ugen, WGet wget, real* u0) {
 #define RCG_ROLL(M, S, C) rollout_cost<Sys, real, TGT, STREAM, M, S, C>(P, pre, N, xs, y0, urow, ugen, wget, u0)
-  if (!GENERIC) {  // MPC, quadratic, diagonal R1
+  if constexpr (!GENERIC) {  // MPC, quadratic, diagonal R1
     if (P.gamma == (real)1) {  // wave-uniform
       // the preset's zero stage weights (Sys::ZW_PRESET) are zero in this handle too: their terms - exact zeros - are
       // not computed (the generated-candidate regime is bound by instruction issue; streamed rollouts hide them anyway)
-      if (!STREAM && Sys::ZW_PRESET != 0u && (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET)
-        return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, true, Sys::ZW_PRESET>(P, pre, N, xs, y0, urow, ugen,
-                                                                                             wget, u0);
-      return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, true>(P, pre, N, xs, y0, urow, ugen, wget, u0);
+      // (NC > 0: k_actor_search's register rows - generated inside the bounds, so the skipped inputs are finite there too)
+      if ((!STREAM || NC > 0) && Sys::ZW_PRESET != 0u && (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET)
+        return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, true, Sys::ZW_PRESET, NC>(P, pre, N, xs, y0, urow,
+                                                                                                 ugen, wget, u0);
+      return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, true, 0u, NC>(P, pre, N, xs, y0, urow, ugen, wget, u0);
     }
-    return RCG_ROLL(RCG_MODE_MPC, 0, -1);
-  }
+    return rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_MPC, 0, -1, false, 0u, NC>(P, pre, N, xs, y0, urow, ugen, wget, u0);
+  } else {
   if (P.mode == RCG_MODE_MPC) return RCG_ROLL(RCG_MODE_MPC, -1, -1);
   if (P.mode == RCG_MODE_RQL && P.stage_kind == 0) {
 #define RCG_ROLL_G1(C) rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_RQL, 0, C, true>(P, pre, N, xs, y0, urow, ugen, wget, u0)
@@ -455,6 +477,7 @@ __device__ __forceinline__ real rollout_dispatch(const KParams<real>& P, const t
     }
   }
   return RCG_ROLL(-1, -1, -1);  // RQL with a full-matrix / biquadratic stage cost
+  }
 #undef RCG_ROLL
 }
 

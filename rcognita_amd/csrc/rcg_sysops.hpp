@@ -659,27 +659,35 @@ int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, const vo
     A.seed = c.seed;
     A.env_id_base = c.env_id_base;
     const int R = c.n_actor * Sys::DU;
+    const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
+    const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
+    // register rows (compile-time horizon): MPC with a diagonal stage cost, the preset's target setting, Nactor 3 / 5 / 10
+    const int nc = (!generic && tgt == Sys::TGT && (c.n_actor == 3 || c.n_actor == 5 || c.n_actor == 10)) ? c.n_actor : 0;
     int wpb = 4;  // waves (= envs) per workgroup
-    const size_t lds_wave = (size_t)search_lds_reals(R) * sizeof(real);
+    const size_t lds_wave = (size_t)search_lds_reals(R, nc > 0) * sizeof(real);
     while (wpb > 1 && lds_wave * wpb > (size_t)64 * 1024) wpb >>= 1;
     const size_t lds = lds_wave * wpb;
     const dim3 grid(blocks_for(c.batch, wpb)), block(64 * wpb);
-    const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
-    const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
     if (tick && sim_first) {
       const int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
       if (rc) return rc;
     }
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
-    if (generic && tgt)
-      RCG_LAUNCH(h, (k_actor_search<Sys, real, true, true>), grid, block, lds, A, P);
+    if (nc == 3)
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, Sys::TGT, 3>), grid, block, lds, A, P);
+    else if (nc == 5)
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, Sys::TGT, 5>), grid, block, lds, A, P);
+    else if (nc == 10)
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, Sys::TGT, 10>), grid, block, lds, A, P);
+    else if (generic && tgt)
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, true, true, 0>), grid, block, lds, A, P);
     else if (generic)
-      RCG_LAUNCH(h, (k_actor_search<Sys, real, true, false>), grid, block, lds, A, P);
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, true, false, 0>), grid, block, lds, A, P);
     else if (tgt)
-      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, true>), grid, block, lds, A, P);
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, true, 0>), grid, block, lds, A, P);
     else
-      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, false>), grid, block, lds, A, P);
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_SEARCH, (generic ? 1 : 0) | (tgt ? 2 : 0), 1);
+      RCG_LAUNCH(h, (k_actor_search<Sys, real, false, false, 0>), grid, block, lds, A, P);
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_SEARCH, (generic ? 1 : 0) | (tgt ? 2 : 0) | (nc > 0 ? 4 : 0), 1);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });

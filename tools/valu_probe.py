@@ -57,6 +57,32 @@ def main():
         print(json.dumps({"launches_each": n, "units_per_launch": units}))
         return
 
+    if part == "search":  # round 5: the device-side candidate search and the stand-alone producer, alone
+        import time
+
+        B, K = 65536, 256
+        e = Engine(preset_engine_config("3wrobot", B, Nactor=10))
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.set_state(states(rng, "3wrobot", B))
+        cbuf = torch.empty((B, K, 10, 2), device="cuda", dtype=torch.float32)
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        out = {}
+        for rounds in (1, 4):
+            out[f"search_tick_rounds_{rounds}_ms"] = timed(lambda: e.control_tick_search(K=K, rounds=rounds, warm_start=True), n * 4)
+        out["cand_sample_ms"] = timed(lambda: e.candidates_sample(K, round=1, out=cbuf), n * 4)
+        units["k_actor_search_3wrobot_N10_K256_f32"] = {"evals": B * K, "envs": B}
+        print(json.dumps({"launches_each": n * 4 + 1, "units_per_launch": units, "timings": out}))
+        return
+
     if part in ("c3rql", "c3sql"):  # configs[2] generated, ONE critic mode (RQL and SQL share a kernel instance)
         mode = part[2:].upper()
         B3, K = 131072, 256
