@@ -76,6 +76,9 @@ def parse(argv=None):
     p.add_argument("--profile-stride", type=int, default=-1,
                    help="time every n-th launch of the dominant kernel in the timed region (events carried by the "
                         "dispatch); -1 = chosen so that 20 .. 40 launches are sampled, 0 = none")
+    p.add_argument("--tick-parts", type=int, default=0, choices=(0, 1, 2),
+                   help="rcg_set_tick_parts of every handle: 0 = the library's rule (an eligible RQL / SQL tick of >= 65 536 envs "
+                        "runs as two halves on two internal streams), 1 = never, 2 = whenever eligible")
     p.add_argument("--parts", type=int, default=None,
                    help="handles per GPU, each on a stream of its own (rcognita_amd.pool.MixedPool(parts=...)): the critic fit "
                         "of one part runs under the actor kernel of another.  Default: 2 for --config C3, else 1")
@@ -581,8 +584,14 @@ def main(argv=None):
         tick = lambda: eng.control_tick(cand, K=K)
     du, ds = (1, 2) if args.config == "C3" else (2, 5)
 
+    for e in engines:
+        e.set_tick_parts(args.tick_parts)
+
     def record_all():
-        """One timing event per engine stream, recorded now (in-stream, no host wait)."""
+        """One timing event per engine stream, recorded now (in-stream, no host wait).  A handle that splits its tick over two
+        internal streams first orders its own stream behind them (rcg_join: two event waits, no host wait)."""
+        for e in engines:
+            e.join()
         evs = []
         for st in streams:
             ev = torch.cuda.Event(enable_timing=True)
@@ -762,6 +771,16 @@ def main(argv=None):
         actor_avg_s = min(actor_avg_s * len(engines), step_ms_compute * 1e-3)
     achieved = bytes_launch / actor_avg_s if actor_avg_s > 0 else 0.0
     per_launch = None
+    split_inside = bool(launch_info and launch_info[0].get("split"))  # the handle ran its tick as two halves (rcg_set_tick_parts)
+    if split_inside and args.config != "C5" and len(engines) == 1:
+        # two half-batch launches per tick on two internal streams, overlapping each other and the other half's fit: as with
+        # --parts handles, the roofline is taken at tick level
+        per_launch = {"algorithmic_bytes": bytes_launch / 2, "avg_launch_ms": actor_avg_s * 1e3,
+                      "frac_of_one_overlapped_launch": (bytes_launch / 2) / actor_avg_s / HBM_PEAK if actor_avg_s > 0 else None,
+                      "note": "the tick runs as two half-batch launches on two internal streams (rcg_set_tick_parts): they "
+                              "overlap, so a launch's own duration is not a statement about the memory system"}
+        actor_avg_s = step_ms_compute * 1e-3
+        achieved = bytes_launch / actor_avg_s
     if args.config != "C5" and len(engines) > 1:
         # --parts handles on streams of their own: their launches OVERLAP on the GPU, so a launch's own duration (what the
         # dispatch stamps and a rocprofv3 trace show) is stretched by its neighbour and bytes / duration of ONE launch says
@@ -792,7 +811,7 @@ def main(argv=None):
                     break
         except Exception:
             traffic = None
-    if traffic is not None and per_launch is not None:
+    if traffic is not None and per_launch is not None and len(engines) > 1:
         traffic *= len(engines)  # tick level, as `achieved`
     kinfo = launch_info[0]
     width = "float32 storage and arithmetic (SURVEY 8a-1 / 8d; the reference computes in float64: value_f64 / roofline_f64)" \

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 116 /* 115 + rcg_sim_step_h: one simulation step of a caller-given length (round 5) */
+#define RCG_VERSION 117 /* 115 + rcg_sim_step_h, rcg_set_tick_parts, rcg_join (round 5) */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -276,6 +276,17 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
  * caller's FFI (a Python caller needs ~12 us per call, and a GPU that idles between short ticks clocks down).  Either way
  * every field ends as T single calls leave it, bit for bit; stops at the first error. */
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);
+/* A tick in two halves.  An RQL / SQL handle whose decision streams a caller's tensor through k_actor_dma (no disturbance
+ * model, 1 .. 8 TD rows) runs rcg_control_tick for the envs [0, B / 2) and [B / 2, B) on two internal streams: the critic fit of
+ * one half (bound by the latency of its longest active-set walk, 63-76 us at configs[2] whatever the batch) then runs under the
+ * streaming kernel of the other, tick after tick - what two handles on two streams did from outside (the controller
+ * loop being replaced, controllers.py:1458-1477, is per env: the halves never meet).  Every field ends bit-identical to the
+ * unsplit tick.  parts: 0 = automatic (split from 65 536 envs), 1 = never, 2 = whenever the tick is eligible.  The handle's own
+ * stream rejoins the halves as soon as any other entry point is called (reads, writes, rcg_synchronize, rcg_release_stream ...);
+ * rcg_join does only that - for a caller that orders its own stream work (an event, a kernel reading rcg_field_ptr memory)
+ * behind the handle's without a host wait.  rcg_last_launch reports a half-batch launch with bit 12 (4096) of `variant`. */
+int rcg_set_tick_parts(rcg_handle* h, int32_t parts);
+int rcg_join(rcg_handle* h);
 /* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398) for every mode
  * (MPC / RQL / SQL, controllers.py:1304-1326; RQL / SQL read the handle's W_CRITIC), stage-cost structure (diagonal or
  * full R1, biquadratic) and critic structure: `iters` iterations of projected limited-memory quasi-Newton descent -
@@ -400,7 +411,8 @@ typedef enum rcg_kernel_id {
 /* variant: k_actor_dma, k_actor_dma_packed: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL; k_actor / k_ticks: bit 0 generic
  * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates, bit 3 the hand-packed generated-grid instance; k_critic_fit: critic_struct + 16 * (rows
  * the instance is compiled for) + 256 * do_sim + 512 * do_fit + 1024 * (the four-lanes-per-env form, structures with >= 20 weights); others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
- * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Each out pointer may be NULL. */
+ * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Bit 12 (4096) of variant: the launch served one half
+ * of a split tick (rcg_set_tick_parts).  Each out pointer may be NULL. */
 int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave);
 /* "k_actor_dma", ... ; "?" for an unknown id.  Never NULL. */
 const char* rcg_kernel_name(int32_t kernel_id);

@@ -146,9 +146,10 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   const int K = A.K;
   const int T = (K + TROWS - 1) / TROWS;  // tiles per env
   const int rem_rows = K % TROWS;         // rows of an env's LAST tile (0: it is full); K % 4 == 0: whole 16-byte pieces
-  const long env0 = wave * A.gpw;
-  if (env0 >= B) return;
-  const long env1 = env0 + A.gpw < B ? env0 + A.gpw : B;
+  const long env_hi = A.env_hi > 0 ? A.env_hi : B;  // (a sub-range of the batch when the handle splits its tick)
+  const long env0 = A.env_lo + wave * A.gpw;
+  if (env0 >= env_hi) return;
+  const long env1 = env0 + A.gpw < env_hi ? env0 + A.gpw : env_hi;
   // 32-bit on purpose: a 64-bit loop compare has no scalar form, and its VGPR temporary once landed in the registers
   // of the in-flight env-state prefetch (a WAW hazard the compiler resolves with s_waitcnt vmcnt(0))
   const int n_tiles = (int)(env1 - env0) * T;

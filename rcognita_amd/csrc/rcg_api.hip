@@ -53,10 +53,28 @@ static int prof_drain(rcg_handle* h) {
 
 // Every entry point that touches HIP runs on the handle's device whatever the calling thread's current device is
 // (two handles on two GPUs in one process, or a handle driven from another thread), and puts the previous one back.
+// A split tick's halves (rcg_handle.hpp: split_stream) rejoin the handle's own stream: everything queued on the two internal
+// streams so far is ordered before whatever the handle's stream is given next.  Non-blocking for the host.
+static void join_split(rcg_handle* h) {
+  if (!h || !h->split_pending) return;
+  for (int p = 0; p < 2; ++p) {
+    (void)hipEventRecord(h->split_join[p], h->split_stream[p]);
+    (void)hipStreamWaitEvent(h->stream, h->split_join[p], 0);
+  }
+  h->split_pending = false;
+}
+
+struct NoJoin {};
 struct DeviceGuard {
   int prev = -1;
   bool switched = false;
-  explicit DeviceGuard(const rcg_handle* h) {
+  explicit DeviceGuard(const rcg_handle* h) {  // every entry point but the tick itself: the halves of a split tick rejoin first
+    if (h) {
+      enter(h->cfg.device);
+      join_split(const_cast<rcg_handle*>(h));
+    }
+  }
+  DeviceGuard(const rcg_handle* h, NoJoin) {
     if (h) enter(h->cfg.device);
   }
   explicit DeviceGuard(int device) { enter(device); }
@@ -206,6 +224,12 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->esz = cfg->dtype == RCG_F64 ? 8 : 4;
   h->stream = nullptr;
   h->own_stream = nullptr;
+  h->tick_parts = 0;
+  h->split_stream[0] = h->split_stream[1] = nullptr;
+  h->split_fork = h->split_join[0] = h->split_join[1] = nullptr;
+  h->split_pending = false;
+  h->sub_lo = h->sub_hi = 0;
+  h->probe = 0;
   h->d_summary = nullptr;
   h->d_const = nullptr;
   h->prof_mask = 0;
@@ -332,6 +356,14 @@ int rcg_destroy(rcg_handle* h) {
   for (int i = 0; i < RCG_FIELD_COUNT_; ++i)
     if (h->f[i]) (void)hipFree(h->f[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  for (int p = 0; p < 2; ++p) {
+    if (h->split_stream[p]) {
+      (void)hipStreamSynchronize(h->split_stream[p]);
+      (void)hipStreamDestroy(h->split_stream[p]);
+    }
+    if (h->split_join[p]) (void)hipEventDestroy(h->split_join[p]);
+  }
+  if (h->split_fork) (void)hipEventDestroy(h->split_fork);
   if (h->d_summary) (void)hipFree(h->d_summary);
   if (h->d_const) (void)hipFree(h->d_const);
   for (auto& p : h->ev_pending) {
@@ -626,11 +658,77 @@ static int tick_critic_phase(rcg_handle* h, const char* who) {
   return h->sys->critic_update(h, h->cfg.substeps_per_tick, 1, do_fit ? 1 : 0);
 }
 
-int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
+// Is this tick one the handle runs as two halves on two internal streams?  RQL / SQL (the fit is what the split hides), a
+// caller's tensor whose decision goes to k_actor_dma, the fused [env step + push + fit] launch (no disturbance model, 1 .. 8 TD
+// rows), and enough envs for two launches to be worth it (rcg_set_tick_parts).
+static bool tick_splits(rcg_handle* h, const void* cand, int32_t K) {
+  if (h->tick_parts == 1 || h->cfg.mode == RCG_MODE_MPC || !cand) return false;
+  if (h->tick_parts == 0 && h->cfg.batch < kSplitMinBatch) return false;
+  const int m = h->cfg.n_critic - 1;
+  if ((h->cfg.flags & RCG_FLAG_DISTURB) || m < 1 || m > kFitMaxRows || h->cfg.batch < 2048) return false;
+  h->probe = 1;
+  const int rc = h->sys->actor(h, "rcg_control_tick", cand, K, nullptr, nullptr, nullptr, nullptr, h->f[RCG_FIELD_ACTION],
+                               h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, false);
+  const bool yes = rc == RCG_OK && h->probe == 3;
+  h->probe = 0;
+  return yes;
+}
+
+static int split_streams(rcg_handle* h) {
+  for (int p = 0; p < 2; ++p) {
+    if (!h->split_stream[p]) HIPCHK(h, hipStreamCreateWithFlags(&h->split_stream[p], hipStreamNonBlocking));
+    if (!h->split_join[p]) HIPCHK(h, hipEventCreateWithFlags(&h->split_join[p], hipEventDisableTiming));
+  }
+  if (!h->split_fork) HIPCHK(h, hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+  return RCG_OK;
+}
+
+int rcg_set_tick_parts(rcg_handle* h, int32_t parts) {
   DeviceGuard dev_guard(h);
   if (!h) return RCG_ERR_BAD_ARG;
+  if (parts < 0 || parts > 2) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_tick_parts: parts must be 0 (auto), 1 or 2");
+  h->tick_parts = parts;
+  return RCG_OK;
+}
+
+int rcg_join(rcg_handle* h) {
+  DeviceGuard dev_guard(h);  // (the guard joins)
+  return h ? RCG_OK : RCG_ERR_BAD_ARG;
+}
+
+int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
+  DeviceGuard dev_guard(h, NoJoin{});
+  if (!h) return RCG_ERR_BAD_ARG;
   int rc = check_candidates(h, "rcg_control_tick", cand, K);
-  if (rc) return rc;
+  if (rc) {
+    join_split(h);
+    return rc;
+  }
+  if (tick_splits(h, cand, K)) {
+    if (h->cfg.n_critic - 1 > kFitMaxRows) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick: too many TD rows");
+    rc = split_streams(h);
+    if (rc) return rc;
+    // fork: whatever the handle's stream holds (the caller's candidates, rcg_wait_stream, a set_field) comes first
+    HIPCHK(h, hipEventRecord(h->split_fork, h->stream));
+    for (int p = 0; p < 2; ++p) HIPCHK(h, hipStreamWaitEvent(h->split_stream[p], h->split_fork, 0));
+    hipStream_t const own = h->stream;
+    const int half = (h->cfg.batch / 2) & ~1023;
+    for (int p = 0; p < 2 && rc == RCG_OK; ++p) {
+      h->stream = h->split_stream[p];
+      h->sub_lo = p ? half : 0;
+      h->sub_hi = p ? h->cfg.batch : half;
+      rc = tick_critic_phase(h, "rcg_control_tick");
+      if (rc == RCG_OK)
+        rc = h->sys->actor(h, "rcg_control_tick", cand, K, nullptr, nullptr, nullptr, nullptr, h->f[RCG_FIELD_ACTION],
+                           h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], true, false);
+    }
+    h->stream = own;
+    h->sub_lo = h->sub_hi = 0;
+    h->split_pending = true;
+    if (rc == RCG_OK) h->tick_count += 1;
+    return rc;
+  }
+  join_split(h);
   bool sim_first = true;  // MPC: env step, then the decision, both issued by the actor launcher
   if (h->cfg.mode != RCG_MODE_MPC) {  // RQL/SQL: the critic bookkeeping sits between the two
     rc = tick_critic_phase(h, "rcg_control_tick");

@@ -88,6 +88,7 @@ struct FitArgs {
   SimArgs<real> sim;      // do_sim
   const real* state;      // [ds][B] do_push: the observation to push (= sim.state)
   const real* action;     // [du][B] do_push: the held action (action_curr)
+  int env_lo, env_hi;     // the envs [env_lo, env_hi) this launch serves (env_hi == 0: the whole batch)
 };
 
 // The part of an env's critic update that precedes the solver: [env step] -> [push] -> TD stack (A, b) and the box.  `store`:
@@ -454,8 +455,8 @@ __device__ __forceinline__ void critic_update_env(const FitArgs<real>& F, const 
 
 template <typename Sys, typename real, int CS, int MAXM>
 __global__ __launch_bounds__(64) void k_critic_fit(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
-  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= P.B) return;
+  const long b = F.env_lo + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (F.env_hi > 0 ? (long)F.env_hi : P.B)) return;
   critic_update_env<Sys, real, CS, MAXM>(F, P, Pr, b);
 }
 

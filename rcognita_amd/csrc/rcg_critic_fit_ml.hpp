@@ -300,8 +300,8 @@ __device__ __forceinline__ void critic_update_env_ml(const FitArgs<real>& F, con
 // one quad per env: blocks of 64 threads = 16 envs
 template <typename Sys, typename real, int CS, int MAXM>
 __global__ __launch_bounds__(64) void k_critic_fit_ml(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
-  const long b = (long)blockIdx.x * (blockDim.x / FIT_L) + (threadIdx.x / FIT_L);
-  if (b >= P.B) return;  // (whole quads leave together: the DPP exchanges below stay inside a quad)
+  const long b = F.env_lo + (long)blockIdx.x * (blockDim.x / FIT_L) + (threadIdx.x / FIT_L);
+  if (b >= (F.env_hi > 0 ? (long)F.env_hi : P.B)) return;  // (whole quads leave together: the DPP exchanges below stay inside a quad)
   critic_update_env_ml<Sys, real, CS, MAXM>(F, P, Pr, b, (int)(threadIdx.x & (FIT_L - 1)));
 }
 

@@ -49,6 +49,17 @@ struct rcg_handle {
   bool scope_due;           // a due ProfScope is alive (dev build: a second launch inside it aborts)
   hipEvent_t order_ev;      // rcg_wait_stream's event (created on first use)
   hipEvent_t release_ev;    // rcg_release_stream's event (created on first use)
+  // A tick in two halves (round 5; rcg_control_tick of an RQL / SQL handle with a caller's tensor on k_actor_dma): the envs
+  // [0, half) and [half, B) run their [env step + push + fit] -> decision on two internal streams, so that - exactly as with
+  // two handles on two streams, MixedPool(parts=2) - the latency-bound fit of one half runs under the streaming kernel of the
+  // other, tick after tick (the halves never meet: envs are independent).  The handle's own stream rejoins them the next
+  // time anything else is asked of the handle (join_split, called by DeviceGuard).
+  int tick_parts;              // rcg_set_tick_parts: 0 auto (2 from kSplitMinBatch envs), 1 never, 2 whenever the tick is eligible
+  hipStream_t split_stream[2];  // created on first use
+  hipEvent_t split_fork, split_join[2];
+  bool split_pending;          // work of a split tick is queued on split_stream[] and not yet joined
+  int sub_lo, sub_hi;          // the launchers' current sub-range of the batch (sub_hi == 0: all envs)
+  int probe;                   // launch_actor: 1 = only report whether this (cand, K) goes to k_actor_dma -> probe = 2 / 3 (no / yes)
   // rcg_last_launch: which kernel served the last launch of each kind
   struct LastLaunch {
     int32_t kernel_id, variant, envs_per_wave;
@@ -56,9 +67,11 @@ struct rcg_handle {
 };
 static constexpr size_t kProfMaxSamples = 65536;
 
+static constexpr int kSplitMinBatch = 65536;   // envs from which an eligible tick is split by default
+static constexpr int kVariantSplitBit = 4096;  // rcg_last_launch: the launch served one half of a split tick
 static inline void note_launch(rcg_handle* h, int kind, int kernel_id, int variant, int envs_per_wave) {
   h->last[kind].kernel_id = kernel_id;
-  h->last[kind].variant = variant;
+  h->last[kind].variant = variant | (h->sub_hi > 0 ? kVariantSplitBit : 0);
   h->last[kind].envs_per_wave = envs_per_wave;
 }
 

@@ -258,6 +258,8 @@ struct ActorArgs {
   int jwave;              // k_actor_dma, J output: stage the costs of all envs of the wave in LDS (else env by env)
   int no_multi;           // development (env RCG_NO_GEN_MULTI): generated tiles one at a time (A/B of rollout_mpc_gen_multi)
   int dbg;                // -DRCG_DEV builds only (env RCG_DBG): bits skip parts of k_actor_dma for timing
+  int env_lo, env_hi;     // k_actor_dma: the envs [env_lo, env_hi) of the batch this launch serves (env_hi == 0: all of them) -
+                          // a handle that splits its tick into halves on two streams (rcg_control_tick, RQL / SQL)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));  // one 16-B global_load_dwordx4 / ds_write_b128

@@ -165,7 +165,8 @@ constexpr int kFitLanesMinDc = 20;
 template <typename Sys, typename real, int CS>
 static bool launch_fit3(rcg_handle* h, const FitArgs<real>& F, bool force_ml) {
   constexpr int DC = CriticDim<CS, Sys::DS, Sys::DU>::value;
-  const dim3 block(64), grid(blocks_for(h->cfg.batch, 64)), grid_ml(blocks_for(h->cfg.batch, 64 / FIT_L));
+  const long n_env = h->sub_hi > 0 ? h->sub_hi - h->sub_lo : h->cfg.batch;
+  const dim3 block(64), grid(blocks_for(n_env, 64)), grid_ml(blocks_for(n_env, 64 / FIT_L));
   if constexpr (DC >= kFitLanesMinDc) {
     RCG_LAUNCH(h, (k_critic_fit_ml<Sys, real, CS, 3>), grid_ml, block, 0, F, h->p64, params<real>(h));
     return true;
@@ -206,7 +207,9 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
     F.sim.accum = (real*)h->f[RCG_FIELD_ACCUM];
     F.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
     F.sim.n_sub = n_substeps;
-    const dim3 grid(blocks_for(h->cfg.batch, 64)), block(64);
+    F.env_lo = h->sub_lo;  // (a half of a split tick; 0, 0: the whole batch)
+    F.env_hi = h->sub_hi;
+    const dim3 grid(blocks_for(h->sub_hi > 0 ? h->sub_hi - h->sub_lo : h->cfg.batch, 64)), block(64);
     bool fit_ml = false;
 #ifdef RCG_DEV
     const bool force_ml = fit_lanes_knob() == FIT_L;  // RCG_FIT_LANES=4: the four-lane form for every structure (experiments)
@@ -404,6 +407,12 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
                        P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain && !knobs.no_pack;
   // rcg_control_tick with the generated grid in the regime of the hand-packed rollout: env step and decision in ONE launch
   // (k_ticks_pk with T = 1 - what rcg_control_ticks runs, so the two entry points cannot differ by a bit)
+  if (h->probe == 1) {  // rcg_control_tick asking, before it launches anything, whether this tick's decision runs on k_actor_dma
+    h->probe = (dma_ok && !pack_ok) ? 3 : 2;
+    return RCG_OK;
+  }
+  if (h->sub_hi > 0 && !(dma_ok && !pack_ok))
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "%s: a split tick needs the k_actor_dma shape", who);
   if constexpr (std::is_same<real, float>::value && GenPk<Sys>::supported && GenPk<Sys>::fuse_tick) {
     if (tick && sim_first && !cand && !generic && !tgt && c.gamma == 1.0 && Sys::ZW_PRESET != 0u &&
         (P.zero_w & Sys::ZW_PRESET) == Sys::ZW_PRESET && K >= 256 && A.n_tiles % 4 == 0 && A.grid_g > 0 &&
@@ -456,13 +465,16 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     //  * rounds: the grid must be several times the 512 resident blocks so that the CUs stay balanced (single-round
     //    grids that do not divide evenly over 256 CUs lost 10 %: gpw = 20, 28, 48) - gpw is the largest power of
     //    two <= 16 that still leaves >= 8192 waves.
+    const long Bn = h->sub_hi > 0 ? h->sub_hi - h->sub_lo : B;  // envs of this launch (a half of a split tick)
     long gpw = 1;
-    while (gpw < 16 && B / (gpw * 2) >= 8192) gpw *= 2;
+    while (gpw < 16 && Bn / (gpw * 2) >= 8192) gpw *= 2;
     if (knobs.gpw > 0) gpw = knobs.gpw;
     gpw = gpw < 1 ? 1 : (gpw > 64 ? 64 : gpw);
     ActorArgs<real> Ad = A;
     Ad.gpw = (int)gpw;
-    const long pw = (B + gpw - 1) / gpw;
+    Ad.env_lo = h->sub_lo;
+    Ad.env_hi = h->sub_hi;
+    const long pw = (Bn + gpw - 1) / gpw;
     const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
     // blocks per CU: 2 for rows of >= 80 bytes (a block keeps R KiB in flight), 4 for shorter rows, which need more
     // waves to keep enough bytes on the wire (measured R = 6 ... 32 floats: 2 vs 4 differ by 1-3 % either side of

@@ -572,6 +572,15 @@ class Engine:
         return Jc.to_host()
 
     # ------------------------------------------------------------------ stateful steps
+    def set_tick_parts(self, parts):
+        """0 = automatic (an eligible RQL / SQL tick is split into two halves on two internal streams from 65 536 envs),
+        1 = never, 2 = whenever eligible (rcg_set_tick_parts)."""
+        N.check(N.lib().rcg_set_tick_parts(self._h, int(parts)), self._h)
+
+    def join(self):
+        """Order the handle's stream behind the halves of a split tick, without a host wait (rcg_join)."""
+        N.check(N.lib().rcg_join(self._h), self._h)
+
     def sim_step(self, n_substeps=1, step=None):
         """``n_substeps`` RK4 substeps of the handle's ``dt_sim``; with ``step``: ONE step of that length, cut into
         ``n_substeps`` substeps (rcg_sim_step_h)."""
@@ -796,8 +805,8 @@ class Engine:
 
     def last_launch(self, kind=N.KERNEL_ACTOR):
         """Which kernel served the last launch of a kind (rcg_last_launch):
-        ``{"kernel": "k_actor_dma", "kernel_id": 2, "variant": 0, "envs_per_wave": 8}``."""
+        ``{"kernel": "k_actor_dma", "kernel_id": 2, "variant": 0, "envs_per_wave": 8, "split": False}``."""
         kid, var, epw = C.c_int32(), C.c_int32(), C.c_int32()
         N.check(N.lib().rcg_last_launch(self._h, int(kind), C.byref(kid), C.byref(var), C.byref(epw)), self._h)
-        return {"kernel": N.lib().rcg_kernel_name(kid.value).decode(), "kernel_id": kid.value, "variant": var.value,
-                "envs_per_wave": epw.value}
+        return {"kernel": N.lib().rcg_kernel_name(kid.value).decode(), "kernel_id": kid.value, "variant": var.value & ~4096,
+                "envs_per_wave": epw.value, "split": bool(var.value & 4096)}  # split: one half of a tick in two halves

@@ -1,0 +1,84 @@
+"""A tick in two halves (rcg_set_tick_parts, include/rcg.h): an RQL / SQL handle whose decision streams a caller's tensor
+through k_actor_dma runs rcg_control_tick for the two halves of its batch on two internal streams - the fit of one half under
+the streaming kernel of the other - and every field must end bit-identical to the unsplit tick.  The loop being replaced is
+per env (controllers.py:1458-1477), so the halves never meet.  ``gpu`` marked."""
+import numpy as np
+import pytest
+
+from oracle import rcg_oracle as O
+from tests.helpers import both, rand_actions, rand_states
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("FIELD_STATE", "FIELD_STATE_PREV", "FIELD_ACTION", "FIELD_ACCUM", "FIELD_BEST_J", "FIELD_BEST_IDX", "FIELD_STEP_IDX",
+          "FIELD_W_CRITIC", "FIELD_W_PREV", "FIELD_OBS_BUF", "FIELD_ACT_BUF", "FIELD_STATUS")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name,mode,cs,B,K,N_", [
+    ("2tank", "RQL", "quadratic", 5000, 64, 20),      # configs[2]'s controller; a batch that is no multiple of anything
+    ("2tank", "SQL", "quad-lin", 4096, 48, 10),        # one ragged tile per env
+    ("3wrobot", "RQL", "quad-nomix", 3072, 64, 5),
+    ("3wrobotNI", "SQL", "quad-mix", 2560, 128, 3),
+])
+def test_split_tick_is_bit_identical_to_the_unsplit_tick(name, mode, cs, B, K, N_, dtype):
+    from rcognita_amd import _native as N
+
+    kw = dict(mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs], n_critic=4, buffer_size=8, n_actor=N_)
+    rng = np.random.default_rng(5)
+    x0 = rand_states(rng, name, B)
+    engs = []
+    for parts in (1, 2):
+        eng, _ = both(name, B, dtype, **kw)
+        eng.set_tick_parts(parts)
+        eng.set_state(x0)
+        engs.append(eng)
+    one, two = engs
+    T = 7
+    for t in range(T):
+        cand = rand_actions(rng, name, (B, K, N_)).astype(one.real)
+        for e in engs:
+            e.control_tick(cand)
+        if t == 0:  # which kernels ran, as the library reports them
+            for e, split in ((one, False), (two, True)):
+                for kind in (N.KERNEL_ACTOR, N.KERNEL_CRITIC):
+                    ll = e.last_launch(kind)
+                    assert ll["split"] == split, (kind, ll)
+                assert e.last_launch(N.KERNEL_ACTOR)["kernel"] == "k_actor_dma"
+        if t in (2, 5):  # a read between two split ticks joins the halves and must see both of them finished
+            np.testing.assert_array_equal(two.get_field(N.FIELD_STEP_IDX), np.full(B, t + 1, np.int32))
+    for f in FIELDS:
+        np.testing.assert_array_equal(two.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+    assert np.array_equal(two.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
+    # T ticks issued by ONE call go through the same path
+    for e in engs:
+        e.control_tick(cand, T=3)
+    for f in FIELDS:
+        np.testing.assert_array_equal(two.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+    # an episode reset between split ticks (it must wait for the halves), then on
+    for e in engs:
+        e.episode_reset()
+        e.control_tick(cand)
+    for f in FIELDS:
+        np.testing.assert_array_equal(two.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+
+
+def test_ticks_that_are_not_eligible_are_not_split():
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(6)
+    # MPC: nothing to hide; generated candidates: not the streaming kernel; K = 16: the packed kernel
+    for name, kw, K, gen in (("3wrobot", dict(n_actor=5), 64, False),
+                             ("2tank", dict(mode=O.MODE_RQL, critic_struct=O.CRITIC_IDS["quadratic"], n_critic=4, buffer_size=8,
+                                            n_actor=10), 64, True),
+                             ("2tank", dict(mode=O.MODE_RQL, critic_struct=O.CRITIC_IDS["quadratic"], n_critic=4, buffer_size=8,
+                                            n_actor=10), 16, False)):
+        B = 4096
+        eng, _ = both(name, B, "f32", **kw)
+        eng.set_tick_parts(2)
+        eng.set_state(rand_states(rng, name, B))
+        cand = None if gen else rand_actions(rng, name, (B, K, kw["n_actor"])).astype(eng.real)
+        eng.control_tick(cand, K=K)
+        assert not eng.last_launch(N.KERNEL_ACTOR)["split"], (name, K, gen)
+    with pytest.raises(N.NativeError):
+        eng.set_tick_parts(3)
