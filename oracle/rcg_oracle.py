@@ -614,6 +614,16 @@ def opt_memory_default(cfg: "OracleCfg") -> int:
 
 
 
+def _quad_sum(R, term, free):
+    """sum_i term(i) over the (free) coordinates, associated as four lanes of a quad do it: p_q = the terms with i = q mod 4 in
+    index order, total = (p0 + p1) + (p2 + p3)."""
+    p = [0.0, 0.0, 0.0, 0.0]
+    for i in range(R):
+        if free is None or free[i]:
+            p[i & 3] += term(i)
+    return (p[0] + p[1]) + (p[2] + p[3])
+
+
 def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY):
     """Projected limited-memory quasi-Newton descent with a 16-way line search, every mode and cost structure.
 
@@ -628,7 +638,8 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
         descent alpha_l = 4^(1 - l) / max_i |d_i / w_i| (four box widths down to 2^-28);  lower J wins, then lower l;
       * the best trial replaces u if it lowers J; otherwise a quasi-Newton iteration drops its memory and the next one
         retries with steepest descent, a steepest-descent iteration ends the search.
-    Deterministic, no finite differences.  Every sum runs in index order, as k_actor_opt (rcg_actor_opt.hpp) does.
+    Deterministic, no finite differences.  Every sum over coordinates is associated as k_actor_opt (rcg_actor_opt.hpp) forms
+    it with four lanes per env (_quad_sum).
     Returns ``(u [N, du], J, accepted steps)``.  Round 3's optimiser was the ``memory = 0`` case (with the steepest-descent
     step scaled over all coordinates): it stalls 3-14 % above SLSQP on the critic-mode fixtures F8c, whose terminal
     action has 1e4 times the curvature of the others; four pairs close that to < 0.5 % in 20 iterations."""
@@ -666,14 +677,13 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
             scale = 1.0
             for t in range(n_pairs):  # newest -> oldest
                 j = (head - 1 - t) % M
-                sy = ss = yy = sq = yhy = 0.0
-                for i in range(R):
-                    if free[i]:
-                        sy += S[j, i] * Y[j, i]
-                        ss += S[j, i] * S[j, i]
-                        yy += Y[j, i] * Y[j, i]
-                        sq += S[j, i] * q[i]
-                        yhy += (Y[j, i] * h0[i]) * Y[j, i]
+                # sums over the coordinates as k_actor_opt's four lanes per env form them (round 5): lane i mod 4 adds its
+                # coordinates in index order, the quad adds (p0 + p1) + (p2 + p3)
+                sy = _quad_sum(R, lambda i: S[j, i] * Y[j, i], free)
+                ss = _quad_sum(R, lambda i: S[j, i] * S[j, i], free)
+                yy = _quad_sum(R, lambda i: Y[j, i] * Y[j, i], free)
+                sq = _quad_sum(R, lambda i: S[j, i] * q[i], free)
+                yhy = _quad_sum(R, lambda i: (Y[j, i] * h0[i]) * Y[j, i], free)
                 ok = sy > 0.0 and sy * sy > 1e-24 * (ss * yy)
                 if t == 0 and ok and yhy > 0.0:
                     scale = sy / yhy
@@ -690,17 +700,12 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
                 if not ok_t[t]:
                     continue
                 j = (head - 1 - t) % M
-                yr = 0.0
-                for i in range(R):
-                    if free[i]:
-                        yr += Y[j, i] * r[i]
+                yr = _quad_sum(R, lambda i: Y[j, i] * r[i], free)
                 c = a_t[t] - yr / sy_t[t]
                 for i in range(R):
                     if free[i]:
                         r[i] = r[i] + S[j, i] * c
-            dg = 0.0
-            for i in range(R):
-                dg += r[i] * g[i]
+            dg = _quad_sum(R, lambda i: r[i] * g[i], None)
             if dg > 0.0 and np.isfinite(dg):
                 d = r
             else:

@@ -66,6 +66,37 @@ __device__ __forceinline__ void row16_argmin(double& bj, int& bi) {
   }
 }
 
+// quad helpers of phase 1b: (p0 + p1) + (p2 + p3) and the maximum over the four lanes of a quad, the same bits in all four
+__device__ __forceinline__ float opt_quad_xchg(float x, bool swap1) {
+  const int b = __float_as_int(x);
+  return __int_as_float(swap1 ? __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, false)
+                              : __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double opt_quad_xchg(double x, bool swap1) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  unsigned lo, hi;
+  if (swap1) {
+    lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0xB1, 0xF, 0xF, false);
+    hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0xB1, 0xF, 0xF, false);
+  } else {
+    lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x4E, 0xF, 0xF, false);
+    hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x4E, 0xF, 0xF, false);
+  }
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <typename real>
+__device__ __forceinline__ real opt_quad_sum(real x) {
+  x += opt_quad_xchg(x, true);   // lanes 0 <-> 1, 2 <-> 3
+  return x + opt_quad_xchg(x, false);  // 0 <-> 2, 1 <-> 3
+}
+template <typename real>
+__device__ __forceinline__ real opt_quad_max(real x) {
+  real o = opt_quad_xchg(x, true);
+  x = o > x ? o : x;
+  o = opt_quad_xchg(x, false);
+  return o > x ? o : x;
+}
+
 template <typename real>
 struct OptArgs {
   const real* obs;        // [dy][B]
@@ -186,7 +217,9 @@ __device__ __forceinline__ void critic_grad_with(const real* chi, const real* y,
 
 // GENERIC = false: MPC with a diagonal quadratic stage cost (every preset in its default mode); true: the rest, mode and
 // structures read from KParams (wave-uniform branches)
-template <typename Sys, typename real, bool TGT, bool GENERIC>
+// PAIRS = false: the instance without curvature pairs (memory 0: box-scaled steepest descent, the default of MPC with a diagonal
+// stage cost) - the quad phase 1b and its registers are compiled out (121 VGPRs, 4 waves per SIMD; 153 with it)
+template <typename Sys, typename real, bool TGT, bool GENERIC, bool PAIRS>
 __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP, NPS = NP > 0 ? NP : 1, G = OPT_G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -198,7 +231,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
   if (b0 >= B) return;
   const int ng = (int)((B - b0) < G ? (B - b0) : G);  // envs of this wave (wave-uniform)
   const int N = P.n_actor, R = N * DU;
-  const int M = A.memory, DCW = A.dcw;
+  const int M = PAIRS ? A.memory : 0, DCW = A.dcw;
   real* const su = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * opt_lds_reals(N, DS, DU, NP, DCW, M);
   real* const sd = su + G * R;
   real* const sX = sd + G * R;
@@ -406,93 +439,143 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
 #pragma unroll
         for (int c = 0; c < DU; ++c) sGc[(k * DU + c) * G + lane] = g[c];
       }
-      // the pair of the last accepted step: its slot holds the gradient at the step's start point
-      if (pending) {
+    }
+    wave_lds_sync();
+    // ---- 1b. FOUR LANES PER ENV (round 5): env e = lanes 4 e .. 4 e + 3, coordinate i of the sequence in lane i mod 4.  The
+    // completion of the pending (s, y) pair, the free set, the two-loop recursion and the direction are sums and updates over
+    // the R coordinates; on lane == env they ran on 16 of the 64 lanes (the critic modes' default, 4 pairs: 0.48 of the issue
+    // slots).  Dot products: each lane sums ITS coordinates in index order, the quad adds (p0 + p1) + (p2 + p3) - the same
+    // bits in its four lanes; oracle/rcg_oracle.py::actor_optimize_single associates its sums the same way.
+    if constexpr (!PAIRS) {  // no pairs (MPC with a diagonal stage cost): free set and box-scaled steepest descent stay on lane == env
+      if (active) {  // (the quad form's hand-over - six shuffles and a barrier - costs more than these two short loops: 0.144 ->
+        const real* const ue = su + lane * R;  // 0.160 ms per C2 tick when it served this case too)
+        gn = 0;
         for (int i = 0; i < R; ++i) {
-          real* const yp = sLY + ((size_t)head * R + i) * G + lane;
-          *yp = sGc[i * G + lane] - *yp;
+          const int c = i % DU;
+          const real ui = ue[i], gi = sGc[i * G + lane];
+          const bool held = (ui <= P.lo[c] && gi > (real)0) || (ui >= P.hi[c] && gi < (real)0);
+          const real dc = held ? (real)0 : gi * w2[c];
+          sd[lane * R + i] = dc;
+          const real m = (dc < 0 ? -dc : dc) / w[c];
+          gn = m > gn ? m : gn;
         }
-        head = head + 1 == M ? 0 : head + 1;
-        n_pairs = n_pairs + 1 < M ? n_pairs + 1 : M;
-        pending = false;
+        quasi = false;
+        if (!(gn > (real)0) || !finite_r<real>(gn)) active = false;
       }
-      // free set: a coordinate on a bound whose descent direction leaves the box is held
-      unsigned long long fm = 0ull;
-      for (int i = 0; i < R; ++i) {
-        const int c = i % DU;
-        const real ui = ue[i], gi = sGc[i * G + lane];
-        const bool held = (ui <= P.lo[c] && gi > (real)0) || (ui >= P.hi[c] && gi < (real)0);
-        if (!held) fm |= 1ull << i;
-      }
-      quasi = n_pairs > 0;
-      if (quasi) {  // L-BFGS two-loop recursion over the pairs restricted to the free set
-        for (int i = 0; i < R; ++i) sQ[i * G + lane] = ((fm >> i) & 1ull) ? sGc[i * G + lane] : (real)0;
-        real a_t[OPT_MAXM], sy_t[OPT_MAXM];
-        unsigned okm = 0u;
-        real scale = 1;
+    } else {
+      const int qe = lane >> 2, qq = lane & 3;  // env and part of this lane in the quad view (qe < 16 always)
+      const bool act_q = __shfl((int)active, qe, 64) != 0;
+      int head_q = __shfl(head, qe, 64), np_q = __shfl(n_pairs, qe, 64);
+      const bool pend_q = __shfl((int)pending, qe, 64) != 0;
+      bool quasi_q = false;
+      real gn_q = 0;
+      if (act_q) {
+        const real* const ue = su + qe * R;
+        // the pair of the last accepted step: its slot holds the gradient at the step's start point
+        if (pend_q) {
+          for (int i = qq; i < R; i += 4) {
+            real* const yp = sLY + ((size_t)head_q * R + i) * G + qe;
+            *yp = sGc[i * G + qe] - *yp;
+          }
+          head_q = head_q + 1 == M ? 0 : head_q + 1;
+          np_q = np_q + 1 < M ? np_q + 1 : M;
+        }
+        // free set: a coordinate on a bound whose descent direction leaves the box is held (this lane's coordinates)
+        unsigned long long fm = 0ull;
+        for (int i = qq; i < R; i += 4) {
+          const int c = i % DU;
+          const real ui = ue[i], gi = sGc[i * G + qe];
+          const bool held = (ui <= P.lo[c] && gi > (real)0) || (ui >= P.hi[c] && gi < (real)0);
+          if (!held) fm |= 1ull << i;
+        }
+        quasi_q = np_q > 0;
+        if (quasi_q) {  // L-BFGS two-loop recursion over the pairs restricted to the free set
+          for (int i = qq; i < R; i += 4) sQ[i * G + qe] = ((fm >> i) & 1ull) ? sGc[i * G + qe] : (real)0;
+          real a_t[OPT_MAXM], sy_t[OPT_MAXM];
+          unsigned okm = 0u;
+          real scale = 1;
 #pragma unroll
-        for (int t = 0; t < OPT_MAXM; ++t) {  // newest -> oldest
-          a_t[t] = 0;
-          sy_t[t] = 1;
-          if (t < n_pairs) {
-            int j = head - 1 - t;
-            if (j < 0) j += M;
-            const real* const Sj = sLS + (size_t)j * R * G + lane;
-            const real* const Yj = sLY + (size_t)j * R * G + lane;
-            real sy = 0, ss = 0, yy = 0, sq = 0, yhy = 0;
-            for (int i = 0; i < R; ++i)
-              if ((fm >> i) & 1ull) {
-                const real s = Sj[i * G], y = Yj[i * G];
-                sy = fma_r(s, y, sy);
-                ss = fma_r(s, s, ss);
-                yy = fma_r(y, y, yy);
-                sq = fma_r(s, sQ[i * G + lane], sq);
-                yhy = fma_r(y * w2[i % DU], y, yhy);
+          for (int t = 0; t < OPT_MAXM; ++t) {  // newest -> oldest
+            a_t[t] = 0;
+            sy_t[t] = 1;
+            if (t < np_q) {
+              int j = head_q - 1 - t;
+              if (j < 0) j += M;
+              const real* const Sj = sLS + (size_t)j * R * G + qe;
+              const real* const Yj = sLY + (size_t)j * R * G + qe;
+              real sy = 0, ss = 0, yy = 0, sq = 0, yhy = 0;
+              for (int i = qq; i < R; i += 4)
+                if ((fm >> i) & 1ull) {
+                  const real s_ = Sj[i * G], y_ = Yj[i * G];
+                  sy = fma_r(s_, y_, sy);
+                  ss = fma_r(s_, s_, ss);
+                  yy = fma_r(y_, y_, yy);
+                  sq = fma_r(s_, sQ[i * G + qe], sq);
+                  yhy = fma_r(y_ * w2[i % DU], y_, yhy);
+                }
+              sy = opt_quad_sum(sy);
+              ss = opt_quad_sum(ss);
+              yy = opt_quad_sum(yy);
+              sq = opt_quad_sum(sq);
+              yhy = opt_quad_sum(yhy);
+              const bool ok = sy > (real)0 && sy * sy > (real)1e-24 * (ss * yy);
+              if (t == 0 && ok && yhy > (real)0) scale = sy / yhy;
+              sy_t[t] = sy;
+              if (ok) {
+                okm |= 1u << t;
+                const real a = sq / sy;
+                a_t[t] = a;
+                for (int i = qq; i < R; i += 4)
+                  if ((fm >> i) & 1ull) sQ[i * G + qe] = fma_r(-a, Yj[i * G], sQ[i * G + qe]);
               }
-            const bool ok = sy > (real)0 && sy * sy > (real)1e-24 * (ss * yy);
-            if (t == 0 && ok && yhy > (real)0) scale = sy / yhy;
-            sy_t[t] = sy;
-            if (ok) {
-              okm |= 1u << t;
-              const real a = sq / sy;
-              a_t[t] = a;
-              for (int i = 0; i < R; ++i)
-                if ((fm >> i) & 1ull) sQ[i * G + lane] = fma_r(-a, Yj[i * G], sQ[i * G + lane]);
             }
           }
-        }
-        for (int i = 0; i < R; ++i) sQ[i * G + lane] = (scale * w2[i % DU]) * sQ[i * G + lane];
+          for (int i = qq; i < R; i += 4) sQ[i * G + qe] = (scale * w2[i % DU]) * sQ[i * G + qe];
 #pragma unroll
-        for (int t = OPT_MAXM - 1; t >= 0; --t) {  // oldest -> newest
-          if (t < n_pairs && ((okm >> t) & 1u)) {
-            int j = head - 1 - t;
-            if (j < 0) j += M;
-            const real* const Sj = sLS + (size_t)j * R * G + lane;
-            const real* const Yj = sLY + (size_t)j * R * G + lane;
-            real yr = 0;
-            for (int i = 0; i < R; ++i)
-              if ((fm >> i) & 1ull) yr = fma_r(Yj[i * G], sQ[i * G + lane], yr);
-            const real cf = a_t[t] - yr / sy_t[t];
-            for (int i = 0; i < R; ++i)
-              if ((fm >> i) & 1ull) sQ[i * G + lane] = fma_r(Sj[i * G], cf, sQ[i * G + lane]);
+          for (int t = OPT_MAXM - 1; t >= 0; --t) {  // oldest -> newest
+            if (t < np_q && ((okm >> t) & 1u)) {
+              int j = head_q - 1 - t;
+              if (j < 0) j += M;
+              const real* const Sj = sLS + (size_t)j * R * G + qe;
+              const real* const Yj = sLY + (size_t)j * R * G + qe;
+              real yr = 0;
+              for (int i = qq; i < R; i += 4)
+                if ((fm >> i) & 1ull) yr = fma_r(Yj[i * G], sQ[i * G + qe], yr);
+              yr = opt_quad_sum(yr);
+              const real cf = a_t[t] - yr / sy_t[t];
+              for (int i = qq; i < R; i += 4)
+                if ((fm >> i) & 1ull) sQ[i * G + qe] = fma_r(Sj[i * G], cf, sQ[i * G + qe]);
+            }
+          }
+          real dg = 0;
+          for (int i = qq; i < R; i += 4) dg = fma_r(sQ[i * G + qe], sGc[i * G + qe], dg);
+          dg = opt_quad_sum(dg);
+          if (!(dg > (real)0) || !finite_r<real>(dg)) {  // not a descent direction: drop the memory
+            quasi_q = false;
+            np_q = 0;
           }
         }
-        real dg = 0;
-        for (int i = 0; i < R; ++i) dg = fma_r(sQ[i * G + lane], sGc[i * G + lane], dg);
-        if (!(dg > (real)0) || !finite_r<real>(dg)) {  // not a descent direction: drop the memory
-          quasi = false;
-          n_pairs = 0;
+        for (int i = qq; i < R; i += 4) {
+          const int c = i % DU;
+          const real dc = quasi_q ? sQ[i * G + qe] : (((fm >> i) & 1ull) ? sGc[i * G + qe] * w2[c] : (real)0);
+          sd[qe * R + i] = dc;
+          const real m = (dc < 0 ? -dc : dc) / w[c];
+          gn_q = m > gn_q ? m : gn_q;
         }
+        gn_q = opt_quad_max(gn_q);
       }
-      gn = 0;
-      for (int i = 0; i < R; ++i) {
-        const int c = i % DU;
-        const real dc = quasi ? sQ[i * G + lane] : (((fm >> i) & 1ull) ? sGc[i * G + lane] * w2[c] : (real)0);
-        sd[lane * R + i] = dc;
-        const real m = (dc < 0 ? -dc : dc) / w[c];
-        gn = m > gn ? m : gn;
+      // back to lane == env: env e's results sit in lane 4 e
+      const int src = (lane < G ? lane : 0) * 4;
+      const int head_b = __shfl(head_q, src, 64), np_b = __shfl(np_q, src, 64), quasi_b = __shfl((int)quasi_q, src, 64);
+      const real gn_b = __shfl(gn_q, src, 64);
+      if (active) {
+        head = head_b;
+        n_pairs = np_b;
+        pending = false;
+        quasi = quasi_b != 0;
+        gn = gn_b;
+        if (!(gn > (real)0) || !finite_r<real>(gn)) active = false;
       }
-      if (!(gn > (real)0) || !finite_r<real>(gn)) active = false;
     }
     wave_lds_sync();
 

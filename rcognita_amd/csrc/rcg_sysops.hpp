@@ -614,20 +614,29 @@ int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state
       const int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
       if (rc) return rc;
     }
-    const void* fn = generic ? (tgt ? (const void*)&k_actor_opt<Sys, real, true, true> : (const void*)&k_actor_opt<Sys, real, false, true>)
-                             : (tgt ? (const void*)&k_actor_opt<Sys, real, true, false> : (const void*)&k_actor_opt<Sys, real, false, false>);
-    if (lds > 64 * 1024)  // beyond the default dynamic-LDS limit (the CU has 160 KB)
-      HIPCHK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool pairs = A.memory > 0;  // the instance with the curvature pairs and the four-lanes-per-env phase 1b
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
-    if (generic && tgt)
-      RCG_LAUNCH(h, (k_actor_opt<Sys, real, true, true>), grid, block, lds, A, P);
-    else if (generic)
-      RCG_LAUNCH(h, (k_actor_opt<Sys, real, false, true>), grid, block, lds, A, P);
-    else if (tgt)
-      RCG_LAUNCH(h, (k_actor_opt<Sys, real, true, false>), grid, block, lds, A, P);
-    else
-      RCG_LAUNCH(h, (k_actor_opt<Sys, real, false, false>), grid, block, lds, A, P);
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_OPT, (generic ? 1 : 0) | (tgt ? 2 : 0), OPT_G);
+#define RCG_OPT_LAUNCH(T, GEN, PR)                                                                                  \
+  do {                                                                                                              \
+    auto fn = k_actor_opt<Sys, real, T, GEN, PR>;                                                                   \
+    if (lds > 64 * 1024) /* beyond the default dynamic-LDS limit (the CU has 160 KB) */                             \
+      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                     \
+    RCG_LAUNCH(h, fn, grid, block, lds, A, P);                                                                      \
+  } while (0)
+    const int sel = (generic ? 4 : 0) | (tgt ? 2 : 0) | (pairs ? 1 : 0);
+    switch (sel) {
+      case 0: RCG_OPT_LAUNCH(false, false, false); break;
+      case 1: RCG_OPT_LAUNCH(false, false, true); break;
+      case 2: RCG_OPT_LAUNCH(true, false, false); break;
+      case 3: RCG_OPT_LAUNCH(true, false, true); break;
+      case 4: RCG_OPT_LAUNCH(false, true, false); break;
+      case 5: RCG_OPT_LAUNCH(false, true, true); break;
+      case 6: RCG_OPT_LAUNCH(true, true, false); break;
+      default: RCG_OPT_LAUNCH(true, true, true); break;
+    }
+#undef RCG_OPT_LAUNCH
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_OPT, (generic ? 1 : 0) | (tgt ? 2 : 0) | (pairs ? 4 : 0), OPT_G);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });

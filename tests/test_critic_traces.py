@@ -131,5 +131,5 @@ def test_sensitivity_fixture_is_what_the_restated_loop_gives(key):
     # which traces the critic-solver exchange moves by more than their band is a measured list, not a hand-made one
     from oracle.gen_trace_sensitivity import band_of
 
-    moved = sorted(k for k, v in fx["traces"].items() if v["exact_critic"]["shift"] > band_of(v["sensitivity"]))
-    assert moved == ["2tank_RQL_quadratic", "3wrobotNI_RQL_quad-mix"], moved
+    moved = sorted(k for k, v in fx["traces"].items() if v["exact_critic"]["shift"] > 0.5 * band_of(v["sensitivity"]))
+    assert moved == ["2tank_RQL_quadratic", "3wrobotNI_RQL_quad-mix", "3wrobot_RQL_quad-nomix"], moved
