@@ -122,6 +122,12 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
                                          (lds_void*)(tile + NFULL * 1024 + i * 256), 4, 0, RCG_DMA_AUX);
   };
 
+  // (MPC tick) the env step of the tick, fused: lane == env for the wave's n_env <= 64 envs - k_sim's code on k_sim's data,
+  // ONE RK4 per wave whatever the number of tiles - and the new states (and the states before the last substep, for the
+  // reference's loop order) parked in LDS, from where the lanes of every tile fetch their env's.  Saves the k_sim launch and
+  // the dispatch gap behind it: 3 us of a 14-20 us tick at K = 8 .. 16.
+  const bool fused = A.sim_n_sub > 0;  // wave-uniform
+  real* const sst = reinterpret_cast<real*>(smem_raw + (size_t)4 * TILE) + (size_t)wave_in_wg * (2 * DS * 64);
   real y0[DS], yn[DS], x0[DS], xn[DS], pn[NP > 0 ? NP : 1];
   const bool lag = A.state_sys != A.obs;  // wave-uniform
 #pragma unroll
@@ -131,11 +137,20 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
   auto fetch_env = [&](int j) {  // the state of MY env of tile j (lanes without a row request nothing)
     if (le < envs_in(j)) {
       const long b = env0 + (long)j * G + le;
+      if (fused) {
+        const int el = j * G + le;
 #pragma unroll
-      for (int c = 0; c < DS; ++c) yn[c] = A.obs[(long)c * B + b];
-      if (lag) {
+        for (int c = 0; c < DS; ++c) {
+          yn[c] = sst[c * 64 + el];
+          xn[c] = sst[(DS + c) * 64 + el];
+        }
+      } else {
 #pragma unroll
-        for (int c = 0; c < DS; ++c) xn[c] = A.state_sys[(long)c * B + b];
+        for (int c = 0; c < DS; ++c) yn[c] = A.obs[(long)c * B + b];
+        if (lag) {
+#pragma unroll
+          for (int c = 0; c < DS; ++c) xn[c] = A.state_sys[(long)c * B + b];
+        }
       }
       if (A.pars_env) {
 #pragma unroll
@@ -144,8 +159,46 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
     }
   };
 
-  fetch_env(0);
-  issue_tile(0);  // after the env request: retiring the env state must not drain the tile (vmcnt retires in order)
+  if (fused) {
+    issue_tile(0);  // the first tile does not depend on the env step: it travels while the wave steps its envs
+    if (lane < n_env) {
+      const long b = env0 + lane;
+      uint32_t st = A.sim_status[b];
+      real x[DS], xp[DS], u[DU];
+#pragma unroll
+      for (int c = 0; c < DS; ++c) xp[c] = x[c] = A.sim_state[(long)c * B + b];
+      if (!(st & 1u)) {
+#pragma unroll
+        for (int c = 0; c < DU; ++c) u[c] = A.sim_action[(long)c * B + b];
+        const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
+        real accum_unused = 0;  // (RCG_FLAG_ACCUM_EVERY_SUBSTEP handles are not fused)
+        if (env_substeps<Sys, real, TGT>(P, pre, A.sim_n_sub, x, xp, u, st, accum_unused)) {
+#pragma unroll
+          for (int c = 0; c < DS; ++c) {
+            A.sim_state[(long)c * B + b] = x[c];
+            A.sim_state_prev[(long)c * B + b] = xp[c];
+          }
+        } else {
+          A.sim_status[b] = st;  // became non-finite: frozen at its last finite state, nothing else is written
+        }
+      }
+      if (st & 1u) {  // a frozen env keeps STATE and STATE_PREV as they are: the decision sees what k_sim would have left
+#pragma unroll
+        for (int c = 0; c < DS; ++c) xp[c] = A.sim_state_prev[(long)c * B + b];
+      }
+#pragma unroll
+      for (int c = 0; c < DS; ++c) {
+        sst[c * 64 + lane] = x[c];
+        sst[(DS + c) * 64 + lane] = xp[c];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    fetch_env(0);  // (from LDS)
+  } else {
+    fetch_env(0);
+    issue_tile(0);  // after the env request: retiring the env state must not drain the tile (vmcnt retires in order)
+  }
 
   const real h = P.h_pred;
   auto pre_env = Sys::template prepare<real>(pn);  // homogeneous parameters: once

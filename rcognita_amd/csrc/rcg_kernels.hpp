@@ -260,6 +260,14 @@ struct ActorArgs {
   int dbg;                // -DRCG_DEV builds only (env RCG_DBG): bits skip parts of k_actor_dma for timing
   int env_lo, env_hi;     // k_actor_dma: the envs [env_lo, env_hi) of the batch this launch serves (env_hi == 0: all of them) -
                           // a handle that splits its tick into halves on two streams (rcg_control_tick, RQL / SQL)
+  // k_actor_dma_packed, MPC tick: the env step of the tick (Simulator.sim_step, k_sim's code) fused into the launch -
+  // sim_n_sub > 0: the wave steps ITS envs first (lane == env), writes STATE / STATE_PREV / STATUS and hands the new states to
+  // its tiles through LDS; obs / state_sys are then not read
+  real* sim_state;        // [ds][B] in/out
+  real* sim_state_prev;   // [ds][B] out
+  const real* sim_action; // [du][B] the held action
+  uint32_t* sim_status;   // [B]
+  int sim_n_sub;
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));  // one 16-B global_load_dwordx4 / ds_write_b128

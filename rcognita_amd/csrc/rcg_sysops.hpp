@@ -421,8 +421,12 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
         action == h->f[RCG_FIELD_ACTION] && best_J == h->f[RCG_FIELD_BEST_J] && (void*)best_idx == h->f[RCG_FIELD_BEST_IDX])
       return op_ticks<Sys>(h, 1, K, nullptr);
   }
-  // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2).
-  if (sim_first) {
+  // The env step of the tick (Simulator.sim_step) precedes the decision: its own launch (k_sim, 6.8 us at C2) - except in front
+  // of k_actor_dma_packed, whose launches are short enough (11-31 us) for the k_sim launch and the gap behind it to be 15-20 %
+  // of the tick: there the wave steps its own envs in its prologue (rcg_actor_dma_packed.hpp)
+  const bool fuse_sim = pack_ok && tick && sim_first && !obs && !state_sys && !A.J &&
+                        !(c.flags & (RCG_FLAG_DISTURB | RCG_FLAG_ACCUM_EVERY_SUBSTEP)) && !knobs.no_tick_fuse;
+  if (sim_first && !fuse_sim) {
     int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
     if (rc) return rc;
   }
@@ -436,7 +440,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     const long pw = (B + gpw - 1) / gpw;
     const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
     const size_t full_tile = (size_t)64 * R * esz;
-    size_t lds_req = 4 * full_tile + (A.J ? 4 * esz * (size_t)gpw * K : 0);
+    size_t lds_req = 4 * full_tile + (A.J ? 4 * esz * (size_t)gpw * K : 0) + (fuse_sim ? 4 * esz * 2 * Sys::DS * 64 : 0);
     const size_t cap = knobs.per_cu == 2 ? (size_t)56 * 1024 : (knobs.per_cu == 8 ? 0 : (size_t)36 * 1024);
     if (lds_req < cap) lds_req = cap;  // 4 resident blocks per CU (dev build: RCG_PER_CU = 2 | 8)
     const ProfPair pp = prof_take(h);  // a due ProfScope's pair travels in the dispatch
@@ -444,17 +448,28 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     Ap.G = pack_g;
     Ap.gpw = (int)gpw;
     Ap.jwave = 1;
+    if (fuse_sim) {
+      Ap.sim_state = (real*)h->f[RCG_FIELD_STATE];
+      Ap.sim_state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
+      Ap.sim_action = (const real*)h->f[RCG_FIELD_ACTION];
+      Ap.sim_status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+      Ap.sim_n_sub = c.substeps_per_tick;
+    }
     // (no instance - RQL / SQL with more than 36 dwords of weights: the tick is served by k_actor_dma / k_actor below)
     const bool launched =
         variant < DMA_RQL_0    ? launch_dma_packed<Sys, real, 3>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b)
         : variant >= DMA_SQL_0 ? launch_dma_packed<Sys, real, 4>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b)
                                : launch_dma_packed<Sys, real, 5>(R, variant, grid, block, lds_req, h->stream, Ap, P, pp.a, pp.b);
     if (launched) {
-      note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA_PACKED, variant, (int)gpw);
+      note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_DMA_PACKED, variant | (fuse_sim ? 16 : 0), (int)gpw);
       HIPCHK(h, hipGetLastError());
       return RCG_OK;
     }
     prof_give_back(h, pp);
+    if (fuse_sim) {  // no packed instance after all: the env step as its own launch, then the other kernels
+      int rc = op_sim_step<Sys>(h, c.substeps_per_tick);
+      if (rc) return rc;
+    }
   }
   if (dma_ok) {
     // Launch geometry, measured on MI355X at C2 (B = 65536, K = 256, N = 10):

@@ -696,5 +696,5 @@ def test_packed_tiles_with_state_lag_and_per_env_parameters(name, Nh, K, dtype):
         eng.control_tick(dc, K=K)
         env = PAR.check_tick(cfg, env, cand.astype(np.float64), PAR.device_fields(eng, N, with_prev=True), tol=TOL[dtype],
                              report=rep, what=f"{name} K={K} {dtype} lag t={t}")
-    assert_kernel(eng, "k_actor_dma_packed", N.DMA_MPC_G1)
+    assert_kernel(eng, "k_actor_dma_packed", N.DMA_MPC_G1 | 16)  # (+ 16: the env step of the tick ran inside the launch)
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
