@@ -735,13 +735,26 @@ struct GenPk<Sys3WRobotNI> {  // state (x, y, alpha), inputs (v, omega); candida
   }
 };
 
+// NaN -> +inf in one instruction: v_min_f32 returns its non-NaN operand (IEEE minNum), every other value is its own
+// minimum with +inf
+__device__ __forceinline__ float nan_to_inf(float v) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(__builtin_huge_valf()));
+  return r;
+}
+__device__ __forceinline__ double nan_to_inf(double v) { return (v != v) ? __builtin_huge_val() : v; }
+
 // Tiles t .. t + NC - 1 of the generated grid for this lane through rollout_mpc_gen_multi, folded into the lane's
 // running (bestJ, bestI, bestU) in candidate order.  Requires one env per wave (K >= 64), du = 2 and 64 % g == 0, so
 // that candidate k + 64 has the same second level as candidate k.
 // PKONLY: the hand-packed rollout and nothing else - the caller (a kernel instance that exists for this one regime) has
 // checked gamma == 1, the preset's zero weights, float, no target: the register budget of that instance is the packed
 // rollout's (the instances that carry every variant need 125-235 VGPRs).
-template <typename Sys, typename real, bool TGT, int NC, bool PKONLY = false>
+// LEAN (k_ticks_pk: K a multiple of 256, every lane has a candidate in every tile, the caller starts with bestI = its first
+// candidate and regenerates the winner's action from the index): the running best is folded in with one v_min (NaN -> +inf:
+// v_min_f32 returns the other operand) and one compare per candidate - no sentinel test, no action bookkeeping.  Same winner:
+// a candidate replaces the best iff its cost is strictly lower, and an all-+inf lane keeps its first index either way.
+template <typename Sys, typename real, bool TGT, int NC, bool PKONLY = false, bool LEAN = false>
 __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const typename Sys::template Pre<real>& pre, int N,
                                                 int K, int g, int t, int lane, bool env_ok, const real* xs,
                                                 const real* y0, real& bestJ, int& bestI, real* bestU) {
@@ -784,6 +797,16 @@ __device__ __forceinline__ void gen_multi_tiles(const KParams<real>& P, const ty
   }
   else
     rollout_mpc_gen_multi<Sys, real, TGT, false, NC>(P, pre, N, xs, y0, u0v, ua[0][1], J);
+  if constexpr (LEAN) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const real Jc = nan_to_inf(J[c]);
+      const bool take = Jc < bestJ;
+      bestJ = take ? Jc : bestJ;
+      bestI = take ? k0 + 64 * c : bestI;
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int k = k0 + 64 * c;

@@ -226,27 +226,29 @@ __global__ __launch_bounds__(256, 4) void k_ticks_pk(const TicksArgs<float> A, c
       }
       const auto pre_e = A.pars_env ? Sys::template bcast<float>(pre, e) : pre;
       float bestJ = inf_r<float>();
-      int bestI = 0x7fffffff;
+      int bestI = lane;  // the lane's first candidate (tile 0): what an all-+inf lane keeps, as numpy.argmin keeps index 0
       float bestU[DU] = {0, 0};
       for (int tl = 0; tl < A.n_tiles; tl += 4)
-        gen_multi_tiles<Sys, float, false, 4, true>(P, pre_e, N, K, A.grid_g, tl, lane, true, xse, ye, bestJ, bestI, bestU);
+        gen_multi_tiles<Sys, float, false, 4, true, true>(P, pre_e, N, K, A.grid_g, tl, lane, true, xse, ye, bestJ, bestI, bestU);
       const unsigned long long key = wave_min_u64(((unsigned long long)float_order_key(bestJ) << 32) | (unsigned)bestI);
-      if (lane == e) {  // receive_action (held until the next tick), upd_accum_obj, the tick counter: in the env's lane
-        myJ = float_from_order_key((unsigned)(key >> 32));
-        myI = (int)(unsigned)key;
+      myJ = lane == e ? float_from_order_key((unsigned)(key >> 32)) : myJ;  // env e's result waits in the env's lane
+      myI = lane == e ? (int)(unsigned)key : myI;
+    }
+    // receive_action (held until the next tick), upd_accum_obj, the tick counter - ONCE per tick for all envs of the wave,
+    // lane == env (round 4 did this inside the env loop under `lane == e`: 25 instructions issued ne times per tick)
+    if (mine) {
 #ifdef RCG_AB_DIV
-        gen_candidate<DU, float>(P, A.grid_g, myI, u);
+      gen_candidate<DU, float>(P, A.grid_g, myI, u);
 #else
-        {  // gen_candidate(myI) with shifts: g is a power of two in this regime (64 % g == 0)
-          const int lg = 31 - __builtin_clz((unsigned)A.grid_g);
-          const float den = (float)(A.grid_g > 1 ? A.grid_g - 1 : 1);
-          u[0] = fma_r((float)(myI >> lg), (P.hi[0] - P.lo[0]) / den, P.lo[0]);
-          u[1] = fma_r((float)(myI & (A.grid_g - 1)), (P.hi[1] - P.lo[1]) / den, P.lo[1]);
-        }
-#endif
-        if (!P.accum_every_substep) accum = accum_update<Sys, false, float>(P, x, u, accum);
-        steps += 1;
+      {  // gen_candidate(myI) with shifts: g is a power of two in this regime (64 % g == 0)
+        const int lg = 31 - __builtin_clz((unsigned)A.grid_g);
+        const float den = (float)(A.grid_g > 1 ? A.grid_g - 1 : 1);
+        u[0] = fma_r((float)(myI >> lg), (P.hi[0] - P.lo[0]) / den, P.lo[0]);
+        u[1] = fma_r((float)(myI & (A.grid_g - 1)), (P.hi[1] - P.lo[1]) / den, P.lo[1]);
       }
+#endif
+      if (!P.accum_every_substep) accum = accum_update<Sys, false, float>(P, x, u, accum);
+      steps += 1;
     }
   }
   if (mine) {  // one coalesced write per field for the envs of this wave
