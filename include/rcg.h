@@ -263,9 +263,10 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
  * under the other inherits the same caveat.  BEST_J / BEST_IDX are the last tick's.  MPC handles: any stage-cost structure,
  * with or without RCG_FLAG_DISTURB.  RQL / SQL handles (1 <= Ncritic - 1 <= 8, no disturbance model, the preset's observation
  * target setting): the two launches of a tick - env step + buffer push + critic fit, then the decision - run as phases of
- * one persistent launch (k_ticks_mem), same functions on the same memory, bit-identical as well; other RQL / SQL handles (and
- * critic structures with 20 or more weights, whose single ticks fit with four lanes per env) get
- * RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of small batches. */
+ * one persistent launch (k_ticks_mem), same functions on the same memory, bit-identical as well (critic structures with 20 or
+ * more weights, whose single ticks fit with four lanes per env, run that four-lane walk as their critic phase; they need
+ * K >= 4); other RQL / SQL handles get RCG_ERR_UNSUPPORTED and loop rcg_control_tick.  Removes the launch-bound regime of
+ * small batches. */
 int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
 /* T consecutive rcg_control_tick(h, cand, K) issued by ONE call: the loop of presets/main_3wrobot.py:415-468 for T sampling
  * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode.  Handles of up to

@@ -849,9 +849,6 @@ int op_ticks(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
 template <typename Sys>
 static bool ticks_mem_ok(const rcg_handle* h) {
   const bool tgt = (h->cfg.flags & RCG_FLAG_HAS_TARGET) != 0;
-  // (the critic phase of k_ticks_mem is the one-lane fit: a structure whose single ticks run the four-lane fit would not end
-  // bit-identical, so those handles loop single ticks)
-  if (dma_dc(h->cfg.critic_struct, Sys::DS, Sys::DU) >= kFitLanesMinDc && h->cfg.n_critic - 1 <= 3) return false;
   return tgt == Sys::TGT || (!tgt && Sys::TGT);  // instances exist for the preset's target setting (zeros serve "no target")
 }
 
@@ -859,7 +856,10 @@ template <typename Sys>
 int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
   constexpr int DU = Sys::DU;
   const rcg_cfg& c = h->cfg;
-  if (!ticks_mem_ok<Sys>(h)) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: no persistent RQL/SQL instance for this observation target / critic structure (>= 20 weights)");
+  if (!ticks_mem_ok<Sys>(h)) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: no persistent RQL/SQL instance for this observation target");
+  // (structures with >= 20 weights fit with four lanes per env: the wave's envs must fit its 16 quads)
+  if (dma_dc(c.critic_struct, Sys::DS, Sys::DU) >= kFitLanesMinDc && c.n_critic - 1 <= 3 && K < 4)
+    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: K >= 4 with this critic structure (four lanes per env in the fit)");
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
     const KParams<real>& P = params<real>(h);
@@ -916,7 +916,8 @@ int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
 #define RCG_TM(CS)                                                                                              \
   do {                                                                                                          \
     if (m <= 3)                                                                                                 \
-      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, 3, Sys::TGT>), grid, block, 0, M, h->p64, P);                  \
+      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, 3, Sys::TGT, (CriticDim<CS, Sys::DS, Sys::DU>::value >= kFitLanesMinDc)>), \
+                 grid, block, 0, M, h->p64, P);                                                                 \
     else                                                                                                        \
       RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, kFitMaxRows, Sys::TGT>), grid, block, 0, M, h->p64, P);        \
   } while (0)

@@ -288,7 +288,9 @@ struct TicksMemArgs {
   int every;   // critic_every_ticks (>= 1)
 };
 
-template <typename Sys, typename real, int CS, int MAXM, bool TGT>
+// ML (round 5): the critic structures with >= 20 weights, whose single ticks fit with FOUR LANES PER ENV (k_critic_fit_ml): the
+// wave's envs (G <= 16) take the quads 0 .. G - 1 of the wave for phase 1 - critic_update_env_ml, the body of that kernel.
+template <typename Sys, typename real, int CS, int MAXM, bool TGT, bool ML = false>
 __global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, const KParams<double> P64,
                                                    const KParams<real> P) {
   const int lane = threadIdx.x & 63;
@@ -301,7 +303,12 @@ __global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, c
   FitArgs<real> F = M.F;
   for (int t = 0; t < M.T; ++t) {
     F.do_fit = ((M.tick0 + t + 1) % M.every) == 0 ? 1 : 0;  // fits on ticks every - 1, 2 every - 1, ... of the episode
-    if (lane < envs_here) critic_update_env<Sys, real, CS, MAXM>(F, P64, P, wave * G + lane);
+    if constexpr (ML) {
+      if (lane < FIT_L * envs_here)  // (whole quads: the DPP exchanges of the four-lane walk stay inside a quad)
+        critic_update_env_ml<Sys, real, CS, MAXM>(F, P64, P, wave * G + (lane / FIT_L), lane & (FIT_L - 1));
+    } else {
+      if (lane < envs_here) critic_update_env<Sys, real, CS, MAXM>(F, P64, P, wave * G + lane);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -277,3 +277,33 @@ def test_critic_fit_on_the_td_stacks_of_the_reference_closed_loop(name, cs, mode
     assert np.all(Jc <= Js + (2e-2 + slack) * scale + 1e-9), float(np.max((Jc - Js) / scale))
     lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
     assert np.all(w >= lo - 1e-4) and np.all(w <= hi + 1e-3)
+
+
+@pytest.mark.parametrize("name,cs", [("3wrobotNI", "quad-lin"), ("3wrobot", "quadratic"), ("2tank", "quadratic")])
+def test_non_finite_buffers_leave_the_fit_at_its_start_point(name, cs):
+    """buffers that hold inf / NaN (an env that ran away before it was frozen).  The walk's comparisons are then
+    comparisons with NaN; the four-lane form (>= 20 weights: the first two cases) must still take the same decisions in the
+    four lanes of a quad (total tie rule, rcg_critic_fit_ml.hpp) and both forms end on the safeguard - clip(w_init) - for
+    those envs, exactly as the oracle does, while every other env of the wave gets its fit."""
+    from rcognita_amd import _native as N
+
+    B = 96
+    eng, cfg = both(name, B, "f64", mode=O.MODE_RQL, critic_struct=O.CRITIC_IDS[cs], n_critic=4, buffer_size=6, n_actor=5)
+    rng = np.random.default_rng(11)
+    ob = np.stack([rand_states(rng, name, B) for _ in range(6)], axis=1)
+    ab = rand_actions(rng, name, (B, 6))
+    wp = 1.0 + rng.random((B, cfg.dc))
+    bad = np.arange(B) % 7 == 3
+    ob[bad, 1, 0] = np.inf          # a TD row with an infinite feature
+    ob[bad & (np.arange(B) % 2 == 1), 2, -1] = np.nan
+    _load_buffers(eng, N, ob, ab, wp)
+    eng.critic_update(do_fit=True)
+    ll = eng.last_launch(N.KERNEL_CRITIC)
+    assert bool(ll["variant"] & 1024) == (cfg.dc >= 20), ll
+    w = eng.get_field(N.FIELD_W_CRITIC).astype(np.float64)
+    lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
+    assert np.all(np.isfinite(w))
+    np.testing.assert_array_equal(w[bad], np.broadcast_to(np.clip(np.ones(cfg.dc), lo, hi), w[bad].shape))
+    w_or = O.critic_fit(cfg, wp[~bad], ob[~bad], ab[~bad])
+    assert rel_err_norm(w[~bad], w_or, floor=1.0) < 1e-6
+    assert not np.allclose(w[~bad], 1.0)

@@ -310,30 +310,36 @@ def test_T_critic_mode_ticks_in_one_launch_equal_T_single_ticks(name, mode, cs, 
     assert N.lib().rcg_tick_count(many._h) == N.lib().rcg_tick_count(one._h) == 4
 
 
-def test_many_weight_structures_loop_single_ticks():
+def test_many_weight_structures_in_one_launch():
     """Critic structures with >= 20 weights (here the kinematic robot's quad-lin: 20) are fitted by the four-lane kernel
-    (k_critic_fit_ml: variant bit 1024 of the fit's launch record); k_ticks_mem's critic phase is the one-lane fit, so
-    rcg_control_ticks refuses these handles and rcg_control_tick_n loops single ticks - bit-identical by construction."""
+    (k_critic_fit_ml: variant bit 1024 of the fit's launch record).  Round 5: k_ticks_mem has the same four-lane walk as its
+    critic phase for them (the wave's envs take its first quads), so rcg_control_ticks serves these handles too - bit-identical
+    to T single ticks; K < 4 (more than 16 envs per wave) is refused and rcg_control_tick_n loops single ticks there."""
     from rcognita_amd import _native as N
 
-    B, K, T = 130, 64, 5
+    B, T = 130, 5
+    for K in (64, 16, 4):
+        one, many, cfg = _pair("3wrobotNI", B, "f64", n_actor=5, mode=O.MODE_RQL, critic_struct=O.CRITIC_QUAD_LIN, n_critic=4,
+                               buffer_size=6)
+        assert cfg.dc == 20
+        x0 = rand_states(np.random.default_rng(3), "3wrobotNI", B) * 0.5
+        one.set_state(x0)
+        many.set_state(x0)
+        for _ in range(T):
+            one.control_tick(None, K=K)
+        ll = one.last_launch(N.KERNEL_CRITIC)
+        assert ll["kernel"] == "k_critic_fit" and (ll["variant"] & 1024) and ll["envs_per_wave"] == 16, ll
+        many.control_ticks(T, K)
+        ll = many.last_launch(N.KERNEL_ACTOR)
+        assert ll["kernel"] == "k_ticks" and (ll["variant"] & 16), ll  # k_ticks_mem
+        for f in FIELDS + ["FIELD_W_CRITIC", "FIELD_W_PREV", "FIELD_OBS_BUF", "FIELD_ACT_BUF"]:
+            np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f"K={K} {f}")
+        assert not np.allclose(many.get_field(N.FIELD_W_CRITIC), 1.0)
     one, many, cfg = _pair("3wrobotNI", B, "f64", n_actor=5, mode=O.MODE_RQL, critic_struct=O.CRITIC_QUAD_LIN, n_critic=4,
                            buffer_size=6)
-    assert cfg.dc == 20
-    x0 = rand_states(np.random.default_rng(3), "3wrobotNI", B) * 0.5
-    one.set_state(x0)
-    many.set_state(x0)
     with pytest.raises(N.NativeError) as ei:
-        many.control_ticks(T, K)
+        many.control_ticks(T, 1)
     assert ei.value.code == N.ERR_UNSUPPORTED
-    for _ in range(T):
-        one.control_tick(None, K=K)
-    many.control_tick(None, K=K, T=T)
-    ll = many.last_launch(N.KERNEL_CRITIC)
-    assert ll["kernel"] == "k_critic_fit" and (ll["variant"] & 1024) and ll["envs_per_wave"] == 16, ll
-    for f in FIELDS + ["FIELD_W_CRITIC", "FIELD_W_PREV", "FIELD_OBS_BUF", "FIELD_ACT_BUF"]:
-        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
-    assert not np.allclose(many.get_field(N.FIELD_W_CRITIC), 1.0)
 
 
 def test_critic_mode_small_batch_rate():
