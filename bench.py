@@ -81,7 +81,7 @@ def parse(argv=None):
                         "runs as two halves on two internal streams), 1 = never, 2 = whenever eligible")
     p.add_argument("--parts", type=int, default=None,
                    help="handles per GPU, each on a stream of its own (rcognita_amd.pool.MixedPool(parts=...)): the critic fit "
-                        "of one part runs under the actor kernel of another.  Default: 2 for --config C3, else 1")
+                        "of one part runs under the actor kernel of another.  Default: 1 (since round 5 an RQL / SQL handle splits its own tick, --tick-parts)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed (RCCL with --dist-backend nccl) even at world_size 1 and run every "
                         "collective of the N>1 path: communicator creation, device all_gather, all_reduce, barrier")
@@ -98,7 +98,7 @@ def parse(argv=None):
     if a.regime is None:
         a.regime = "generated" if a.config == "C5" else "streamed"
     if a.parts is None:
-        a.parts = 2 if a.config == "C3" else 1
+        a.parts = 1  # (round 4: 2 for C3 - two handles on two streams hid the critic fit; since round 5 ONE handle does that itself)
     if a.parts > 1 and a.config == "C5":
         p.error("--parts applies to the single-system configs (C5 already runs one handle per system type)")
     if a.config == "C5" and a.regime != "generated":
@@ -584,8 +584,8 @@ def main(argv=None):
         tick = lambda: eng.control_tick(cand, K=K)
     du, ds = (1, 2) if args.config == "C3" else (2, 5)
 
-    for e in engines:
-        e.set_tick_parts(args.tick_parts)
+    for e in engines:  # (several handles already overlap each other: no split inside them unless asked for)
+        e.set_tick_parts(args.tick_parts if (args.tick_parts or len(engines) == 1) else 1)
 
     def record_all():
         """One timing event per engine stream, recorded now (in-stream, no host wait).  A handle that splits its tick over two

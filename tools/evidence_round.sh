@@ -20,6 +20,7 @@ python bench.py --gpus 2 --dist-backend gloo --single-device --steps 100 --warmu
 python bench.py --parts 2 $B > "$O/${R}_bench_c2_two_handles.json" 2>> "$O/err.log"
 python bench.py --config C3 $B > "$O/${R}_bench_c3_two_handles.json" 2>> "$O/err.log"
 python bench.py --config C3 --parts 1 $B > "$O/${R}_bench_c3_one_handle.json" 2>> "$O/err.log"
+python bench.py --config C3 --parts 1 --tick-parts 1 $B > "$O/${R}_bench_c3_one_handle_unsplit.json" 2>> "$O/err.log"
 python bench.py --config C3 --dtype f64 $B > "$O/${R}_bench_c3_f64.json" 2>> "$O/err.log"
 python bench.py --config C3 --regime generated $B > "$O/${R}_bench_c3_generated.json" 2>> "$O/err.log"
 python bench.py --config C4 --steps 50 --warmup 10 $B > "$O/${R}_bench_c4_one_rank.json" 2>> "$O/err.log"
@@ -37,7 +38,9 @@ python tools/split_probe.py 2>/dev/null | grep "S =" > "$O/${R}_split_probe.txt"
 python tools/critic_fit_probe.py quadratic 2>/dev/null | grep -v amdgpu > "$O/${R}_critic_fit_probe.txt"
 [ -x build/event_probe ] && ./build/event_probe > "$O/${R}_event_probe.txt" 2>&1
 [ -f rcognita_amd/lib/librcg_dev.so ] && python tools/packed_sweep.py > "$O/${R}_packed_sweep.txt" 2>&1
-python -m pytest tests/test_hip_ref_traces.py tests/test_hip_configs.py -q -s -k "F7 or free_running or trace" 2>&1 | grep -E "^TRACE|FREE RUN|passed|failed" > "$O/${R}_trace_and_free_run_tests.txt"
+python -m pytest tests/test_hip_teacher_forced.py tests/test_hip_ref_traces.py tests/test_hip_configs.py -q -s -k "F7 or free_running or trace or teacher" 2>&1 | grep -E "^TRACE|^TEACHER|FREE RUN|passed|failed" > "$O/${R}_trace_and_free_run_tests.txt"
+python tools/valu_probe.py search 2>/dev/null | tail -1 > "$O/${R}_search_probe.json"
+python tools/fill_bw_probe.py 2>/dev/null > "$O/${R}_fill_bw_probe.txt"
 # round 4: T ticks per launch against per-tick launches (small batches), the optimiser's cost against SLSQP's, the search
 python -m pytest tests/test_hip_ticks.py -q -s -k "rate or launch_bound or persistent" 2>&1 | grep -E "B=|persistent|passed|failed" > "$O/${R}_ticks_rates.txt"
 python -m pytest tests/test_hip_optimizer.py tests/test_hip_search.py -q -s 2>&1 | grep -E "SLSQP|slsqp|search|gap|passed|failed" > "$O/${R}_optimizer_and_search_quality.txt"

@@ -60,6 +60,8 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu_p
   python3 tools/valu_probe.py pool > gpurun_out/valu_units_pool.json 2> gpurun_out/prof_valu_pool.log
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu_c3rql -o v -- \
   python3 tools/valu_probe.py c3rql > gpurun_out/valu_units_c3rql.json 2> gpurun_out/prof_valu_c3rql.log
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d gpurun_out/prof_valu_search -o v -- \
+  python3 tools/valu_probe.py search > gpurun_out/valu_units_search.json 2> gpurun_out/prof_valu_search.log
 fi
 if [ "$PART" != 1 ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_configs -o kt -- \
