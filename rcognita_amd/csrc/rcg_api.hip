@@ -904,14 +904,20 @@ int rcg_candidates_sample(rcg_handle* h, void* cand, int32_t K, int32_t round, c
   int KB = 256;
   while (KB > 64 && (size_t)rcg::cand_block_draws(KB, n_draws, h->du) * 32 > (size_t)48 * 1024) KB >>= 1;
   const size_t lds = (size_t)rcg::cand_block_draws(KB, n_draws, h->du) * 32;
-  if (lds > (size_t)64 * 1024)
+  if (lds > (size_t)160 * 1024)
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_candidates_sample: rows of %d reals need %zu B of LDS per 64 candidates", R, lds);
   if ((K + KB - 1) / KB > 65535) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_candidates_sample: K too large");
   const dim3 grid((unsigned)h->cfg.batch, (unsigned)((K + KB - 1) / KB)), block(256);
 #define RCG_SAMPLE(DU, real, P)                                                                                          \
-  hipLaunchKernelGGL((k_cand_sample<DU, real>), grid, block, lds, h->stream, (real*)cand, (const real*)centre, ep, st, (int)K, \
-                     (int)round, R, (uint64_t)h->cfg.seed, (int64_t)h->cfg.env_id_base, (real)h->cfg.action_init[0],       \
-                     (real)h->cfg.action_init[1], KB, P)
+  do {                                                                                                                   \
+    auto fn = k_cand_sample<DU, real>;                                                                                   \
+    if (lds > (size_t)64 * 1024) /* very long rows (R > 190): beyond the default dynamic-LDS limit */                    \
+      HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                    (int)lds));                                                                          \
+    hipLaunchKernelGGL(fn, grid, block, lds, h->stream, (real*)cand, (const real*)centre, ep, st, (int)K, (int)round, R, \
+                       (uint64_t)h->cfg.seed, (int64_t)h->cfg.env_id_base, (real)h->cfg.action_init[0],                  \
+                       (real)h->cfg.action_init[1], KB, P);                                                              \
+  } while (0)
   if (h->cfg.dtype == RCG_F64) {
     if (h->du == 1)
       RCG_SAMPLE(1, double, h->p64);

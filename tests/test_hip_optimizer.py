@@ -155,7 +155,9 @@ def test_optimizer_in_the_critic_modes_vs_reference_slsqp(name, cs, mode, dtype)
     U_or, J_or, its_or = O.actor_optimize(cfg, obs_r, st_r, O.action_sqn_init(cfg, ai), iters=30, w_critic=w_r)
     # the quasi-Newton path divides by curvature estimates: rounding-level differences between the kernel's fused
     # multiply-adds and numpy move the iterates, not the cost reached
-    assert np.max(np.abs(J - J_or) / scale) < (1e-6 if dtype == "f64" else 2e-3)
+    twin = float(np.max(np.abs(J - J_or) / scale))
+    print(f"F8c {name} {mode} {cs} {dtype}: |J - J_twin| / scale after 30 iterations: {twin:.2e} (gap to SLSQP above: the real guard)")
+    assert twin < (1e-6 if dtype == "f64" else 2e-3)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

@@ -43,7 +43,7 @@ python tools/valu_probe.py search 2>/dev/null | tail -1 > "$O/${R}_search_probe.
 python tools/fill_bw_probe.py 2>/dev/null > "$O/${R}_fill_bw_probe.txt"
 # round 4: T ticks per launch against per-tick launches (small batches), the optimiser's cost against SLSQP's, the search
 python -m pytest tests/test_hip_ticks.py -q -s -k "rate or launch_bound or persistent" 2>&1 | grep -E "B=|persistent|passed|failed" > "$O/${R}_ticks_rates.txt"
-python -m pytest tests/test_hip_optimizer.py tests/test_hip_search.py -q -s 2>&1 | grep -E "SLSQP|slsqp|search|gap|passed|failed" > "$O/${R}_optimizer_and_search_quality.txt"
+python -m pytest tests/test_hip_optimizer.py tests/test_hip_search.py -q -s 2>&1 | grep -E "SLSQP|slsqp|search|gap|twin|passed|failed" > "$O/${R}_optimizer_and_search_quality.txt"
 if [ -f rcognita_amd/lib/librcg_dev.so ]; then
   MODE=mpc bash tools/ab_min_k.sh > "$O/${R}_ab_min_k.txt" 2>&1
   MODE=crit bash tools/ab_min_k.sh 2>&1 | grep -E "==|AB" > "$O/${R}_ab_packed_critic.txt"

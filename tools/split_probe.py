@@ -29,6 +29,7 @@ for S in [int(v) for v in os.environ.get("SPLITS", "1,2,4,1,2").split(",")]:
         e = Engine(preset_engine_config("2tank", n, Nactor=Nh, mode="RQL", critic_struct="quadratic", Ncritic=4, buffer_size=10))
         st = torch.cuda.Stream()
         e.set_stream(st.cuda_stream)
+        e.set_tick_parts(int(os.environ.get("TICK_PARTS", "1")))  # 1: the handles' own split off (this tool measures handles on streams)
         e.set_state(x0[i * n:(i + 1) * n])
         engs.append(e)
         streams.append(st)
@@ -40,6 +41,8 @@ for S in [int(v) for v in os.environ.get("SPLITS", "1,2,4,1,2").split(",")]:
 
     for _ in range(400):
         tick()
+    for e in engs:  # (round 5) a handle that splits its own tick over two internal streams: order its stream behind them
+        e.join()
     a = [torch.cuda.Event(enable_timing=True) for _ in streams]
     b = [torch.cuda.Event(enable_timing=True) for _ in streams]
     here = [torch.cuda.Event() for _ in streams]  # align the streams on the device: the timed ticks start together
@@ -54,6 +57,8 @@ for S in [int(v) for v in os.environ.get("SPLITS", "1,2,4,1,2").split(",")]:
     T = 300
     for _ in range(T):
         tick()
+    for e in engs:
+        e.join()
     for ev, st in zip(b, streams):
         ev.record(st)
     torch.cuda.synchronize()
