@@ -272,8 +272,10 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
  * periods with the SAME candidate tensor (or the generated grid, cand == NULL) at every tick, any mode.  Handles of up to
  * 16384 envs run them as ONE launch: MPC on k_ticks (a caller's tensor: the wave's candidate rows are staged into LDS once
  * and re-walked T times; a tensor whose rows do not fit a wave's 32 KB AND that exceeds 128 MB - half the Infinity Cache -
- * would be re-staged from HBM by plain loads every tick and loops single ticks on k_actor_dma instead), RQL / SQL with the generated grid on k_ticks_mem; larger batches, and RQL / SQL with a caller's
- * tensor (their single ticks run on k_actor_dma), issue the launches of T single ticks without T trips through the
+ * would be re-staged from HBM by plain loads every tick and loops single ticks on k_actor_dma instead), RQL / SQL on k_ticks_mem
+ * - with the generated grid, and since round 5 with a caller's tensor as well (diagonal stage cost; the decision phase walks the
+ * tensor with the accumulation order of k_actor_dma / k_actor_dma_packed, the kernels of the single ticks); larger batches issue
+ * the launches of T single ticks without T trips through the
  * caller's FFI (a Python caller needs ~12 us per call, and a GPU that idles between short ticks clocks down).  Either way
  * every field ends as T single calls leave it, bit for bit; stops at the first error. */
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);

@@ -781,6 +781,22 @@ int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T) {
     if (rc != RCG_ERR_UNSUPPORTED) return rc;  // (no instance for this observation target: the loop below)
     h->err.clear();  // the refusal was this function's own probe, not the caller's error (rcg_last_error after RCG_OK)
   }
+  if (T > 1 && cand && h->cfg.mode != RCG_MODE_MPC && h->cfg.batch <= kPersistentTicksMaxBatch &&
+      h->cfg.n_critic - 1 >= 1 && h->cfg.n_critic - 1 <= kFitMaxRows && !(h->cfg.flags & RCG_FLAG_DISTURB) &&
+      h->p32.stage_kind == 0 && ticks_rows_stay_close(h, cand, K)) {
+    // RQL / SQL over a caller's tensor (round 5): k_ticks_mem with the streamed decision phase - the accumulation order of
+    // k_actor_dma / k_actor_dma_packed, so every field ends as T single ticks on those kernels leave it
+    DeviceGuard dev_guard(h);
+    int rc = check_candidates(h, "rcg_control_tick_n", cand, K);
+    if (rc) return rc;
+    rc = h->sys->ticks_mem(h, T, K, cand);
+    if (rc == RCG_OK) {
+      h->tick_count += T;
+      return rc;
+    }
+    if (rc != RCG_ERR_UNSUPPORTED) return rc;
+    h->err.clear();
+  }
   for (int32_t t = 0; t < T; ++t) {
     const int rc = rcg_control_tick(h, cand, K);
     if (rc) return rc;
@@ -800,7 +816,7 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K) {
       return rcg_fail(h, RCG_ERR_UNSUPPORTED,
                       "rcg_control_ticks: RQL/SQL need 1 <= Ncritic-1 <= %d rows and no disturbance model here (loop "
                       "rcg_control_tick)", kFitMaxRows);
-    rc = h->sys->ticks_mem(h, T, K);
+    rc = h->sys->ticks_mem(h, T, K, nullptr);
     if (rc == RCG_OK) h->tick_count += T;
     return rc;
   }

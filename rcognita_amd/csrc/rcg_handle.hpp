@@ -228,6 +228,6 @@ struct SysVTable {
   int (*search)(rcg_handle*, int32_t K, int32_t rounds, int32_t round0, const void* obs, const void* state_sys,
                 const void* centre, int shift, void* u_best, void* action, void* best_J, int32_t* best_idx, bool tick,
                 bool sim_first);
-  int (*ticks_mem)(rcg_handle*, int32_t T, int32_t K);  // RQL / SQL: T ticks in one launch (k_ticks_mem)
+  int (*ticks_mem)(rcg_handle*, int32_t T, int32_t K, const void* cand);  // RQL / SQL: T ticks in one launch (k_ticks_mem)
 };
 extern const SysVTable kVt3WRobot, kVt3WRobotNI, kVt2Tank;

@@ -462,7 +462,10 @@ __device__ __forceinline__ real rollout_dispatch(const KParams<real>& P, const t
   if (P.mode == RCG_MODE_MPC) return RCG_ROLL(RCG_MODE_MPC, -1, -1);
   if (P.mode == RCG_MODE_RQL && P.stage_kind == 0) {
 #define RCG_ROLL_G1(C) rollout_cost<Sys, real, TGT, STREAM, RCG_MODE_RQL, 0, C, true>(P, pre, N, xs, y0, urow, ugen, wget, u0)
-    if (P.gamma == (real)1) {  // wave-uniform: per-component stage sums over the first N - 1 steps
+    // (generated candidates only: a STREAMED row is accumulated as k_actor_dma / k_actor_dma_packed accumulate it - gamma^k rho_k
+    // step by step - so that the decision phase of k_ticks_mem over a caller's tensor, which is this code, leaves the bits the
+    // single ticks on those kernels leave: round 5)
+    if (P.gamma == (real)1 && !STREAM) {  // wave-uniform: per-component stage sums over the first N - 1 steps
       switch (P.critic_struct) {
         case RCG_CRITIC_QUAD_LIN: return RCG_ROLL_G1(RCG_CRITIC_QUAD_LIN);
         case RCG_CRITIC_QUADRATIC: return RCG_ROLL_G1(RCG_CRITIC_QUADRATIC);

@@ -18,7 +18,7 @@
   X int rcg::op_actor<RCG_S>(rcg_handle*, const char*, const void*, int, const void*, const void*, const void*, void*, \
                              void*, void*, int32_t*, bool, bool);
 #define RCG_OP_TICKS(X) X int rcg::op_ticks<RCG_S>(rcg_handle*, int32_t, int32_t, const void*);
-#define RCG_OP_TICKS_MEM(X) X int rcg::op_ticks_mem<RCG_S>(rcg_handle*, int32_t, int32_t);
+#define RCG_OP_TICKS_MEM(X) X int rcg::op_ticks_mem<RCG_S>(rcg_handle*, int32_t, int32_t, const void*);
 #define RCG_OP_OPT(X)                                                                                                  \
   X int rcg::op_optimize<RCG_S>(rcg_handle*, int32_t, const void*, const void*, const void*, int, void*, void*, void*, \
                                 int32_t*, bool, bool);                                                                 \

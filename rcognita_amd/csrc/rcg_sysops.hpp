@@ -853,7 +853,7 @@ static bool ticks_mem_ok(const rcg_handle* h) {
 }
 
 template <typename Sys>
-int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
+int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K, const void* cand) {
   constexpr int DU = Sys::DU;
   const rcg_cfg& c = h->cfg;
   if (!ticks_mem_ok<Sys>(h)) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_ticks: no persistent RQL/SQL instance for this observation target");
@@ -866,6 +866,7 @@ int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
     TicksMemArgs<real> M;
     memset(&M, 0, sizeof M);
     ActorArgs<real>& A = M.A;
+    A.cand = (const real*)cand;  // nullptr: the generated grid
     A.obs = (const real*)h->f[RCG_FIELD_STATE];
     A.state_sys = (const real*)h->f[(c.flags & RCG_FLAG_REF_LAG) ? RCG_FIELD_STATE_PREV : RCG_FIELD_STATE];
     A.pars_env = (const real*)h->f[RCG_FIELD_PARS];
@@ -887,8 +888,13 @@ int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
       A.G = 64 / kp;
       A.n_tiles = 1;
     }
-    A.grid_g = DU == 1 ? K : (int)std::floor(std::sqrt((double)K) + 1e-9);
+    A.grid_g = cand ? 0 : (DU == 1 ? K : (int)std::floor(std::sqrt((double)K) + 1e-9));
     A.no_multi = dev_knobs().no_gen_multi ? 1 : 0;
+    const size_t row_bytes = (size_t)c.n_actor * DU * sizeof(real);
+    A.vec_ok = (cand && row_bytes % 16 == 0 && ((uintptr_t)cand % 16) == 0) ? 1 : 0;
+    const size_t lds = cand ? (size_t)4 * 64 * row_bytes : 0;  // four waves, a 64-row tile each
+    if (lds > (size_t)64 * 1024)
+      return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick_n: rows of %zu bytes do not fit the persistent kernel's tiles", row_bytes);
     FitArgs<real>& F = M.F;
     F.w_critic = (real*)h->f[RCG_FIELD_W_CRITIC];
     F.w_prev = (real*)h->f[RCG_FIELD_W_PREV];
@@ -915,9 +921,13 @@ int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
     ProfScope prof_scope(h, RCG_KERNEL_ACTOR);
 #define RCG_TM(CS)                                                                                              \
   do {                                                                                                          \
-    if (m <= 3)                                                                                                 \
-      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, 3, Sys::TGT, (CriticDim<CS, Sys::DS, Sys::DU>::value >= kFitLanesMinDc)>), \
-                 grid, block, 0, M, h->p64, P);                                                                 \
+    constexpr bool ml_ = CriticDim<CS, Sys::DS, Sys::DU>::value >= kFitLanesMinDc;                              \
+    if (m <= 3 && cand)                                                                                         \
+      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, 3, Sys::TGT, ml_, true>), grid, block, lds, M, h->p64, P);      \
+    else if (m <= 3)                                                                                            \
+      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, 3, Sys::TGT, ml_, false>), grid, block, 0, M, h->p64, P);       \
+    else if (cand)                                                                                              \
+      RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, kFitMaxRows, Sys::TGT, false, true>), grid, block, lds, M, h->p64, P); \
     else                                                                                                        \
       RCG_LAUNCH(h, (k_ticks_mem<Sys, real, CS, kFitMaxRows, Sys::TGT>), grid, block, 0, M, h->p64, P);        \
   } while (0)
@@ -928,7 +938,7 @@ int op_ticks_mem(rcg_handle* h, int32_t T, int32_t K) {
       default: RCG_TM(RCG_CRITIC_QUAD_MIX); break;
     }
 #undef RCG_TM
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_TICKS, 16 | 1 | (Sys::TGT ? 2 : 0), A.G);  // variant bit 4: k_ticks_mem
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_TICKS, 16 | 1 | (Sys::TGT ? 2 : 0) | (cand ? 4 : 0), A.G);  // variant bit 4: k_ticks_mem
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });

@@ -290,9 +290,12 @@ struct TicksMemArgs {
 
 // ML (round 5): the critic structures with >= 20 weights, whose single ticks fit with FOUR LANES PER ENV (k_critic_fit_ml): the
 // wave's envs (G <= 16) take the quads 0 .. G - 1 of the wave for phase 1 - critic_update_env_ml, the body of that kernel.
-template <typename Sys, typename real, int CS, int MAXM, bool TGT, bool ML = false>
+// STREAM (round 5): the decision phase walks a caller's tensor (actor_wave's streamed form: the wave's tile staged through
+// LDS every tick - at the batch sizes this launch is for the tensor stays in L2 / the Infinity Cache).
+template <typename Sys, typename real, int CS, int MAXM, bool TGT, bool ML = false, bool STREAM = false>
 __global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, const KParams<double> P64,
                                                    const KParams<real> P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_tm[];
   const int lane = threadIdx.x & 63;
   const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
@@ -313,7 +316,12 @@ __global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    actor_wave<Sys, real, true, TGT, false>(M.A, P, wave, nullptr);
+    if constexpr (STREAM) {
+      real* const lds = reinterpret_cast<real*>(smem_raw_tm) + (size_t)wave_in_wg * 64 * (P.n_actor * Sys::DU);
+      actor_wave<Sys, real, true, TGT, true>(M.A, P, wave, lds);
+    } else {
+      actor_wave<Sys, real, true, TGT, false>(M.A, P, wave, nullptr);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -157,7 +157,7 @@ def test_optimizer_in_the_critic_modes_vs_reference_slsqp(name, cs, mode, dtype)
     # multiply-adds and numpy move the iterates, not the cost reached
     twin = float(np.max(np.abs(J - J_or) / scale))
     print(f"F8c {name} {mode} {cs} {dtype}: |J - J_twin| / scale after 30 iterations: {twin:.2e} (gap to SLSQP above: the real guard)")
-    assert twin < (1e-6 if dtype == "f64" else 2e-3)
+    assert twin < (1e-7 if dtype == "f64" else 1e-3)  # measured (profiles/r05_optimizer_and_search_quality.txt): <= 3.9e-9 / 4.0e-4
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])

@@ -360,3 +360,76 @@ def test_critic_mode_small_batch_rate():
         rates[tag] = 3 * T * B / (time.perf_counter() - t0)
     print(f"\nRQL B={B} K={K}: {rates}")
     assert rates["one_launch"] > 1.2 * rates["per_tick_launches"]
+
+
+CRITIC_FIELDS = FIELDS + ["FIELD_W_CRITIC", "FIELD_W_PREV", "FIELD_OBS_BUF", "FIELD_ACT_BUF"]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name,mode,cs,K,B,kw", [
+    ("2tank", "RQL", "quadratic", 64, 1024, {}),                    # configs[2]'s controller; single ticks: k_actor_dma
+    ("2tank", "SQL", "quad-lin", 48, 515, {}),                      # one ragged tile per env on k_actor_dma
+    ("2tank", "RQL", "quad-nomix", 16, 130, dict(ref_lag=True)),    # four envs per tile: k_actor_dma_packed
+    ("3wrobot", "RQL", "quad-nomix", 64, 300, {}),
+    ("3wrobot", "SQL", "quad-nomix", 8, 77, {}),                    # packed, eight envs per tile
+    ("3wrobot", "RQL", "quad-lin", 64, 130, {}),                     # 35 weights: the four-lane fit, weights parked in LDS by k_actor_dma
+    ("3wrobotNI", "SQL", "quad-mix", 128, 66, {}),
+    ("3wrobotNI", "RQL", "quad-mix", 33, 40, {}),                    # K = 33: one ragged tile
+])
+def test_streamed_critic_mode_T_ticks_in_one_launch_equal_T_single_ticks(name, mode, cs, K, B, kw, dtype):
+    """Round 5: rcg_control_tick_n with a caller's tensor on an RQL / SQL handle - ONE launch of k_ticks_mem whose decision phase
+    walks the tensor (actor_wave's streamed form, with the accumulation order of the streamed production kernels) against T
+    single ticks on k_actor_dma / k_actor_dma_packed: every field bit-identical, weights and buffers included, kernel
+    identities asserted."""
+    from rcognita_amd import _native as N
+    from tests.helpers import assert_kernel
+
+    rng = np.random.default_rng(K * 11 + B)
+    T, Nh = 6, 5
+    one, many, cfg = _pair(name, B, dtype, n_actor=Nh, mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs], n_critic=4,
+                           buffer_size=6, **kw)
+    x0 = rand_states(rng, name, B) * (0.5 if name != "2tank" else 1.0)
+    lo, hi = cfg.ctrl_bnds[:, 0], cfg.ctrl_bnds[:, 1]
+    c = (lo + (hi - lo) * rng.random((B, K, Nh, cfg.du))).astype(one.real)
+    ca, cb = one.to_device(c), many.to_device(c)
+    one.set_state(x0)
+    many.set_state(x0)
+    for _ in range(T):
+        one.control_tick(ca, K=K)
+    many.control_tick(cb, K=K, T=T)
+    ll = assert_kernel(many, "k_ticks")
+    assert (ll["variant"] & 16) and (ll["variant"] & 4), ll  # k_ticks_mem, streamed
+    # (K = 33 rows of 40 bytes in f32 are not a whole number of 16-byte pieces per env: k_actor serves those single ticks)
+    assert one.last_launch(N.KERNEL_ACTOR)["kernel"] in ("k_actor_dma", "k_actor_dma_packed", "k_actor")
+    for f in CRITIC_FIELDS:
+        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+    assert not np.allclose(many.get_field(N.FIELD_W_CRITIC), 1.0)
+    assert N.lib().rcg_tick_count(many._h) == N.lib().rcg_tick_count(one._h) == T
+    many.control_tick(cb, K=K)
+    one.control_tick(ca, K=K, T=1)
+    for f in CRITIC_FIELDS:
+        np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f)
+
+
+def test_streamed_critic_mode_small_batch_rate():
+    """configs[2]'s controller at B = 1024 with a caller's tensor (launch-bound under two launches per tick): T ticks in one
+    launch against the loop of single ticks issued from one native call (bar of VERDICT r4: 2 x)."""
+    import torch
+
+    B, K, T, Nh = 1024, 64, 128, 10
+    rates = {}
+    for tag in ("per_tick_launches", "one_launch"):
+        eng, cfg = both("2tank", B, "f32", n_actor=Nh, mode=O.MODE_RQL, critic_struct=O.CRITIC_QUADRATIC, n_critic=4, buffer_size=10)
+        eng.set_state(rand_states(np.random.default_rng(1), "2tank", B))
+        cand = torch.rand((B, K, Nh, 1), device="cuda").contiguous()
+        torch.cuda.synchronize()
+        step = (lambda: [eng.control_tick(cand, K=K) for _ in range(T)]) if tag == "per_tick_launches" else (lambda: eng.control_tick(cand, K=K, T=T))
+        step()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        eng.synchronize()
+        rates[tag] = 3 * T * B / (time.perf_counter() - t0)
+    print(f"\nstreamed RQL B={B} K={K}: {rates}")
+    assert rates["one_launch"] >= 1.5 * rates["per_tick_launches"], rates
