@@ -848,8 +848,11 @@ __device__ __forceinline__ real accum_update(const KParams<real>& P, const real*
 
 // The decision of one wave's env(s): K x _actor_cost + argmin + tick epilogue.  The body of k_actor, and of the decision
 // phase of k_ticks_mem (rcg_ticks.hpp).  `wave`: the wave's index in the grid (wave-uniform), `lds`: its LDS region (streamed).
+// `staged` (k_ticks_mem over a caller's tensor, ticks after the first, one tile per wave): the wave's tile is still in its LDS
+// region from the previous tick - nothing else writes there - and is not staged again.
 template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false>
-__device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KParams<real>& P, const long wave, real* const lds) {
+__device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KParams<real>& P, const long wave, real* const lds,
+                                           const bool staged = false) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
   const int lane = threadIdx.x & 63;
   const long B = P.B;
@@ -918,11 +921,13 @@ __device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KPara
     if (STREAM) {
       const long row0 = big ? b * K + (long)t * 64 : wave * A.G * (long)K;
       const int nrows = big ? (K - t * 64 < 64 ? K - t * 64 : 64) : envs_here * K;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous tile's LDS reads are done
-      stage_tile<real>(A.cand + row0 * R, lds, nrows * R, lane, A.vec_ok);
-      // LDS ops of one wave are executed in order; wait for our own writes, no workgroup barrier
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
+      if (!staged) {  // wave-uniform
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous tile's LDS reads are done
+        stage_tile<real>(A.cand + row0 * R, lds, nrows * R, lane, A.vec_ok);
+        // LDS ops of one wave are executed in order; wait for our own writes, no workgroup barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
       r = valid ? (big ? kl : e * K + kl) : 0;
     } else {
       gen_candidate<DU, real>(P, A.grid_g, k, ugen);

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, c
     __builtin_amdgcn_wave_barrier();
     if constexpr (STREAM) {
       real* const lds = reinterpret_cast<real*>(smem_raw_tm) + (size_t)wave_in_wg * 64 * (P.n_actor * Sys::DU);
-      actor_wave<Sys, real, true, TGT, true>(M.A, P, wave, lds);
+      actor_wave<Sys, real, true, TGT, true>(M.A, P, wave, lds, t > 0 && M.A.n_tiles == 1);  // one tile per wave: it stays
     } else {
       actor_wave<Sys, real, true, TGT, false>(M.A, P, wave, nullptr);
     }
