@@ -813,6 +813,8 @@ def main(argv=None):
             traffic = None
     if traffic is not None and per_launch is not None and len(engines) > 1:
         traffic *= len(engines)  # tick level, as `achieved`
+    if traffic is not None and split_inside and len(engines) == 1:
+        traffic *= 2  # the stored counter pass saw the tick's two half-batch launches one by one: tick level, as `achieved`
     kinfo = launch_info[0]
     width = "float32 storage and arithmetic (SURVEY 8a-1 / 8d; the reference computes in float64: value_f64 / roofline_f64)" \
         if args.dtype == "f32" else "float64, the reference's width"
