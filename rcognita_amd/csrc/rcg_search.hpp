@@ -200,7 +200,7 @@ struct SearchArgs {
 // per-wave LDS: tile [64][R] | centre [R].  Runtime-horizon instances build and walk the lane's row in the tile; the
 // register-row instances park there the best row each lane has met in the round, so that the winner's row is one LDS copy
 // (regenerating it from its counters cost a draw, eight normals and a select tree per round and wave)
-__host__ __device__ constexpr int search_lds_reals(int R, bool /*reg_rows*/) { return 65 * R; }
+__host__ __device__ constexpr int search_lds_reals(int R, bool /*reg_rows*/) { return (65 * R + 3) & ~3; }  // (a whole number of 16-byte pieces per wave)
 
 template <typename Sys, typename real, bool GENERIC, bool TGT, int NC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC > 0 && sizeof(real) == 4 ? 4 : 1))) void k_actor_search(const SearchArgs<real> A, const KParams<real> P) {
@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC > 0 && s
   const int K = A.K, N = NC > 0 ? NC : P.n_actor, R = N * DU;
   real* const wave_lds = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * search_lds_reals(R, NC > 0);
   real* const tile = wave_lds;
-  real* const centre = wave_lds + 64 * R;
+  // (16-byte aligned: the wave's region is a whole number of 16-byte pieces and 64 rows are 256 R bytes - the centre's reads
+  // become ds_read_b128)
+  real* const centre = static_cast<real*>(__builtin_assume_aligned(wave_lds + 64 * R, 16));
   real* const myrow = tile + (size_t)lane * R;
 
   real y0[DS], xs[DS];

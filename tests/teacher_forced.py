@@ -63,9 +63,10 @@ class Tally:
                 f"{self.n_sharp} of {self.n_comp} (tick, component) pairs, worst |du| / tau {self.worst_a:.3f}")
 
 
-def check_tick(tally, cfg, z, i, w_dev, u_dev, fracs):
+def check_tick(tally, cfg, z, i, w_dev, u_dev, fracs, p_tol=1e-9):
     """``w_dev``: the weights the fit under test returned for tick ``i`` (None if the reference did not refit there);
-    ``u_dev [N, du]``: the sequence the actor under test returned with the reference's weights."""
+    ``u_dev [N, du]``: the sequence the actor under test returned with the reference's weights; ``p_tol``: relative slack of the
+    fit-objective comparison (1e-9 for float64 arithmetic; a float32 handle stores buffers and weights in float32)."""
     obs, xs = z["tick_obs"][i], z["tick_state_sys"][i]
     tally.n_ticks += 1
     if w_dev is not None:
@@ -83,7 +84,7 @@ def check_tick(tally, cfg, z, i, w_dev, u_dev, fracs):
         p_dev = jc + 0.5 * mu * float(np.sum((w_dev - w0) ** 2))
         p_ref = jc_ref + 0.5 * mu * float(np.sum((z["tick_w"][i] - w0) ** 2))
         tally.worst_p = max(tally.worst_p, (p_dev - p_ref) / max(p_ref, 1e-300))
-        if not p_dev <= p_ref * (1 + 1e-9) + 1e-12:
+        if not p_dev <= p_ref * (1 + p_tol) + 1e-12:
             tally.failures.append(f"tick {i}: regularised objective {p_dev:.10g} above its value at SLSQP's weights {p_ref:.10g}")
         lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
         if np.any(w_dev < lo - 1e-9) or np.any(w_dev > hi + 1e-9):

@@ -41,7 +41,7 @@ STATE_BAND = 0.05
 RATE = {"3wrobot": {3: 30.0, 4: 100.0}}
 
 
-def make_loop_objects(name, mode, Nactor, t1, x0=None, critic_struct="quad-nomix", **ctrl_kw):
+def make_loop_objects(name, mode, Nactor, t1, x0=None, critic_struct="quad-nomix", dtype="f64", **ctrl_kw):
     """System, controller and simulator wired as the reference's presets wire them (presets/main_3wrobot.py:199-300)."""
     from rcognita_amd import controllers, simulator, systems
 
@@ -51,7 +51,7 @@ def make_loop_objects(name, mode, Nactor, t1, x0=None, critic_struct="quad-nomix
     dt = p["dt"]
     my_sys = getattr(systems, CLS[name])(sys_type="diff_eqn", dim_state=ds, dim_input=du, dim_output=ds, dim_disturb=dd,
                                          pars=list(p["pars"]), ctrl_bnds=ctrl_bnds, is_dyn_ctrl=0, is_disturb=0,
-                                         pars_disturb=[], dtype="f64")
+                                         pars_disturb=[], dtype=dtype)
     x0 = np.array(p["x0"] if x0 is None else x0, dtype=float)
     my_ctrl = controllers.CtrlOptPred(du, ds, mode, ctrl_bnds=ctrl_bnds, action_init=[0.5] if name == "2tank" else [],
                                       t0=0, sampling_time=dt, Nactor=Nactor, pred_step_size=dt * p["mult"],
@@ -61,12 +61,12 @@ def make_loop_objects(name, mode, Nactor, t1, x0=None, critic_struct="quad-nomix
                                       critic_struct=critic_struct, stage_obj_struct="quadratic",
                                       stage_obj_pars=[np.diag(np.array(p["R1"], dtype=float))],
                                       observation_target=[] if p["target"] is None else np.array(p["target"]),
-                                      dtype="f64", **ctrl_kw)
+                                      dtype=dtype, **ctrl_kw)
     # simulation steps of dt / 2: what the reference's solver takes (max_step = dt / 2 hard-coded, simulator.py:150)
     my_sim = simulator.Simulator(sys_type="diff_eqn", closed_loop_rhs=my_sys.closed_loop_rhs, sys_out=my_sys.out,
                                  state_init=x0, disturb_init=[], action_init=np.zeros(du), t0=0, t1=t1, dt=dt / 2,
                                  max_step=dt / 2, first_step=1e-6, atol=1e-5, rtol=1e-3, is_disturb=0, is_dyn_ctrl=0,
-                                 dtype="f64")
+                                 dtype=dtype)
     return my_sys, my_ctrl, my_sim
 
 

@@ -23,15 +23,19 @@ from tests.test_hip_ref_traces import make_loop_objects
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name,cs", CASES)
-def test_teacher_forced_replay_of_the_reference_loop_through_the_mirror_classes(name, cs, mode):
+def test_teacher_forced_replay_of_the_reference_loop_through_the_mirror_classes(name, cs, mode, dtype):
+    """``dtype``: the width of the handles behind the mirror classes - float64 (their default, the reference's width) and
+    float32 (the production width: buffers, weights and sequences pass through float32 on the device; the fit itself is
+    float64 inside either way, its objective is compared at 1e-5)."""
     meta, z = load_golden(f"F7c_trace_{name}_{mode}_{cs}")
     cfg = trace_cfg(meta)
     ds, du, _ = DIMS[name]
     dt, N = meta["dt"], meta["Nactor"]
-    _, ctrl, _ = make_loop_objects(name, mode, N, meta["t1"], x0=meta["x0"], critic_struct=cs)
-    tally = TF.Tally(f"(mirror classes, f64) {name} {mode} {cs}")
+    _, ctrl, _ = make_loop_objects(name, mode, N, meta["t1"], x0=meta["x0"], critic_struct=cs, dtype=dtype)
+    tally = TF.Tally(f"(mirror classes, {dtype}) {name} {mode} {cs}")
     for i in range(len(z["tick_t"])):
         t, obs = float(z["tick_t"][i]), z["tick_obs"][i]
         ob, ab = z["tick_obs_buf"][i], z["tick_act_buf"][i]
@@ -49,12 +53,14 @@ def test_teacher_forced_replay_of_the_reference_loop_through_the_mirror_classes(
         w_dev = np.array(ctrl.w_critic, dtype=float).reshape(-1) if fitted else None
         if not fitted:
             assert np.array_equal(np.asarray(ctrl.w_critic, dtype=float).reshape(-1), z["tick_w_prev"][i])
+        if dtype == "f32" and w_dev is not None:  # what the fit saw is the float32 image of the stack: the weights stay in the box
+            w_dev = np.clip(w_dev, *TF.O.critic_bounds(cfg.critic_struct, cfg.dc))
         # the actor on the reference's weights
         ctrl.w_critic = z["tick_w"][i].copy()
         a = ctrl._actor_optimizer(obs)
         u_dev = np.asarray(ctrl._prev_opt, dtype=float).reshape(N, du)
         assert np.array_equal(np.asarray(a, dtype=float).reshape(-1), u_dev[0])
-        TF.check_tick(tally, cfg, z, i, w_dev, u_dev, meta["first_fracs"])
+        TF.check_tick(tally, cfg, z, i, w_dev, u_dev, meta["first_fracs"], p_tol=1e-9 if dtype == "f64" else 1e-5)
     print("\n" + tally.line())
     assert not tally.failures, "\n".join(tally.failures[:10])
     assert tally.n_sharp > 0, "no tick of this trace pins the first action: the fixture cannot falsify the actor"
