@@ -54,6 +54,7 @@ struct rcg_handle {
   // two handles on two streams, MixedPool(parts=2) - the latency-bound fit of one half runs under the streaming kernel of the
   // other, tick after tick (the halves never meet: envs are independent).  The handle's own stream rejoins them the next
   // time anything else is asked of the handle (join_split, called by DeviceGuard).
+  void* bounce;                // pinned host buffer (kBounceBytes, allocated on first use): small device-to-host reads land here
   int tick_parts;              // rcg_set_tick_parts: 0 auto (2 from kSplitMinBatch envs), 1 never, 2 whenever the tick is eligible
   hipStream_t split_stream[2];  // created on first use
   hipEvent_t split_fork, split_join[2];
@@ -67,6 +68,7 @@ struct rcg_handle {
 };
 static constexpr size_t kProfMaxSamples = 65536;
 
+static constexpr size_t kBounceBytes = 16384;  // host reads up to this size go through the handle's pinned buffer
 static constexpr int kSplitMinBatch = 65536;   // envs from which an eligible tick is split by default
 static constexpr int kVariantSplitBit = 4096;  // rcg_last_launch: the launch served one half of a split tick
 static inline void note_launch(rcg_handle* h, int kind, int kernel_id, int variant, int envs_per_wave) {
