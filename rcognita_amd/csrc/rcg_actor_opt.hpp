@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
     for (int k = 0; k < N; ++k) {
       real u[DU];
 #pragma unroll
-      for (int c = 0; c < DU; ++c) u[c] = clamp_r<real>(fma_r(-alpha, de[k * DU + c], ue[k * DU + c]), P.lo[c], P.hi[c]);
+      for (int c = 0; c < DU; ++c)  // (finite: a direction that is not finite has ended the env's search in phase 1)
+        u[c] = clamp_fin(fma_r(-alpha, de[k * DU + c], ue[k * DU + c]), P.lo[c], P.hi[c]);
       if (k > 0) {
         real d[DS];
         // f32: hardware v_sin/v_cos behind the exact reduction, as in every f32 rollout of the build (the trial

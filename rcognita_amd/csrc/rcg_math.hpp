@@ -114,6 +114,11 @@ __device__ __forceinline__ real clamp_r(real v, real lo, real hi) {
   return v < lo ? lo : (v > hi ? hi : v);
 }
 
+// np.clip for a FINITE v and lo <= hi (generated candidates, trial points of the line search): one v_med3_f32 instead of two
+// compares and two selects; the same value as clamp_r for every finite input (a NaN would come out as a bound)
+__device__ __forceinline__ float clamp_fin(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+__device__ __forceinline__ double clamp_fin(double v, double lo, double hi) { return __builtin_fmin(__builtin_fmax(v, lo), hi); }
+
 template <typename real>
 __device__ __forceinline__ bool finite_r(real v) {
   return __builtin_isfinite(v);

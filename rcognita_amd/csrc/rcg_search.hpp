@@ -80,10 +80,6 @@ __device__ __forceinline__ float pick8(const float* n, int q) {
   return (q & 4) ? b1 : b0;
 }
 
-// np.clip for a finite v and lo <= hi (candidates are finite by construction): one v_med3_f32 instead of two compares and two
-// selects per row element
-__device__ __forceinline__ float clamp_fin(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
-__device__ __forceinline__ double clamp_fin(double v, double lo, double hi) { return __builtin_fmin(__builtin_fmax(v, lo), hi); }
 
 // first per-step candidate: the last quarter of the K candidates draws one normal per input AND step, the others one per input
 // (round 4: the last half - on the reference's own decisions, fixtures F8, the search ends within 0.40 % of SLSQP's cost either
