@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The reference's headless preset loop through the drop-in classes at B = 1 (the 3-wheel robot, MPC, Nactor = 5, simulation steps of
+dt / 2): simulation steps per second and where the host time goes (cProfile).  GPU box only.   python tools/b1_profile.py"""
 import cProfile, pstats, sys, time
 sys.path.insert(0,'.')
 import numpy as np
