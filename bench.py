@@ -1078,13 +1078,20 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
         eng2.control_tick(None, K=K)
     # wall rate first, un-sampled (a launch that carries start / stop events costs the stream ~7 us: 10 % of this tick),
     # then the kernel's own duration on every launch of a second loop
-    n2 = max(100, args.steps // 4)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
+    # (device time between two in-stream events behind a short spin, as the headline is taken: round 4 read the host clock
+    # around 100 ticks from an empty queue, which charged the launch ramp and the final synchronize - 1 to 2 of 5 ms - to the rate)
+    n2 = max(400, args.steps // 2)
+    st2 = torch.cuda.current_stream()  # the stream the engines were given (main() passes its pointer)
+    assert st2.cuda_stream == stream_ptr, (st2.cuda_stream, stream_ptr)
+    ea2, eb2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(100):
+        eng2.control_tick(None, K=K)
+    ea2.record(st2)
     for _ in range(n2):
         eng2.control_tick(None, K=K)
+    eb2.record(st2)
     torch.cuda.synchronize()
-    d2 = time.perf_counter() - t1
+    d2 = ea2.elapsed_time(eb2) * 1e-3
     eng2.profile((N.KERNEL_ACTOR,), stride=1)
     for _ in range(max(10, args.steps // 4)):
         eng2.control_tick(None, K=K)
