@@ -613,11 +613,19 @@ int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state
     A.memory = opt_memory_of(h);
     const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
     A.dcw = c.mode != RCG_MODE_MPC ? h->dc : 0;
-    // waves per block: 4 (one per SIMD) while the block's LDS fits the CU's 160 KB, else 2 or 1 (long horizons in f64
-    // with curvature pairs: 3wrobot N = 20, f64, 4 pairs needs 70 KB per wave)
+    // waves per block: the waves of a block do not cooperate, so the block size only decides how many waves of LDS fit a CU's
+    // 160 KB: 4 (one per SIMD) unless 2 or 1 bring more waves onto the CU (quad-mix on the 3-wheel robot with 4 pairs: 20.4 KB
+    // per wave = ONE block of four, but seven blocks of one; long horizons in f64: N = 20, 4 pairs needs 70 KB per wave)
     const size_t lds_wave = opt_wave_lds_bytes(h);
     int wpb = 4;
-    while (wpb > 1 && lds_wave * wpb > (size_t)160 * 1024) wpb >>= 1;
+    size_t on_cu = 0;
+    for (int cand_wpb = 4; cand_wpb >= 1; cand_wpb >>= 1) {
+      const size_t fit = lds_wave * cand_wpb ? ((size_t)160 * 1024 / (lds_wave * cand_wpb)) * cand_wpb : 0;
+      if (fit > on_cu) {
+        on_cu = fit;
+        wpb = cand_wpb;
+      }
+    }
     const size_t lds = lds_wave * wpb;
     if (lds > (size_t)160 * 1024)
       return rcg_fail(h, RCG_ERR_UNSUPPORTED,
