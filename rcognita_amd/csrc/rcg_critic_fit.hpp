@@ -89,6 +89,11 @@ struct FitArgs {
   const real* state;      // [ds][B] do_push: the observation to push (= sim.state)
   const real* action;     // [du][B] do_push: the held action (action_curr)
   int env_lo, env_hi;     // the envs [env_lo, env_hi) this launch serves (env_hi == 0: the whole batch)
+  // k_ticks_mem only (0 elsewhere): the two buffers as RINGS while the launch runs - ring = 1 + the physical row this push overwrites
+  // (the oldest); logical row r after the push is physical row (ring + r) mod buffer_size.  The physical shift of a push is two
+  // dependent load -> store passes over the rows (buffer_size 10: ~3 us of a 20 us tick on a wave that runs alone on its SIMD);
+  // the launch rotates the rows back into place after its last tick (critic_ring_unrotate), so every launch starts and ends canonical.
+  int ring;
 };
 
 // The part of an env's critic update that precedes the solver: [env step] -> [push] -> TD stack (A, b) and the box.  `store`:
@@ -118,13 +123,21 @@ __device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KP
   }
   real ko[KEEP][DS], ka[KEEP][DU];  // do_push: old rows 1 .. KEEP (= new rows 0 .. KEEP - 1); else rows 0 .. KEEP - 1
   const int koff = F.do_push ? 1 : 0;
+  const int ring = F.ring;  // > 0: ring mode (with do_push)
+  // physical row of the row that is logical row r once this call's push is done
+  auto phys = [&](int r) -> int {
+    if (!ring) return r;
+    const int p = ring + r;
+    return p >= bs ? p - bs : p;
+  };
 #pragma unroll
   for (int k = 0; k < KEEP; ++k)
     if (k + koff < bs) {
+      const int pr = ring ? phys(k) : k + koff;
 #pragma unroll
-      for (int c = 0; c < DS; ++c) ko[k][c] = F.obs_buf[((long)(k + koff) * DS + c) * B + b];
+      for (int c = 0; c < DS; ++c) ko[k][c] = F.obs_buf[((long)pr * DS + c) * B + b];
 #pragma unroll
-      for (int c = 0; c < DU; ++c) ka[k][c] = F.act_buf[((long)(k + koff) * DU + c) * B + b];
+      for (int c = 0; c < DU; ++c) ka[k][c] = F.act_buf[((long)pr * DU + c) * B + b];
     }
 
   if (F.do_sim || F.do_push) {
@@ -153,7 +166,20 @@ __device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KP
         }
       }
     }
-    if (F.do_push) {  // push_vec on both buffers: drop row 0, append (obs, action_curr) at the bottom (utilities.py:78-79)
+    if (F.do_push && ring) {  // ring mode: the new row takes the oldest row's place, nothing else moves
+#pragma unroll
+      for (int c = 0; c < DS; ++c) if (store) F.obs_buf[((long)(ring - 1) * DS + c) * B + b] = xs[c];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) if (store) F.act_buf[((long)(ring - 1) * DU + c) * B + b] = ua[c];
+#pragma unroll
+      for (int k = 0; k < KEEP; ++k)
+        if (k == bs - 1) {
+#pragma unroll
+          for (int c = 0; c < DS; ++c) ko[k][c] = xs[c];
+#pragma unroll
+          for (int c = 0; c < DU; ++c) ka[k][c] = ua[c];
+        }
+    } else if (F.do_push) {  // push_vec on both buffers: drop row 0, append (obs, action_curr) at the bottom (utilities.py:78-79)
 #pragma unroll
       for (int k = 0; k < KEEP; ++k)
         if (k + 1 < bs) {
@@ -224,10 +250,11 @@ __device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KP
 #pragma unroll
         for (int c = 0; c < DU; ++c) u[c] = (double)ka[r][c];
       } else {  // m > 3: beyond the kept rows (written above by this lane: same-address order, served by L2)
+        const int pr = phys(r);
 #pragma unroll
-        for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)r * DS + c) * B + b];
+        for (int c = 0; c < DS; ++c) y[c] = (double)F.obs_buf[((long)pr * DS + c) * B + b];
 #pragma unroll
-        for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)r * DU + c) * B + b];
+        for (int c = 0; c < DU; ++c) u[c] = (double)F.act_buf[((long)pr * DU + c) * B + b];
       }
       if (P.has_target)
         make_chi<DS, DU, true, double>(P, y, u, chi);
@@ -249,6 +276,49 @@ __device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KP
   }
 
   return true;
+}
+
+// After `pushes` ring-mode pushes physical row p of env b holds logical row (p - pushes) mod buffer_size: rotate both buffers left by
+// pushes mod buffer_size, in place (cycle by cycle; all components of a row travel together), by the lane that stored them.
+template <typename Sys, typename real>
+__device__ __forceinline__ void critic_ring_unrotate(const FitArgs<real>& F, const KParams<real>& Pr, const long b, const int pushes) {
+  constexpr int DS = Sys::DS, DU = Sys::DU;
+  const long B = Pr.B;
+  const int bs = Pr.buffer_size, sh = pushes % bs;
+  if (sh == 0) return;
+  int g = bs, r = sh;  // gcd(bs, sh) = the number of cycles
+  while (r) {
+    const int q = g % r;
+    g = r;
+    r = q;
+  }
+  for (int s = 0; s < g; ++s) {
+    real to[DS], ta[DU];
+#pragma unroll
+    for (int c = 0; c < DS; ++c) to[c] = F.obs_buf[((long)s * DS + c) * B + b];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) ta[c] = F.act_buf[((long)s * DU + c) * B + b];
+    int j = s;
+    for (;;) {
+      int nx = j + sh;
+      if (nx >= bs) nx -= bs;
+      if (nx == s) break;
+      real vo[DS], va[DU];
+#pragma unroll
+      for (int c = 0; c < DS; ++c) vo[c] = F.obs_buf[((long)nx * DS + c) * B + b];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) va[c] = F.act_buf[((long)nx * DU + c) * B + b];
+#pragma unroll
+      for (int c = 0; c < DS; ++c) F.obs_buf[((long)j * DS + c) * B + b] = vo[c];
+#pragma unroll
+      for (int c = 0; c < DU; ++c) F.act_buf[((long)j * DU + c) * B + b] = va[c];
+      j = nx;
+    }
+#pragma unroll
+    for (int c = 0; c < DS; ++c) F.obs_buf[((long)j * DS + c) * B + b] = to[c];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) F.act_buf[((long)j * DU + c) * B + b] = ta[c];
+  }
 }
 
 // Everything of one env, lane-private: [env step] -> [push] -> [fit], in and out through the handle's tensors.  The body of

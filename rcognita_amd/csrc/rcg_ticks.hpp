@@ -304,8 +304,12 @@ __global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, c
   if (wave * G >= B) return;  // wave-uniform: every wave that stays runs all T ticks and exits
   const int envs_here = (int)((B - wave * G) < G ? (B - wave * G) : G);
   FitArgs<real> F = M.F;
+  const int bs = P.buffer_size;
+  int ring = 1;  // the buffers are rings inside the launch (FitArgs::ring): tick t overwrites physical row t mod buffer_size
   for (int t = 0; t < M.T; ++t) {
     F.do_fit = ((M.tick0 + t + 1) % M.every) == 0 ? 1 : 0;  // fits on ticks every - 1, 2 every - 1, ... of the episode
+    F.ring = ring;
+    ring = ring == bs ? 1 : ring + 1;
     if constexpr (ML) {
       if (lane < FIT_L * envs_here)  // (whole quads: the DPP exchanges of the four-lane walk stay inside a quad)
         critic_update_env_ml<Sys, real, CS, MAXM>(F, P64, P, wave * G + (lane / FIT_L), lane & (FIT_L - 1));
@@ -326,6 +330,12 @@ __global__ __launch_bounds__(256) void k_ticks_mem(const TicksMemArgs<real> M, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __builtin_amdgcn_wave_barrier();
+  }
+  // the rows back into place: by the lane that stored them (its own stores, its own loads)
+  if constexpr (ML) {
+    if (lane < FIT_L * envs_here && (lane & (FIT_L - 1)) == 0) critic_ring_unrotate<Sys, real>(F, P, wave * G + (lane / FIT_L), M.T);
+  } else {
+    if (lane < envs_here) critic_ring_unrotate<Sys, real>(F, P, wave * G + lane, M.T);
   }
 }
 
