@@ -433,3 +433,28 @@ def test_streamed_critic_mode_small_batch_rate():
         rates[tag] = 3 * T * B / (time.perf_counter() - t0)
     print(f"\nstreamed RQL B={B} K={K}: {rates}")
     assert rates["one_launch"] >= 1.5 * rates["per_tick_launches"], rates
+
+
+@pytest.mark.parametrize("cs,bs,nc", [("quad-nomix", 4, 4), ("quad-nomix", 6, 3), ("quadratic", 10, 4), ("quad-lin", 9, 6)])
+def test_ring_pushes_inside_one_launch_end_in_place(cs, bs, nc):
+    """k_ticks_mem keeps the two buffers as rings while it runs (a push overwrites the oldest row) and rotates the rows back
+    after its last tick: for every T - below, at and above buffer_size, rotations of one cycle and of several (gcd > 1), the
+    TD stack reaching past the rows kept in registers (Ncritic = 6), the four-lane fit (quad-lin: 35 weights) - both buffers
+    and the weights end bit-identical to T single ticks, and a second launch continues from them."""
+    from rcognita_amd import _native as N
+
+    B, K = 37, 64
+    for T in (1, 2, 3, bs - 1, bs, bs + 1, 2 * bs, 2 * bs + 3):
+        one, many, _ = _pair("3wrobot", B, "f32", n_actor=4, mode=O.MODE_RQL, critic_struct=O.CRITIC_IDS[cs], n_critic=nc,
+                             buffer_size=bs)
+        x0 = rand_states(np.random.default_rng(100 * bs + T), "3wrobot", B) * 0.5
+        one.set_state(x0)
+        many.set_state(x0)
+        for _ in range(T + 2):
+            one.control_tick(None, K=K)
+        many.control_ticks(T, K)
+        many.control_ticks(2, K)
+        for f in ("FIELD_OBS_BUF", "FIELD_ACT_BUF", "FIELD_W_CRITIC", "FIELD_W_PREV", "FIELD_STATE", "FIELD_ACTION"):
+            np.testing.assert_array_equal(many.get_field(getattr(N, f)), one.get_field(getattr(N, f)), err_msg=f"{f} T={T}")
+        one.close()
+        many.close()
