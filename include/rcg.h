@@ -60,6 +60,18 @@ typedef enum rcg_critic_struct {
   RCG_CRITIC_QUAD_NOMIX = 2,
   RCG_CRITIC_QUAD_MIX = 3
 } rcg_critic_struct;
+/* Element type of a handle's tensors and arithmetic.  The reference computes in float64 throughout (RCG_F64 agrees with it
+ * to 1e-11 and is the default of the drop-in classes).  RCG_F32, measured against numbers the reference produced at robot
+ * headings |alpha| of 30 ... 1e4 rad from float32-exact inputs (fixture F13, tests/test_hip_large_heading.py,
+ * profiles/r06_large_heading.txt):
+ *   - every operator as a MAP from the same inputs - rcg_rhs, rcg_actor_cost / rcg_actor_argmin / the decision of a tick on every
+ *     kernel, one rcg_sim_step - stays inside 1e-5 relative (measured <= 4.7e-7 for the costs, <= 2.8e-6 for one env step) at
+ *     EVERY heading: the float32 trig is v_sin / v_cos behind an exact two-constant reduction (4.5e-7 absolute out to 1e6 rad),
+ *     the simulator's a three-constant reduction + minimax polynomials (1.2e-7);
+ *   - a FREE-RUNNING float32 trajectory stores its heading to 2^-24 |alpha| per step, which no kernel can undo: after n steps the
+ *     heading may have drifted n * 2^-24 * |alpha| and the position speed * time * that much.  Measured over 104 steps: inside
+ *     3e-5 of the reference for |alpha| <= 72 rad (400 steps to -72 rad: 9.6e-6), 2.2e-4 at 1e3 rad, 2.3e-2 at 1e4 rad (the NI
+ *     robot at 8 m/s).  Loops that spin the robot beyond ~100 rad and need trajectory-level agreement use RCG_F64. */
 typedef enum rcg_dtype { RCG_F32 = 0, RCG_F64 = 1 } rcg_dtype;
 typedef enum rcg_where { RCG_HOST = 0, RCG_DEVICE = 1 } rcg_where;
 

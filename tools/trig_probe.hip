@@ -17,27 +17,27 @@ __global__ void k64(const double* x, double* s, double* c, int n) {
 __global__ void k(const float* x, float* s, float* c, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float v = x[i];
-  // k = nearest integer number of revolutions; r = x - k*2pi (two-constant Cody-Waite with FMA)
-  const float kf = __builtin_rintf(v * 0.15915494309189533577f);
-  float r = __builtin_fmaf(kf, -6.28318548202514648438f, v);  // fl(2pi)
-  r = __builtin_fmaf(kf, 1.74845553146951715e-7f, r);         // 2pi - fl(2pi) = -1.7484555e-7
-  const float t = r * 0.15915494309189533577f;                // revolutions in [-0.5, 0.5]
-  s[i] = __builtin_amdgcn_sinf(t);
-  c[i] = __builtin_amdgcn_cosf(t);
+  rcg::sincos_hw(x[i], &s[i], &c[i]);  // the shipped function: two-constant reduction + v_sin_f32 / v_cos_f32
+}
+
+__global__ void kr(const float* x, float* s, float* c, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rcg::sincos_r<float>(x[i], &s[i], &c[i]);  // the simulator's form: three-constant reduction + minimax
 }
 
 int main() {
   const int n = 1 << 22;
   std::vector<float> hx(n), hs(n), hc(n);
-  for (double range : {3.2, 100.0, 1000.0}) {
+  for (int form = 0; form < 2; ++form)
+  for (double range : {3.2, 100.0, 1000.0, 1e4, 1e5, 1e6}) {
     for (int i = 0; i < n; ++i) hx[i] = (float)(((double)rand() / RAND_MAX * 2 - 1) * range);
     float *dx, *ds, *dc;
     hipMalloc(&dx, n * 4);
     hipMalloc(&ds, n * 4);
     hipMalloc(&dc, n * 4);
     hipMemcpy(dx, hx.data(), n * 4, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dx, ds, dc, n);
+    hipLaunchKernelGGL(form ? kr : k, dim3(n / 256), dim3(256), 0, 0, dx, ds, dc, n);
     hipMemcpy(hs.data(), ds, n * 4, hipMemcpyDeviceToHost);
     hipMemcpy(hc.data(), dc, n * 4, hipMemcpyDeviceToHost);
     double es = 0, ec = 0;
@@ -45,7 +45,7 @@ int main() {
       es = fmax(es, fabs((double)hs[i] - sin((double)hx[i])));
       ec = fmax(ec, fabs((double)hc[i] - cos((double)hx[i])));
     }
-    printf("range +-%g: max abs err sin %.3e cos %.3e\n", range, es, ec);
+    printf("%s, range +-%g: max abs err sin %.3e cos %.3e\n", form ? "f32 sincos_r" : "f32 sincos_hw", range, es, ec);
     hipFree(dx);
     hipFree(ds);
     hipFree(dc);
