@@ -16,7 +16,7 @@ OBJDIR  := $(ROOT)build/obj
 ORACLE  := $(ROOT)oracle
 
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -ffp-contract=fast \
-            -I$(ROOT)include
+            -I$(ROOT)include -MMD -MP
 # the C ABI; the system-templated launchers and kernels: rcg_sys_inst.hip compiled once per (system, part), see that file
 UNITS   := rcg_api
 SYSP    := $(foreach s,Sys3WRobot.kVt3WRobot Sys3WRobotNI.kVt3WRobotNI Sys2Tank.kVt2Tank,$(foreach p,0 1 2 3 4,$(s).$(p)))
@@ -28,7 +28,11 @@ DMAFLAGS = -DRCG_INST_SYS=$(word 1,$(subst ., ,$*)) -DRCG_INST_REAL=$(word 2,$(s
 objs     = $(addprefix $(1)/rcg_sys.,$(addsuffix .o,$(SYSP))) $(addprefix $(1)/,$(addsuffix .o,$(UNITS))) \
            $(addprefix $(1)/rcg_dma.,$(addsuffix .o,$(DMA)))
 OBJS    := $(call objs,$(OBJDIR))
-HDRS    := $(wildcard $(CSRC)/*.hpp) $(ROOT)include/rcg.h
+# headers: every object depends on exactly the headers it includes (-MMD -MP writes a .d beside each .o; an object built
+# before the .d files existed has none and falls back to "all headers")
+ALLHDRS := $(wildcard $(CSRC)/*.hpp) $(ROOT)include/rcg.h
+hdrs     = $(if $(wildcard $(1:.o=.d)),,$(ALLHDRS))
+.SECONDEXPANSION:
 
 DEVOBJDIR := $(ROOT)build/obj_dev
 DEVOBJS   := $(call objs,$(DEVOBJDIR))
@@ -42,15 +46,15 @@ all: lib oracle
 lib: $(LIBDIR)/librcg.so
 oracle: $(ORACLE)/_build/liboracle.so
 
-$(OBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+$(OBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(DMAFLAGS) -c $< -o $@
 
-$(OBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+$(OBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(SYSFLAGS) -c $< -o $@
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $$(call hdrs,$$@)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -64,15 +68,15 @@ $(ORACLE)/_build/liboracle.so: $(ORACLE)/oracle.c
 
 dev: $(LIBDIR)/librcg_dev.so
 
-$(DEVOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+$(DEVOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(DEVOBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRCG_DEV $(DMAFLAGS) -c $< -o $@
 
-$(DEVOBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+$(DEVOBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(DEVOBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRCG_DEV $(SYSFLAGS) -c $< -o $@
 
-$(DEVOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+$(DEVOBJDIR)/%.o: $(CSRC)/%.hip $$(call hdrs,$$@)
 	@mkdir -p $(DEVOBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRCG_DEV -c $< -o $@
 
@@ -85,15 +89,15 @@ $(LIBDIR)/librcg_dev.so: $(DEVOBJS)
 ab: $(LIBDIR)/librcg_ab.so
 ABOBJDIR := $(ROOT)build/obj_ab
 ABOBJS   := $(call objs,$(ABOBJDIR))
-$(ABOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+$(ABOBJDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(ABOBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) $(DMAFLAGS) -c $< -o $@
 
-$(ABOBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+$(ABOBJDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(ABOBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) $(SYSFLAGS) -c $< -o $@
 
-$(ABOBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+$(ABOBJDIR)/%.o: $(CSRC)/%.hip $$(call hdrs,$$@)
 	@mkdir -p $(ABOBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(ABFLAGS) -c $< -o $@
 
@@ -107,15 +111,15 @@ asan: $(ASANDIR)/abi_asan
 ASANHIP := -std=c++17 --offload-arch=$(ARCH) --offload-host-only $(SANFLAGS) -fPIC -Wall -Wno-unused-function \
            -ffp-contract=fast -I$(ROOT)include
 
-$(ASANDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $(HDRS)
+$(ASANDIR)/rcg_dma.%.o: $(CSRC)/rcg_dma_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(ASANDIR)
 	$(HIPCC) $(ASANHIP) $(DMAFLAGS) -c $< -o $@
 
-$(ASANDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $(HDRS)
+$(ASANDIR)/rcg_sys.%.o: $(CSRC)/rcg_sys_inst.hip $$(call hdrs,$$@)
 	@mkdir -p $(ASANDIR)
 	$(HIPCC) $(ASANHIP) $(SYSFLAGS) -c $< -o $@
 
-$(ASANDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+$(ASANDIR)/%.o: $(CSRC)/%.hip $$(call hdrs,$$@)
 	@mkdir -p $(ASANDIR)
 	$(HIPCC) $(ASANHIP) -c $< -o $@
 
@@ -135,5 +139,7 @@ $(ASANDIR)/abi_asan: $(ASANOBJS) $(ASANDIR)/asan_driver.o $(ASANDIR)/no_device_i
 
 clean:
 	rm -rf $(LIBDIR)/librcg.so $(LIBDIR)/librcg_dev.so $(LIBDIR)/librcg_ab.so $(OBJDIR) $(DEVOBJDIR) $(ABOBJDIR) $(ASANDIR) $(ORACLE)/_build
+
+-include $(wildcard $(OBJDIR)/*.d) $(wildcard $(DEVOBJDIR)/*.d) $(wildcard $(ABOBJDIR)/*.d)
 
 .PHONY: all lib oracle dev ab asan clean

@@ -5,8 +5,11 @@
 
 Workload, default (BASELINE.json configs[1], SURVEY.md 8d "C2"): Sys3WRobot, B = 65536 envs per GPU, RK4
 dt = 0.01 (one substep per control tick), CtrlOptPred MPC, Nactor = 10, K = 256 candidate action
-sequences per env streamed from HBM as a [B][K][N][du] f32 tensor (the `_actor_cost(action_sqn, obs)`
-operator shape).  One "step" = one env.control-step (unit U2) for every env of the batch:
+sequences per env streamed from HBM as a [B][K][N][du] tensor (the `_actor_cost(action_sqn, obs)`
+operator shape) in FLOAT64 - the reference's own arithmetic width ("all reference arithmetic is float64"):
+`value`, `ms_per_step`, `roofline` and `dtype` are the float64 tick; the float32 tick of the same workload (half the
+candidate bytes) is measured in the same run, the same way (in-stream event bracket + dispatch stamps), and reported as
+`value_f32` / `roofline_f32`.  One "step" = one env.control-step (unit U2) for every env of the batch:
 rcg_control_tick = k_sim (closed_loop_rhs under RK4) + k_actor_dma (K rollouts + argmin + accum update).
 Inputs are synthetic and resident in HBM before the timed region.
   --config C3   configs[2]: Sys2Tank, 131072 envs per GPU, Nactor = 20, RQL with the quadratic critic refitted every tick
@@ -64,7 +67,10 @@ def parse(argv=None):
     p.add_argument("--candidates", type=int, default=256, help="K candidate sequences per env")
     p.add_argument("--nactor", type=int, default=None, help="horizon (default 10; C3: 20; C5: 15)")
     p.add_argument("--regime", choices=["streamed", "generated"], default=None)
-    p.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    p.add_argument("--dtype", choices=["f32", "f64"], default=None,
+                   help="element type of the headline tick.  Default f64 = the reference's own arithmetic width for the streamed "
+                        "(HBM-bound) configs, with the f32 tick (half the candidate bytes) beside it as value_f32 / roofline_f32; "
+                        "the generated-grid regime (--regime generated, --config C5) is a float32 regime (k_ticks_pk) and defaults to f32")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true")
     p.add_argument("--no-parity", action="store_true")
@@ -97,6 +103,8 @@ def parse(argv=None):
         a.nactor = {"C5": 15, "C3": 20}.get(a.config, 10)
     if a.regime is None:
         a.regime = "generated" if a.config == "C5" else "streamed"
+    if a.dtype is None:
+        a.dtype = "f32" if a.regime == "generated" else "f64"
     if a.parts is None:
         a.parts = 1  # (round 4: 2 for C3 - two handles on two streams hid the critic fit; since round 5 ONE handle does that itself)
     if a.parts > 1 and a.config == "C5":
@@ -816,8 +824,8 @@ def main(argv=None):
     if traffic is not None and split_inside and len(engines) == 1:
         traffic *= 2  # the stored counter pass saw the tick's two half-batch launches one by one: tick level, as `achieved`
     kinfo = launch_info[0]
-    width = "float32 storage and arithmetic (SURVEY 8a-1 / 8d; the reference computes in float64: value_f64 / roofline_f64)" \
-        if args.dtype == "f32" else "float64, the reference's width"
+    width = "float32 storage and arithmetic (SURVEY 8a-1 / 8d; the reference computes in float64: run without --dtype f32)" \
+        if args.dtype == "f32" else "float64, the reference's width (float32 beside it: value_f32 / roofline_f32)"
     workload = {
         "C2": f"Sys3WRobot B={args.batch}/GPU RK4 dt=0.01 S=1, CtrlOptPred MPC Nactor={Nh}, K={K} {args.regime} "
               f"candidates (BASELINE configs[1]); headline in {width}",
@@ -947,15 +955,17 @@ def main(argv=None):
     cl = closed_loop_value(out.get("secondary") or {})
     if cl:
         out["value_closed_loop"] = cl
-    # the reference's arithmetic width next to the headline: the float64 run of the same tick
-    f64 = (out.get("secondary") or {}).get("f64")
-    if args.dtype == "f64":
-        out["value_f64"], out["roofline_f64"] = out["value"], {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
-    elif f64 and "env_control_steps_per_s" in f64:
-        out["value_f64"] = f64["env_control_steps_per_s"]
-        out["roofline_f64"] = dict(f64["roofline"], kernel=f64["kernel"], avg_launch_ms=f64["kernel_avg_ms"],
-                                   note="the same tick with float64 storage and arithmetic (the reference's width), "
-                                        "this run, secondary.f64")
+    # the two arithmetic widths side by side: the headline is the reference's (float64); the other width of the same tick is
+    # this run's secondary.other_width, timed like the headline (in-stream event bracket + dispatch stamps)
+    mine = {k: out["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms",
+                                                "algorithmic_bytes_per_launch")}
+    ow = (out.get("secondary") or {}).get("other_width")
+    out["value_" + args.dtype], out["roofline_" + args.dtype] = out["value"], mine
+    if ow and "env_control_steps_per_s" in ow:
+        out["value_" + ow["dtype"]] = ow["env_control_steps_per_s"]
+        out["roofline_" + ow["dtype"]] = dict(ow["roofline"], kernel=ow["kernel"], avg_launch_ms=ow["kernel_avg_ms"],
+                                              note=f"the same tick with {ow['dtype']} storage and arithmetic, this run "
+                                                   "(secondary.other_width)")
 
     if not args.no_cpu_baseline and world == 1 and args.config == "C2":
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
@@ -999,7 +1009,7 @@ def closed_loop_value(sec):
         return None
     best = max(regimes, key=lambda k: regimes[k]["value"])
     return {"value": regimes[best]["value"], "unit": "env-control-steps/s", "regime": best, "what": regimes[best]["what"],
-            "regimes": regimes,
+            "regimes": regimes, "dtype": "f32",
             "note": "candidates change every tick in each of these; the headline `value` streams one static tensor"}
 
 
@@ -1069,6 +1079,13 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
     """Other regimes of the same workload on this GPU (rank 0, N = 1 only; not part of `value`)."""
     sec = {}
     du, ds = 2, 5
+    # the headline's width and the width of the regimes below: generated grid, device search, optimiser, small batches are
+    # float32 regimes (k_ticks_pk / the packed rollouts exist in float32 only; their stored instruction counts are float32's);
+    # they are measured in float32 whatever the headline's width, and say so
+    head_dtype = args.dtype
+    args = argparse.Namespace(**vars(args))
+    args.dtype = "f32"
+    sec["regimes_dtype"] = "f32 (generated_grid, sim_step_only, device_search, produced_stream, optimizer_tick, small_batch_ticks)"
     # (1) generated level-grid candidates (VALU-bound regime, SURVEY.md 8d) at the same K
     ecfg, bnds = c2_engine_config(args, device, B)
     eng2 = Engine(ecfg)
@@ -1199,42 +1216,49 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
         sec["small_batch_ticks"] = sb
     except Exception as e:  # never let a secondary figure take the bench line down
         sec["small_batch_ticks"] = {"error": str(e)[:300]}
-    # (3) the reference's own arithmetic width: the same tick in float64 (streamed candidates, 2 x the bytes)
-    if args.dtype == "f32" and args.regime == "streamed":
+    # (3) the OTHER arithmetic width of the streamed tick (headline float64 -> float32 here, and the reverse), timed as the
+    # headline is: a spin on the new tensor, then n ticks between two in-stream events, the kernel's own duration from the
+    # stamps carried by every 4th dispatch
+    if args.regime == "streamed":
+        od = "f32" if head_dtype == "f64" else "f64"
         try:
-            ecfg64, _ = c2_engine_config(args, device, B, dtype="f64")
-            e64 = Engine(ecfg64)
-            e64.set_stream(stream_ptr)
-            e64.set_state(x0)
+            td = torch.float32 if od == "f32" else torch.float64
+            oesz = 4 if od == "f32" else 8
+            ecfg_o, _ = c2_engine_config(args, device, B, dtype=od)
+            eo = Engine(ecfg_o)
+            eo.set_stream(stream_ptr)
+            eo.set_state(x0)
             gen = torch.Generator(device="cuda")
             gen.manual_seed(4321)
-            blo = torch.tensor(bnds[:, 0], device="cuda", dtype=torch.float64)
-            bhi = torch.tensor(bnds[:, 1], device="cuda", dtype=torch.float64)
-            c64 = (torch.rand((B, K, Nh, du), generator=gen, device="cuda", dtype=torch.float64) * (bhi - blo) + blo).contiguous()
-            for _ in range(150):  # the f64 candidate tensor is new to the GPU: same clock / TLB warm-up as the main line
-                e64.control_tick(c64, K=K)
-            e64.profile((N.KERNEL_ACTOR,), stride=4)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n4 = max(20, args.steps // 5)
+            blo = torch.tensor(bnds[:, 0], device="cuda", dtype=td)
+            bhi = torch.tensor(bnds[:, 1], device="cuda", dtype=td)
+            co = (torch.rand((B, K, Nh, du), generator=gen, device="cuda", dtype=td) * (bhi - blo) + blo).contiguous()
+            for _ in range(150):  # the tensor is new to the GPU: same clock / TLB warm-up as the main line
+                eo.control_tick(co, K=K)
+            eo.profile((N.KERNEL_ACTOR,), stride=4)
+            n4 = max(40, args.steps // 2)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(st2)
             for _ in range(n4):
-                e64.control_tick(c64, K=K)
+                eo.control_tick(co, K=K)
+            eb.record(st2)
             torch.cuda.synchronize()
-            d4 = time.perf_counter() - t1
-            ms4, c4 = e64.profile_read(N.KERNEL_ACTOR)
-            k64 = e64.last_launch(N.KERNEL_ACTOR)["kernel"]
-            e64.close()
-            b64 = actor_bytes_per_launch(B, K, Nh, du, ds, 8, True)
-            sec["f64"] = {"env_control_steps_per_s": B * n4 / d4, "ms_per_step": d4 / n4 * 1e3, "dtype": "f64",
-                          "kernel": k64 + "<double>",
-                          "kernel_avg_ms": ms4 / max(c4, 1),
-                          "roofline": {"bound": "hbm", "achieved": b64 / (ms4 / max(c4, 1) * 1e-3) / 1e9,
-                                       "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                       "frac": b64 / (ms4 / max(c4, 1) * 1e-3) / HBM_PEAK,
-                                       "algorithmic_bytes_per_launch": b64}}
-            del c64
+            d4 = ea.elapsed_time(eb) * 1e-3
+            ms4, c4 = eo.profile_read(N.KERNEL_ACTOR)
+            ko = eo.last_launch(N.KERNEL_ACTOR)["kernel"]
+            eo.close()
+            bo = actor_bytes_per_launch(B, K, Nh, du, ds, oesz, True)
+            sec["other_width"] = {"env_control_steps_per_s": B * n4 / d4, "ms_per_step": d4 / n4 * 1e3, "dtype": od,
+                                  "steps": n4, "clock": "HIP events recorded in-stream around the steps (as the headline)",
+                                  "kernel": ko + ("<float>" if od == "f32" else "<double>"),
+                                  "kernel_avg_ms": ms4 / max(c4, 1), "launches_timed": int(c4),
+                                  "roofline": {"bound": "hbm", "achieved": bo / (ms4 / max(c4, 1) * 1e-3) / 1e9,
+                                               "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                               "frac": bo / (ms4 / max(c4, 1) * 1e-3) / HBM_PEAK,
+                                               "algorithmic_bytes_per_launch": bo}}
+            del co
         except Exception as e:  # never let a secondary figure take the bench line down
-            sec["f64"] = {"error": str(e)[:300]}
+            sec["other_width"] = {"error": str(e)[:300]}
     return sec
 
 
