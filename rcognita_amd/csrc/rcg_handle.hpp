@@ -28,6 +28,8 @@ struct rcg_handle {
   long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
   int opt_memory;   // curvature pairs of k_actor_opt (rcg_set_optimizer); -1: the default of opt_memory_of()
   void* d_const;    // constant block in HBM, layout kConst* below
+  void* fit_scratch;         // k_critic_fit_gen (Ncritic - 1 > kFitMaxRows): per-env stack / factor, allocated on first use
+  size_t fit_scratch_bytes;
   rcg::KParams<float> p32;
   rcg::KParams<double> p64;
   const struct SysVTable* sys;
@@ -79,7 +81,7 @@ static inline void note_launch(rcg_handle* h, int kind, int kernel_id, int varia
 
 // [0,392) R1|R2 as f32, [512,1296) R1|R2 as f64, [1296,2256) w_init|w_min|w_max as f64
 static constexpr size_t kConstR64 = 512, kConstW = 1296, kConstBytes = 2256;
-static constexpr int kFitMaxRows = 8;  // Ncritic - 1 <= 8 for the native critic fit
+static constexpr int kFitMaxRows = 8;  // Ncritic - 1 <= 8: the register kernels (k_critic_fit); beyond: k_critic_fit_gen (HBM scratch)
 
 // sets the handle's (or, for h == nullptr, the thread's) error text and returns `code`
 int rcg_fail(rcg_handle* h, int code, const char* fmt, ...);
@@ -197,10 +199,15 @@ inline const rcg::KParams<double>& params<double>(const rcg_handle* h) {
 // stalls 3-14 % above SLSQP there, fixtures F8c) - and none for MPC with a diagonal R1, where box-scaled steepest descent
 // reaches SLSQP's optimum on every decision of the reference's own loops (fixtures F8, mpc_tick_* of F7c: <= 3.5e-4 after
 // 10 iterations, 0 after 30) and the pairs would cost 2.4 x the time (LDS footprint: 77 KB per block instead of 26).
+// A long horizon (the reference's is unbounded) keeps fewer pairs by default: as many of the 4 as leave a wave's working set
+// inside the CU's 160 KB of LDS (3-wheel robot, float64, critic modes: 4 pairs up to Nactor = 41, none from 63).
 static inline int opt_memory_of(const rcg_handle* h) {
   if (h->opt_memory >= 0) return h->opt_memory;
   const bool generic = !(h->cfg.mode == RCG_MODE_MPC && h->p32.stage_kind == 0);
-  return generic ? 4 : 0;
+  const int dcw = h->cfg.mode != RCG_MODE_MPC ? h->dc : 0;
+  int mem = generic ? 4 : 0;
+  while (mem > 0 && (size_t)rcg::opt_lds_reals(h->cfg.n_actor, h->ds, h->du, h->np, dcw, mem) * h->esz > (size_t)160 * 1024) --mem;
+  return mem;
 }
 static inline size_t opt_wave_lds_bytes(const rcg_handle* h) {
   const int dcw = h->cfg.mode != RCG_MODE_MPC ? h->dc : 0;

@@ -850,9 +850,13 @@ __device__ __forceinline__ real accum_update(const KParams<real>& P, const real*
 // phase of k_ticks_mem (rcg_ticks.hpp).  `wave`: the wave's index in the grid (wave-uniform), `lds`: its LDS region (streamed).
 // `staged` (k_ticks_mem over a caller's tensor, ticks after the first, one tile per wave): the wave's tile is still in its LDS
 // region from the previous tick - nothing else writes there - and is not staged again.
-template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false>
+// DIRECT (streamed rows too long for an LDS tile - beyond RCG_MAX_ROW reals, rcg.h): nothing is staged, every lane walks ITS row
+// straight from HBM (a row is contiguous: each of a lane's cache lines serves 16 / DU of its steps; the reference's horizon is
+// unbounded, controllers.py:965 - any Nactor runs here, the short rows every preset has run on the staged kernels)
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false, bool DIRECT = false>
 __device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KParams<real>& P, const long wave, real* const lds,
                                            const bool staged = false) {
+  static_assert(!DIRECT || (STREAM && GENERIC && !PKONLY), "DIRECT is a variant of the streamed generic instance");
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU;
   const int lane = threadIdx.x & 63;
   const long B = P.B;
@@ -921,7 +925,7 @@ __device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KPara
     if (STREAM) {
       const long row0 = big ? b * K + (long)t * 64 : wave * A.G * (long)K;
       const int nrows = big ? (K - t * 64 < 64 ? K - t * 64 : 64) : envs_here * K;
-      if (!staged) {  // wave-uniform
+      if (!staged && !DIRECT) {  // wave-uniform
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous tile's LDS reads are done
         stage_tile<real>(A.cand + row0 * R, lds, nrows * R, lane, A.vec_ok);
         // LDS ops of one wave are executed in order; wait for our own writes, no workgroup barrier
@@ -932,7 +936,11 @@ __device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KPara
     } else {
       gen_candidate<DU, real>(P, A.grid_g, k, ugen);
     }
-    const real* const urow = lds + (size_t)r * R;
+    const real* urow = lds + (size_t)r * R;
+    if constexpr (DIRECT) {
+      const long row0 = big ? b * K + (long)t * 64 : wave * A.G * (long)K;
+      urow = A.cand + (row0 + r) * R;
+    }
     real u0[DU];
     const real J = rollout_dispatch<Sys, real, GENERIC, TGT, STREAM>(P, pre, N, xs, y0, urow, ugen, wget, u0);
 
@@ -961,7 +969,7 @@ __device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KPara
 
 // (the instances without the generic cost structures ask for 4 waves per SIMD, i.e. <= 128 VGPRs: the generated-grid
 // instance sits at 125-129 registers depending on details, and the step from 4 to 3 resident waves costs it 15 %)
-template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false>
+template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false, bool DIRECT = false>
 __global__ __launch_bounds__(256, (GENERIC || sizeof(real) > 4) ? 1 : 4) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // readfirstlane makes the wave index provably wave-uniform: tile bases, row counts and the env's
@@ -969,7 +977,7 @@ __global__ __launch_bounds__(256, (GENERIC || sizeof(real) > 4) ? 1 : 4) void k_
   const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
   real* const lds = reinterpret_cast<real*>(smem_raw) + (size_t)wave_in_wg * 64 * (P.n_actor * Sys::DU);
-  actor_wave<Sys, real, GENERIC, TGT, STREAM, PKONLY>(A, P, wave, lds);
+  actor_wave<Sys, real, GENERIC, TGT, STREAM, PKONLY, DIRECT>(A, P, wave, lds);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include "rcg_critic_fit_ml.hpp"
 #include "rcg_actor_opt.hpp"
 #include "rcg_critic_fit.hpp"
+#include "rcg_critic_fit_gen.hpp"
 #include "rcg_disturb.hpp"
 #include "rcg_handle.hpp"
 #include "rcg_nominal.hpp"
@@ -161,7 +162,9 @@ static int fit_lanes_knob();  // (DevKnobs, below)
 // kFitLanesMinDc weights; four lanes per env (k_critic_fit_ml, rcg_critic_fit_ml.hpp) from there on: the one-lane walk of a
 // 35-weight structure takes 2.3 ms for 32 768 envs, the four-lane one 0.41 (profiles/r04_fit_four_lanes.txt); with few
 // weights the four-lane form is the slower one (configs[2], 6 weights: 65 -> 88 us).  Returns which form ran.
-constexpr int kFitLanesMinDc = 20;
+// Round 6: from 9 weights (was 20) - the structures with 9-17 weights measured 1.2-1.3 x faster on four lanes in round 4 (2tank
+// quad-lin 83 -> 66 us, 3wrobotNI quad-mix 145 -> 116, 3wrobotNI quadratic 238 -> 196; 7 weights: 61 -> 59, 6 weights: 65 -> 89).
+constexpr int kFitLanesMinDc = 9;
 template <typename Sys, typename real, int CS>
 static bool launch_fit3(rcg_handle* h, const FitArgs<real>& F, bool force_ml) {
   constexpr int DC = CriticDim<CS, Sys::DS, Sys::DU>::value;
@@ -216,13 +219,37 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
 #else
     const bool force_ml = false;
 #endif
+    // more TD rows than the register kernels hold (Ncritic - 1 > 8; the reference only clips Ncritic to buffer_size - 1,
+    // controllers.py:1015): k_critic_fit_gen with the env's stack and factor in a scratch tensor of the handle, allocated on
+    // first use (rcg_critic_fit_gen.hpp)
+    const bool gen = m > kFitMaxRows;
+    if (gen && do_fit) {
+      const size_t need = (size_t)fit_gen_scratch_doubles(m, h->dc) * (size_t)h->cfg.batch * sizeof(double);
+      if (h->fit_scratch_bytes < need) {
+        if (h->fit_scratch) {
+          HIPCHK(h, hipStreamSynchronize(h->stream));
+          HIPCHK(h, hipFree(h->fit_scratch));
+          h->fit_scratch = nullptr;
+          h->fit_scratch_bytes = 0;
+        }
+        if (hipMalloc(&h->fit_scratch, need) != hipSuccess) {
+          (void)hipGetLastError();
+          return rcg_fail(h, RCG_ERR_HIP, "critic fit with %d TD rows: cannot allocate %zu bytes of scratch for %d envs", m, need,
+                          h->cfg.batch);
+        }
+        h->fit_scratch_bytes = need;
+      }
+    }
 #define RCG_FIT(CS)                                                                                                    \
   do {                                                                                                                 \
     if (m <= 3)                                                                                                        \
       fit_ml = launch_fit3<Sys, real, CS>(h, F, force_ml);                                                             \
-    else                                                                                                               \
+    else if (!gen)                                                                                                     \
       RCG_LAUNCH(h, (k_critic_fit<Sys, real, CS, kFitMaxRows>), grid, block, 0, F, h->p64,             \
                          params<real>(h));                                                                             \
+    else                                                                                                               \
+      RCG_LAUNCH(h, (k_critic_fit_gen<Sys, real, CS>), grid, block, 0, F, h->p64, params<real>(h),                     \
+                 (double*)h->fit_scratch);                                                                             \
   } while (0)
     switch (h->cfg.critic_struct) {
       case RCG_CRITIC_QUAD_LIN: RCG_FIT(RCG_CRITIC_QUAD_LIN); break;
@@ -232,8 +259,8 @@ int op_critic_update(rcg_handle* h, int32_t n_substeps, int32_t do_push, int32_t
     }
 #undef RCG_FIT
     note_launch(h, RCG_KERNEL_CRITIC, RCG_KID_CRITIC_FIT,
-                h->cfg.critic_struct + 16 * (m <= 3 ? 3 : kFitMaxRows) + (F.do_sim ? 256 : 0) + (do_fit ? 512 : 0) +
-                    (fit_ml ? 1024 : 0),
+                h->cfg.critic_struct + 16 * (m <= 3 ? 3 : (gen ? 0 : kFitMaxRows)) + (F.do_sim ? 256 : 0) + (do_fit ? 512 : 0) +
+                    (fit_ml ? 1024 : 0) + (gen ? 2048 : 0),
                 fit_ml ? 16 : 64);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
@@ -362,7 +389,10 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   const long B = c.batch;
   const long n_waves = (B + A.G - 1) / A.G;
   int wpb = 4;  // waves per workgroup
-  size_t lds_per_wave = cand ? 64 * row_bytes : 0;
+  // rows beyond RCG_MAX_ROW reals (the reference's horizon is unbounded, controllers.py:965): no LDS tile - the generic
+  // instance's DIRECT form, every lane walking its row straight from HBM (rcg_kernels.hpp::actor_wave)
+  const bool long_row = cand && R > RCG_MAX_ROW;
+  size_t lds_per_wave = (cand && !long_row) ? 64 * row_bytes : 0;
   while (wpb > 1 && lds_per_wave * wpb > 64 * 1024) wpb >>= 1;
   size_t lds = lds_per_wave * wpb;
   if (cand && (size_t)dev_knobs().plain_lds > lds) lds = (size_t)dev_knobs().plain_lds;  // residency experiments
@@ -544,6 +574,15 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
       return RCG_OK;
     }
   }
+  if (long_row) {
+    if (tgt)
+      RCG_LAUNCH(h, (k_actor<Sys, real, true, true, true, false, true>), dim3(blocks), dim3(64 * wpb), 0, A, P);
+    else
+      RCG_LAUNCH(h, (k_actor<Sys, real, true, false, true, false, true>), dim3(blocks), dim3(64 * wpb), 0, A, P);
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR, 1 | (tgt ? 2 : 0) | 4 | 16, A.G);  // variant bit 4: DIRECT rows
+    HIPCHK(h, hipGetLastError());
+    return RCG_OK;
+  }
 #define RCG_LAUNCH_ACTOR(GEN, TGT, STR) \
   RCG_LAUNCH(h, (k_actor<Sys, real, GEN, TGT, STR>), dim3(blocks), dim3(64 * wpb), lds, A, P)
 #define RCG_LAUNCH_ACTOR2(GEN, TGT)      \
@@ -711,6 +750,9 @@ int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, const vo
     const size_t lds_wave = (size_t)search_lds_reals(R, nc > 0) * sizeof(real);
     while (wpb > 1 && lds_wave * wpb > (size_t)64 * 1024) wpb >>= 1;
     const size_t lds = lds_wave * wpb;
+    if (lds > (size_t)64 * 1024)  // (65 rows per wave: 126 doubles / 252 floats per row)
+      return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_actor_search: rows of %d reals need %zu B of LDS per wave (at most 65536)", R,
+                      lds_wave);
     const dim3 grid(blocks_for(c.batch, wpb)), block(64 * wpb);
     if (tick && sim_first) {
       const int rc = op_sim_step<Sys>(h, c.substeps_per_tick);

@@ -82,3 +82,62 @@ def test_ticks_that_are_not_eligible_are_not_split():
         assert not eng.last_launch(N.KERNEL_ACTOR)["split"], (name, K, gen)
     with pytest.raises(N.NativeError):
         eng.set_tick_parts(3)
+
+
+class _DevView:
+    """A device pointer as something torch can wrap (the caller that cached rcg_field_ptr)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def test_work_a_caller_enqueues_behind_a_tick_sees_the_whole_tick():
+    """a caller that cached rcg_field_ptr(ACTION) and enqueues its own kernel on the stream it gave
+    rcg_set_stream right behind rcg_control_tick must read a FINISHED tick - at 65 536 envs, RQL, streamed, where round 5's
+    automatic rule split the tick over two internal streams the caller's stream did not wait for.  Now: automatic (parts = 0)
+    never splits on a caller's stream; the pipelining is the explicit opt-in parts = 2, whose contract is rcg_join; a handle on
+    a stream of its own still splits automatically.  All of them leave the same bits."""
+    import torch
+
+    from rcognita_amd import _native as N
+
+    B, K, Nh, T = 65536, 64, 10, 5
+    kw = dict(mode=O.MODE_RQL, critic_struct=O.CRITIC_IDS["quadratic"], n_critic=4, buffer_size=10, n_actor=Nh)
+    rng = np.random.default_rng(11)
+    x0 = rand_states(rng, "2tank", B)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        cand = torch.rand((B, K, Nh, 1), device="cuda", dtype=torch.float32)
+    s.synchronize()
+    snaps = {}
+    for label, parts in (("automatic", 0), ("opt-in + rcg_join", 2), ("never", 1)):
+        eng, _ = both("2tank", B, "f32", **kw)
+        eng.set_stream(s.cuda_stream)
+        eng.set_tick_parts(parts)
+        eng.set_state(x0)
+        view = torch.as_tensor(_DevView(eng.field_ptr(N.FIELD_ACTION), B, "<f4"), device="cuda")  # cached BEFORE the ticks
+        got = []
+        for t in range(T):
+            eng.control_tick(cand)
+            if parts == 2:
+                eng.join()
+            with torch.cuda.stream(s):
+                got.append(view.clone())  # the caller's own kernel, on the caller's stream, immediately behind the tick
+        s.synchronize()
+        ll = eng.last_launch(N.KERNEL_ACTOR)
+        assert ll["kernel"] == "k_actor_dma" and ll["split"] == (parts == 2), (label, ll)
+        snaps[label] = [g.cpu().numpy() for g in got]
+        np.testing.assert_array_equal(snaps[label][-1], eng.get_field(N.FIELD_ACTION)[:, 0])
+        eng.close()
+    for label in ("opt-in + rcg_join", "never"):
+        for t in range(T):
+            np.testing.assert_array_equal(snaps[label][t], snaps["automatic"][t], err_msg=f"{label} tick {t}")
+    # on a stream of its own the handle still splits by itself (nobody else can enqueue there)
+    eng, _ = both("2tank", B, "f32", **kw)
+    eng.use_own_stream()
+    eng.set_state(x0)
+    torch.cuda.synchronize()
+    for t in range(T):
+        eng.control_tick(cand)
+    assert eng.last_launch(N.KERNEL_ACTOR)["split"]
+    np.testing.assert_array_equal(eng.get_field(N.FIELD_ACTION)[:, 0], snaps["automatic"][-1])
