@@ -6,6 +6,8 @@
 #                      k_actor_dma compiled in; for tools/ only - a tool binds it with rcognita_amd._native.use_library(path))
 #   make asan       -> build/asan/abi_asan: the C oracle and the HOST side of librcg (host-only compile of the .hip units,
 #                      no device code) under clang -fsanitize=address,undefined, with tests/asan_driver.c; CPU only
+MAKEFLAGS += -r
+.SUFFIXES:
 HIPCC   ?= hipcc
 CC      := gcc
 ARCH    ?= gfx950
@@ -22,7 +24,7 @@ UNITS   := rcg_api
 SYSP    := $(foreach s,Sys3WRobot.kVt3WRobot Sys3WRobotNI.kVt3WRobotNI Sys2Tank.kVt2Tank,$(foreach p,0 1 2 3 4,$(s).$(p)))
 SYSFLAGS = -DRCG_SYS=$(word 1,$(subst ., ,$*)) -DRCG_SYS_VT=$(word 2,$(subst ., ,$*)) -DRCG_SYS_PART=$(word 3,$(subst ., ,$*))
 # k_actor_dma instances: rcg_dma_inst.hip compiled once per (system, element type, group), see that file
-DMA     := $(foreach s,Sys3WRobot Sys3WRobotNI Sys2Tank,$(foreach r,float double,$(foreach g,0 1 2 3 4 5,$(s).$(r).$(g))))
+DMA     := $(foreach s,Sys3WRobot Sys3WRobotNI Sys2Tank,$(foreach r,float double,$(foreach g,0 1 2 3 4 5 6,$(s).$(r).$(g))))
 DMAFLAGS = -DRCG_INST_SYS=$(word 1,$(subst ., ,$*)) -DRCG_INST_REAL=$(word 2,$(subst ., ,$*)) \
            -DRCG_INST_GROUP=$(word 3,$(subst ., ,$*))
 objs     = $(addprefix $(1)/rcg_sys.,$(addsuffix .o,$(SYSP))) $(addprefix $(1)/,$(addsuffix .o,$(UNITS))) \
@@ -140,6 +142,9 @@ $(ASANDIR)/abi_asan: $(ASANOBJS) $(ASANDIR)/asan_driver.o $(ASANDIR)/no_device_i
 clean:
 	rm -rf $(LIBDIR)/librcg.so $(LIBDIR)/librcg_dev.so $(LIBDIR)/librcg_ab.so $(OBJDIR) $(DEVOBJDIR) $(ABOBJDIR) $(ASANDIR) $(ORACLE)/_build
 
+# (the included dependency files are not targets: without this rule make tries to REMAKE them through its built-in
+# "link an executable from a .o" rule and compiles rcg_sys.*.d.o objects)
+%.d: ;
 -include $(wildcard $(OBJDIR)/*.d) $(wildcard $(DEVOBJDIR)/*.d) $(wildcard $(ABOBJDIR)/*.d)
 
 .PHONY: all lib oracle dev ab asan clean

@@ -82,9 +82,12 @@ def parse(argv=None):
     p.add_argument("--profile-stride", type=int, default=-1,
                    help="time every n-th launch of the dominant kernel in the timed region (events carried by the "
                         "dispatch); -1 = chosen so that 20 .. 40 launches are sampled, 0 = none")
-    p.add_argument("--tick-parts", type=int, default=0, choices=(0, 1, 2),
-                   help="rcg_set_tick_parts of every handle: 0 = the library's rule (an eligible RQL / SQL tick of >= 65 536 envs "
-                        "runs as two halves on two internal streams), 1 = never, 2 = whenever eligible")
+    p.add_argument("--tick-parts", type=int, default=None, choices=(0, 1, 2),
+                   help="rcg_set_tick_parts of every handle.  Default: 2 for a single RQL / SQL handle (--config C3) - the explicit "
+                        "opt-in to the pipelined split tick; this harness honours its contract (rcg_join in front of every event "
+                        "it records on the handle's stream) - and 0 otherwise.  0 = the library's rule (since round 6: never on a "
+                        "caller's stream, which is what this harness hands the handle; on a stream the handle owns an eligible tick of >= "
+                        "65 536 envs runs as two halves on two internal streams), 1 = never, 2 = whenever eligible")
     p.add_argument("--parts", type=int, default=None,
                    help="handles per GPU, each on a stream of its own (rcognita_amd.pool.MixedPool(parts=...)): the critic fit "
                         "of one part runs under the actor kernel of another.  Default: 1 (since round 5 an RQL / SQL handle splits its own tick, --tick-parts)")
@@ -592,6 +595,8 @@ def main(argv=None):
         tick = lambda: eng.control_tick(cand, K=K)
     du, ds = (1, 2) if args.config == "C3" else (2, 5)
 
+    if args.tick_parts is None:
+        args.tick_parts = 2 if (args.config == "C3" and len(engines) == 1) else 0
     for e in engines:  # (several handles already overlap each other: no split inside them unless asked for)
         e.set_tick_parts(args.tick_parts if (args.tick_parts or len(engines) == 1) else 1)
 

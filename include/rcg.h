@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 117 /* 115 + rcg_sim_step_h, rcg_set_tick_parts, rcg_join (round 5) */
+#define RCG_VERSION 118 /* 117 + rcg_loop_step (round 6) */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -251,6 +251,26 @@ int rcg_sim_step(rcg_handle* h, int32_t n_substeps);
  * caller walk a recorded time grid of the reference - tests/test_hip_ref_traces.py replays the reference's closed loops at
  * the reference's own step and decision instants.  SUBSTEP_IDX / the disturbance draw advance as in rcg_sim_step. */
 int rcg_sim_step_h(rcg_handle* h, int32_t n_substeps, double step);
+/* One iteration of the reference's headless loop body (presets/main_3wrobot.py:419-429) in ONE call with ONE host wait, for the
+ * drop-in classes at small batch (round 6; the separate calls cost three device-to-host round trips per simulation step):
+ *   System.receive_action       ACTION := action_in (host, [B][du] doubles; NULL: the handle's own)
+ *   Simulator.sim_step          one step of length step_h in n_substeps RK4 substeps; STATE_PREV := the state before it
+ *   CtrlOptPred.compute_action  RCG_LOOP_PUSH (RQL / SQL): push_vec(action_curr, observation) on both buffers (utilities.py:78,
+ *                               controllers.py:1463-1464); RCG_LOOP_FIT: the critic fit (controllers.py:1466-1471);
+ *                               RCG_LOOP_DECIDE: rcg_actor_optimize, `iters` iterations from action_sqn_init, the rollout from
+ *                               STATE_PREV - the loop hands the controller System._state one iteration late (controllers.py:
+ *                               1056-1061) - with STATE as the observation; ACTION := the optimum's first action, ACTION_SQN := it
+ *   CtrlOptPred.stage_obj       rho(STATE, ACTION)
+ * out (host): [B][ds + du + 2 (+ dc in RQL / SQL)] doubles per env: state, action, stage_obj, best_J (NaN without
+ * RCG_LOOP_DECIDE), W_CRITIC.  ACCUM / STEP_IDX are not touched (upd_accum_obj is the caller's multiply-add; the caller decides
+ * from its clock which steps are samples).  Every number equals what the separate calls (rcg_set_field, rcg_sim_step_h,
+ * rcg_critic_update, rcg_actor_optimize, rcg_stage_obj) leave, bit for bit.  Handles whose rows fit the 16-KB pinned buffer
+ * (3-wheel robot, MPC: up to 200 envs); no disturbance model. */
+#define RCG_LOOP_DECIDE 1
+#define RCG_LOOP_PUSH 2
+#define RCG_LOOP_FIT 4
+int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t n_substeps, int32_t flags, int32_t iters,
+                  double* out);
 /* Replacement of CtrlOptPred._actor_optimizer (controllers.py:1330-1427): evaluate _actor_cost for
  * K candidates per env and take the argmin (lower J wins, ties -> lower index, NaN = +inf).
  * cand [B][K][N][du], or NULL for the generated level grid (K levels for du = 1, g*g for du = 2).

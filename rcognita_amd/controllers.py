@@ -129,9 +129,78 @@ class CtrlOptPred:
             raise ValueError(f"actor_opt must be 'auto', 'gradient' or 'sampling', got {actor_opt!r}")
         self._use_gradient = actor_opt in ("auto", "gradient")
         self._search_draw = 0  # decisions made so far: the draw counter of the device-side search
-        self._prev_opt = None  # previous optimal sequence [B, N, du] (warm start)
+        self._prev_opt_val = None  # last optimal sequence [B, N, du]
+        self._prev_opt_on_device = False
         self.last_J = None
         self.last_idx = None
+        # the fused loop step (rcg_loop_step, Simulator.sim_step): what it computed ahead for compute_action / stage_obj
+        self._dtype = dtype
+        self._fz = None
+        self._fused_dirty = True  # the handle's STATE / buffers / weights must be uploaded before the next fused step
+        self.fused_steps = 0      # statistics: loop iterations served by one native call ...
+        self.fused_decisions = 0  # ... and decisions of compute_action taken from them
+        sys_obj._register_controller(self)
+
+    # the optimal sequence of the last decision; after a fused step it stays on the device until somebody asks
+    @property
+    def _prev_opt(self):
+        if self._prev_opt_on_device:
+            self._prev_opt_val = self._eng.get_field(N.FIELD_ACTION_SQN).astype(float)
+            self._prev_opt_on_device = False
+        return self._prev_opt_val
+
+    @_prev_opt.setter
+    def _prev_opt(self, v):
+        self._prev_opt_val, self._prev_opt_on_device = v, False
+
+    # ------------------------------------------------------------------ fused loop step
+    def _can_fuse(self, sim):
+        """One native call per loop iteration (rcg_loop_step) when: the decision is the on-device optimiser, no disturbance
+        model, same batch and element type as the simulator, rows that fit the handle's pinned buffer, a non-empty TD stack."""
+        row = self.dim_output + self.dim_input + 2 + (self.dim_critic if self.mode != "MPC" else 0)
+        return (sim.sys is self.sys and sim.B == self.B and sim.dtype == self._dtype and not sim.is_disturb
+                and self.candidates is None and self._use_gradient and (self.mode == "MPC" or self.Ncritic - 1 >= 1)
+                and self.B * (row + self.dim_input + 1) * 8 <= 16384)
+
+    def _tick_flags(self, t):
+        """What compute_action(t, .) will do, WITHOUT doing it: (sample, critic refit) - the float clock tests of
+        controllers.py:1440, 1466."""
+        tick = (t - self.ctrl_clock) >= self.sampling_time * (1 - self.clock_tol)
+        fit = tick and self.mode != "MPC" and (t - self.critic_clock) >= self.critic_period * (1 - self.clock_tol)
+        return bool(tick), bool(fit)
+
+    def _fused_sync(self, state):
+        """Bring the handle to the host objects' state: the simulator's state, the critic buffers and weights."""
+        self._eng.set_state(np.asarray(state, dtype=float).reshape(self.B, -1), also_init=False)
+        if self.mode != "MPC":
+            self._sync_critic_state()
+            self._eng.set_field(N.FIELD_W_CRITIC, self._b(self.w_critic, self.dim_critic))
+        self._fused_dirty = False
+
+    def _fused_step(self, sim, act, t_new, step):
+        """Called by Simulator.sim_step: hold `act` over one step, and compute ahead what the loop body will ask for at
+        t_new - the decision (if t_new is a sample), the critic push / refit, the stage cost.  Returns the new state [B, ds],
+        or None when this iteration cannot be fused (the critic push would need the controller's own action_curr where it
+        differs from the action the system holds: only before the first decision)."""
+        if self._fz is not None and self._fz["tick"]:  # a decision computed ahead that nobody took: the handle's buffers moved on
+            self._fused_dirty = True
+        self._fz = None
+        tick, fit = self._tick_flags(t_new)
+        push = tick and self.mode != "MPC"
+        if push and not np.array_equal(self._b(self.action_curr, self.dim_input), act):
+            self._fused_dirty = True
+            return None
+        prev = np.array(np.asarray(sim.state_full, dtype=float).reshape(self.B, -1)[:, :self.dim_output], copy=True)
+        if self._fused_dirty:
+            self._fused_sync(prev)
+        st, a, stage, bj, w = self._eng.loop_step(act, step, sim.n_substeps, decide=tick, push=push, fit=fit, iters=self.opt_iters)
+        st = np.array(st, copy=True)
+        a_new = np.array(a, copy=True) if tick else np.array(act, copy=True)
+        self._fz = dict(t=t_new, obs=st, xs=prev, tick=tick, fit=fit, action=a_new, J=np.array(bj, copy=True),
+                        w=None if w is None else np.array(w, copy=True))
+        self._stage_last = (st, a_new, np.array(stage, copy=True))
+        self.fused_steps += 1
+        return st
 
     # ------------------------------------------------------------------ helpers
     def _b(self, a, d):
@@ -247,7 +316,12 @@ class CtrlOptPred:
     def compute_action(self, t, observation):
         """Main method (rcognita/controllers.py:1429-1493)."""
         time_in_sample = t - self.ctrl_clock
+        fz, self._fz = self._fz, None
         if time_in_sample >= self.sampling_time * (1 - self.clock_tol):  # new sample
+            if (fz is not None and fz["tick"] and fz["t"] == t and np.array_equal(self._b(observation, self.dim_output), fz["obs"])
+                    and np.array_equal(self._b(self.state_sys, self.dim_output), fz["xs"])):
+                return self._take_fused(t, observation, fz)
+            self._fused_dirty = True  # the separate calls below use the handle's fields as scratch (and fz, if any, was for other inputs)
             self.ctrl_clock = t
             if self.mode in ("RQL", "SQL"):
                 time_in_critic_period = t - self.critic_clock
@@ -274,6 +348,36 @@ class CtrlOptPred:
             self.action_curr = action
             return action
         return self.action_curr
+
+
+    def _take_fused(self, t, observation, fz):
+        """compute_action's bookkeeping (controllers.py:1440-1493) around a decision rcg_loop_step already made from exactly
+        these inputs: clocks, the host copies of the critic buffers and weights, the action."""
+        self.ctrl_clock = t
+        if self.mode in ("RQL", "SQL"):
+            a, y = np.asarray(self.action_curr, dtype=float), np.asarray(observation, dtype=float)
+            if self._batched:
+                if self.action_buffer.ndim == 2:
+                    self.action_buffer = np.broadcast_to(self.action_buffer, (self.B,) + self.action_buffer.shape).copy()
+                    self.observation_buffer = np.broadcast_to(self.observation_buffer,
+                                                              (self.B,) + self.observation_buffer.shape).copy()
+                self.action_buffer = np.concatenate([self.action_buffer[:, 1:], a[:, None]], axis=1)
+                self.observation_buffer = np.concatenate([self.observation_buffer[:, 1:], y[:, None]], axis=1)
+            else:
+                self.action_buffer = np.vstack([self.action_buffer[1:], a])
+                self.observation_buffer = np.vstack([self.observation_buffer[1:], y])
+            if fz["fit"]:
+                self.critic_clock = t
+                self.w_critic = fz["w"].copy() if self._batched else fz["w"][0].copy()
+                self.w_critic_prev = self.w_critic
+            else:
+                self.w_critic = self.w_critic_prev
+        self._prev_opt_on_device = True
+        self.fused_decisions += 1
+        self.last_J, self.last_idx = fz["J"], None
+        action = fz["action"] if self._batched else fz["action"][0]
+        self.action_curr = action
+        return action
 
 
 class _CtrlNominal:

@@ -21,7 +21,7 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
     } else {
 #define RCG_DMA_CASE(V)                                                                                              \
   case V: {                                                                                                          \
-    auto fn = k_actor_dma<Sys, real, R, Sys::TGT, V>;                                                                \
+    auto fn = k_actor_dma<Sys, real, R, ((V) >= DMA_MPC_GEND ? true : Sys::TGT), V>;                                 \
     if (lds > 64 * 1024) /* f64 rows beyond 256 bytes: four 64-row tiles exceed the default dynamic-LDS limit */     \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 (int)lds);                                                                           \
@@ -35,6 +35,11 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
         switch (variant) {
           RCG_DMA_CASE(DMA_MPC_G1)
           RCG_DMA_CASE(DMA_MPC)
+        }
+      } else if constexpr (GROUP == 6) {
+        switch (variant) {
+          RCG_DMA_CASE(DMA_MPC_GEND)
+          RCG_DMA_CASE(DMA_MPC_GENF)
         }
       } else if constexpr (GROUP == 1) {
         switch (variant) {

@@ -411,8 +411,17 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   constexpr size_t esz = sizeof(real);
   const size_t tile = (size_t)64 * dma_rpl(R, (int)esz) * R * esz;  // one wave's LDS tile (64 x rows-per-lane rows)
   const bool mode_ok = c.mode == RCG_MODE_MPC || !knobs.mpc_only;
+  // MPC with a stage cost no preset has (a full R1, the biquadratic structure; with or without an observation target): the
+  // instances DMA_MPC_GEND / DMA_MPC_GENF (round 6; until then k_actor's plain staging, 0.09-0.37 of the
+  // HBM peak at the C2 shape: profiles/r06_generic_stream_probe_*.txt)
+  // (a diagonal quadratic cost with a target on a robot stays on k_actor's target instance: 0.78 of the peak there against 0.75 on
+  // DMA_MPC_GEND, and its gamma == 1 accumulation - per component - is the one k_ticks re-walks the rows with)
+  const bool std_cost = P.stage_kind == 0 && (tgt == Sys::TGT || !tgt);
+  const bool gen_cost = c.mode == RCG_MODE_MPC && P.stage_kind != 0 && !knobs.force_plain;
   int variant;
-  if (c.mode == RCG_MODE_MPC)
+  if (gen_cost)
+    variant = (P.stage_kind & STAGE_FULL) ? DMA_MPC_GENF : DMA_MPC_GEND;
+  else if (c.mode == RCG_MODE_MPC)
     variant = (c.gamma == 1.0 && !knobs.no_g1) ? DMA_MPC_G1 : DMA_MPC;  // per-component accumulation when gamma == 1
   else if (c.mode == RCG_MODE_RQL)
     variant = DMA_RQL_0 + c.critic_struct;
@@ -426,7 +435,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   // overtakes k_actor: 66 against 105 us at K = 24, 65 against 50 at K = 16; profiles/r04_ab_min_k.txt)
   const int dma_min_k = (c.mode != RCG_MODE_MPC && knobs.dma_min_k > 20) ? 20 : knobs.dma_min_k;
   const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= dma_min_k && slab16 && R <= dma_max_row<real>() &&
-                      P.stage_kind == 0 && mode_ok && (tgt == Sys::TGT || !tgt) && !knobs.force_plain &&
+                      (std_cost || gen_cost) && mode_ok && !knobs.force_plain &&
                       // J staging must fit next to the tiles (one block per CU then)
                       !(A.J && 4 * tile + wslot + 4 * esz * K > (size_t)160 * 1024);
   // Few candidates per env (4 <= K <= 32, whole 16-byte pieces per env) -> k_actor_dma_packed (rcg_actor_dma_packed.hpp): 64 / K envs
@@ -531,8 +540,9 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     // structures in f32, 2tank quad-lin in f64), which are bound by VALU issue, not by the stream: more resident waves hide
     // more of it - 4-5 % on random weights, 8-11 % inside a closed loop (profiles/r04_per_cu_matrix.txt, r04_ab_per_cu.txt:
     // SQL quad-lin 307 -> 280 us, SQL quadratic 261 -> 232); MPC and the small structures lose 1-2 % with 4
-    const bool valu_heavy = variant >= DMA_RQL_0 &&
-                            (size_t)dma_dc(variant >= DMA_SQL_0 ? variant - DMA_SQL_0 : variant - DMA_RQL_0, Sys::DS, DU) * esz >= 68;
+    const bool valu_heavy = variant == DMA_MPC_GENF ||  // (35-77 fused multiply-adds per step of stage cost)
+                            ((dma_is_rql(variant) || dma_is_sql(variant)) &&
+                             (size_t)dma_dc(dma_is_sql(variant) ? variant - DMA_SQL_0 : variant - DMA_RQL_0, Sys::DS, DU) * esz >= 68);
     const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 80 && long_slab && !valu_heavy) ? 2 : 4);
     // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
     Ad.jwave = (A.J && 4 * tile + wslot + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
@@ -547,7 +557,9 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     // 10-13 % slower)
     bool ok = false;
     const ProfPair pp = prof_take(h);  // a due ProfScope's pair travels in the dispatch
-    if (variant < DMA_RQL_0)
+    if (variant >= DMA_MPC_GEND)
+      ok = launch_dma<Sys, real, 6>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);
+    else if (variant < DMA_RQL_0)
       ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);
     else if (variant >= DMA_SQL_0)
       ok = launch_dma<Sys, real, 1>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);

@@ -589,6 +589,24 @@ class Engine:
         else:
             N.check(N.lib().rcg_sim_step_h(self._h, int(n_substeps), float(step)), self._h)
 
+    def loop_step(self, action, step, n_substeps=1, decide=False, push=False, fit=False, iters=10):
+        """One iteration of the reference's loop body in one native call and one host wait (rcg_loop_step): hold ``action
+        [B, du]`` (None: the handle's own) over one simulation step of length ``step``, then - as asked - push the critic
+        buffers, refit the critic, decide with the on-device optimiser (rollout from the state before the step), and
+        evaluate the stage cost of (new state, action).  Returns ``(state [B, ds], action [B, du], stage_obj [B], best_J [B]
+        (NaN without ``decide``), w_critic [B, dc] or None)`` as float64."""
+        row = self.ds + self.du + 2 + (self.dc if self.cfg.mode != "MPC" else 0)
+        out = np.empty((self.B, row), dtype=np.float64)
+        a = None
+        if action is not None:
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=np.float64), (self.B, self.du)))
+        flags = (N.LOOP_DECIDE if decide else 0) | (N.LOOP_PUSH if push else 0) | (N.LOOP_FIT if fit else 0)
+        N.check(N.lib().rcg_loop_step(self._h, None if a is None else a.ctypes.data_as(C.POINTER(C.c_double)), float(step),
+                                      int(n_substeps), flags, int(iters), out.ctypes.data_as(C.POINTER(C.c_double))), self._h)
+        ds, du = self.ds, self.du
+        return (out[:, :ds], out[:, ds:ds + du], out[:, ds + du], out[:, ds + du + 1],
+                out[:, ds + du + 2:] if row > ds + du + 2 else None)
+
     def actor_argmin(self, cand=None, K=None, obs=None, state_sys=None):
         """Returns ``(action [B, du], best_J [B], best_idx [B] int32)``."""
         keep = []

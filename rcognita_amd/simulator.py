@@ -63,6 +63,9 @@ class Simulator:
             state_init = np.concatenate([state_init, np.broadcast_to(self._q0, state_init.shape[:-1] + self._q0.shape)],
                                         axis=-1)
         self.state_full_init = state_init.copy()
+        self.dtype = dtype
+        self._eng_stale = False  # the fused loop step advanced the state on the controller's handle, not on this one
+        self.fuse = True  # build-specific: let sim_step run the fused loop step when a CtrlOptPred of the same System allows it
         self.step_idx = 0  # int: sim steps done in the current episode
         self.episode_idx = 0
         self.t = t0
@@ -81,6 +84,29 @@ class Simulator:
         (rcg_sim_step_h).  The reference's solver picks its own steps; a caller that has a recorded time grid of the
         reference can walk it (tests/test_hip_ref_traces.py)."""
         act = np.broadcast_to(np.asarray(self.sys.action, dtype=float), (self.B, self.sys.dim_input))
+        ctrl = self.sys._fused_controller(self) if self.fuse else None
+        if ctrl is not None:  # the whole loop iteration in one native call (rcg_loop_step); compute_action / stage_obj pick it up
+            self.step_idx += 1
+            t_new = self.t0 + self.step_idx * self.dt if t_next is None else float(t_next)
+            st = ctrl._fused_step(self, act, t_new, float(self.dt) if t_next is None else float(t_next) - float(self.t))
+            if st is not None:
+                self.t = t_new
+                self._eng_stale = True
+                self.state_full = self._shape(st)
+                self.state = self.state_full[..., 0:self.dim_state]
+                self.observation = self.sys_out(self.state)
+                if self.sys.ctrl_bnds.any():
+                    b = self.sys.ctrl_bnds
+                    self.sys.action = np.clip(np.asarray(self.sys.action, dtype=float), b[:, 0], b[:, 1])
+                self.sys._state = self.state
+                return
+            self.step_idx -= 1  # (this step could not be fused after all: the separate calls below)
+        if self._eng_stale:  # the controller's handle holds the current state: bring this one up to date
+            self._eng.set_state(np.asarray(self.state_full, dtype=float).reshape(self.B, -1)[:, :self.dim_state], also_init=False)
+            self._eng_stale = False
+        ref = getattr(self.sys, "_ctrl_ref", None)
+        if ref is not None and ref() is not None:
+            ref()._fused_dirty = True  # the state moves outside the controller's handle
         self._eng.set_field(N.FIELD_ACTION, act)
         self.step_idx += 1
         if t_next is None:
@@ -114,6 +140,10 @@ class Simulator:
         """Episode reset (rcognita/simulator.py:197-204, whose ``.observation`` assignment never resets
         the solver state - SURVEY.md 3.4): here the state really returns to ``state_init``."""
         self._eng.episode_reset()
+        self._eng_stale = False
+        ref = getattr(self.sys, "_ctrl_ref", None)
+        if ref is not None and ref() is not None:
+            ref()._fused_dirty = True
         self.step_idx = 0
         self.episode_idx += 1
         self.t = self.t0

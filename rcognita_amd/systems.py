@@ -69,6 +69,19 @@ class System:
                                             pars=list(self.pars), ctrl_bnds=self.ctrl_bnds, **self._disturb_cfg()))
         return self._ops
 
+    # ---- the fused loop step (rcg_loop_step): the System is what a Simulator and a CtrlOptPred have in common - the simulator is
+    # built around `my_sys.closed_loop_rhs`, the controller around `my_sys._state_dyn` (presets/main_3wrobot.py:218-320) - so it is
+    # where the two find each other
+    def _register_controller(self, ctrl):
+        import weakref
+
+        self._ctrl_ref = weakref.ref(ctrl)
+
+    def _fused_controller(self, sim):
+        ref = getattr(self, "_ctrl_ref", None)
+        ctrl = ref() if ref is not None else None
+        return ctrl if (ctrl is not None and ctrl._can_fuse(sim)) else None
+
     def native_spec(self):
         """What a Simulator / CtrlOptPred needs to build its own handle for this system."""
         return dict(sys_id=self._sys_id, pars=list(self.pars), ctrl_bnds=self.ctrl_bnds, disturb=self._disturb_cfg())

@@ -756,3 +756,56 @@ def test_packed_tiles_with_state_lag_and_per_env_parameters(name, Nh, K, dtype):
                              report=rep, what=f"{name} K={K} {dtype} lag t={t}")
     assert_kernel(eng, "k_actor_dma_packed", N.DMA_MPC_G1 | 16)  # (+ 16: the env step of the tick ran inside the launch)
     np.testing.assert_array_equal(eng.get_field(N.FIELD_STEP_IDX), np.full(B, T, np.int32))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,case", [("3wrobot", "full"), ("3wrobot", "biquad_full_tgt"), ("3wrobot", "biquad_diag"),
+                                       ("3wrobot", "biquad_diag_tgt"), ("3wrobotNI", "nonsym"), ("2tank", "full"),
+                                       ("2tank", "biquad_full_no_tgt")])
+def test_streamed_cost_structures_no_preset_has_on_the_production_kernel(name, case, dtype):
+    """Full R1 (symmetric and not), the biquadratic stage cost (controllers.py:1079-1082) with diagonal and full matrices, an
+    observation target on a robot, the tank without its target: streamed K = 128 through k_actor_dma's DMA_MPC_GEND /
+    DMA_MPC_GENF instances (round 6; round 5 ran them on k_actor's plain staging) - operator, argmin and three closed-loop
+    ticks against the oracle, whose stage_obj is pinned on the reference's F2 values for exactly these structures."""
+    from oracle import parity as PAR
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(len(case) + len(name))
+    n = len(PRESETS[name]["R1"])
+    A = rng.uniform(-1, 1, (n, n))
+    ds = n - len(PRESETS[name]["bnds"])
+    kw = {
+        "full": dict(R1=A @ A.T),
+        "nonsym": dict(R1=rng.uniform(-1, 1, (n, n)) + 2 * np.eye(n)),
+        "biquad_full_tgt": dict(R1=A @ A.T, R2=np.diag(rng.uniform(0, 1e-3, n)) + 1e-4 * (A.T @ A),
+                                stage_obj_struct=O.STAGE_BIQUADRATIC, target=rng.uniform(-1, 1, ds)),
+        "biquad_full_no_tgt": dict(R1=A @ A.T, R2=np.diag(rng.uniform(0, 1e-3, n)) + 1e-4 * (A.T @ A),
+                                   stage_obj_struct=O.STAGE_BIQUADRATIC, target=None),
+        "biquad_diag": dict(R2=np.diag(rng.uniform(0, 1e-3, n)), stage_obj_struct=O.STAGE_BIQUADRATIC),
+        "biquad_diag_tgt": dict(R2=np.diag(rng.uniform(0, 1e-3, n)), stage_obj_struct=O.STAGE_BIQUADRATIC,
+                                target=rng.uniform(-1, 1, ds)),
+    }[case]
+    B, K, Nh = 21, 128, 7
+    eng, cfg = both(name, B, dtype, n_actor=Nh, gamma=0.96, **kw)
+    x = rand_states(rng, name, B).astype(eng.real)
+    cand = rand_actions(rng, name, (B, K, Nh)).astype(eng.real)
+    dcand = eng.to_device(cand)
+    eng.set_state(x)
+    x64, c64 = x.astype(np.float64), cand.astype(np.float64)
+    J = eng.actor_cost(dcand)
+    full = case in ("full", "nonsym", "biquad_full_tgt", "biquad_full_no_tgt")
+    assert_kernel(eng, "k_actor_dma", N.DMA_MPC_GENF if full else N.DMA_MPC_GEND)
+    J_or = O.actor_cost(c64, x64[:, None, :], x64[:, None, :], cfg)
+    # full matrices mix signs: the cost is compared at the magnitude of the env's largest cost
+    scale = np.maximum(np.max(np.abs(J_or), axis=1, keepdims=True), 1.0)
+    assert np.max(np.abs(J - J_or) / scale) <= TOL[dtype] * (4 if (dtype == "f32" and full) else 1), case
+    a, bj, bi = eng.actor_argmin(dcand)
+    np.testing.assert_array_equal(bi, np.argmin(np.where(np.isnan(J), np.inf, J), axis=1).astype(np.int32))
+    np.testing.assert_array_equal(a, cand[np.arange(B), bi, 0, :])
+    env = O.new_batch(cfg, x64)
+    rep = PAR.TickReport()
+    for t in range(3):
+        eng.control_tick(dcand)
+        env = PAR.check_tick(cfg, env, c64, PAR.device_fields(eng, N, critic=False),
+                             tol=TOL[dtype] * (4 if (dtype == "f32" and full) else 1), report=rep, what=f"{case} t={t}")
+    assert_kernel(eng, "k_actor_dma", N.DMA_MPC_GENF if full else N.DMA_MPC_GEND)

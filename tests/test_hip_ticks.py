@@ -153,6 +153,10 @@ def test_tick_n_equals_n_single_ticks(name, mode, streamed):
     np.testing.assert_array_equal(a.get_state(), b.get_state())
 
 
+_FULL7 = np.random.default_rng(70).uniform(-1, 1, (7, 7))
+_FULL5 = np.random.default_rng(50).uniform(-1, 1, (5, 5))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("name,K,B,kw", [
     ("3wrobot", 64, 1024, {}),                                     # one env per wave, one tile, rows resident in LDS
@@ -162,6 +166,12 @@ def test_tick_n_equals_n_single_ticks(name, mode, streamed):
     ("2tank", 48, 515, {}),                                        # du = 1, target, one ragged tile
     ("3wrobot", 1024, 9, {}),                                      # 80 KB of rows per wave: re-staged tile by tile every tick
     ("2tank", 40, 33, dict(stage_obj_struct=O.STAGE_BIQUADRATIC, R2=np.diag([1.0, 2.0, 0.5]))),  # generic stage cost
+    # round 6: cost structures no preset has, single ticks on k_actor_dma's DMA_MPC_GEND / DMA_MPC_GENF instances - the full
+    # matrices go through the same symmetrised-triangle arithmetic in every kernel (rcg_kernels.hpp::quad_sym)
+    ("3wrobot", 64, 200, dict(R1=_FULL7 @ _FULL7.T)),
+    ("3wrobotNI", 128, 50, dict(R1=_FULL5 @ _FULL5.T, R2=1e-4 * (_FULL5.T @ _FULL5), stage_obj_struct=O.STAGE_BIQUADRATIC,
+                                target=[0.5, -1.0, 0.25], gamma=0.95)),
+    ("3wrobot", 64, 70, dict(target=[1.0, -2.0, 0.5, 0.0, 0.0])),
 ])
 def test_streamed_T_ticks_in_one_launch_equal_T_single_ticks(name, K, B, kw, dtype):
     """rcg_control_tick_n with a caller's candidate tensor on an MPC handle: ONE launch of k_ticks (the wave's rows staged
