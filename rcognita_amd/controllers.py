@@ -157,10 +157,16 @@ class CtrlOptPred:
     def _can_fuse(self, sim):
         """One native call per loop iteration (rcg_loop_step) when: the decision is the on-device optimiser, no disturbance
         model, same batch and element type as the simulator, rows that fit the handle's pinned buffer, a non-empty TD stack."""
+        key = (id(sim), self.candidates is None, self._use_gradient)
+        hit = getattr(self, "_can_fuse_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         row = self.dim_output + self.dim_input + 2 + (self.dim_critic if self.mode != "MPC" else 0)
-        return (sim.sys is self.sys and sim.B == self.B and sim.dtype == self._dtype and not sim.is_disturb
-                and self.candidates is None and self._use_gradient and (self.mode == "MPC" or self.Ncritic - 1 >= 1)
-                and self.B * (row + self.dim_input + 1) * 8 <= 16384)
+        ok = (sim.sys is self.sys and sim.B == self.B and sim.dtype == self._dtype and not sim.is_disturb
+              and self.candidates is None and self._use_gradient and (self.mode == "MPC" or self.Ncritic - 1 >= 1)
+              and self.B * (row + self.dim_input) * 8 <= 16384)
+        self._can_fuse_cache = (key, ok)
+        return ok
 
     def _tick_flags(self, t):
         """What compute_action(t, .) will do, WITHOUT doing it: (sample, critic refit) - the float clock tests of
@@ -187,28 +193,34 @@ class CtrlOptPred:
         self._fz = None
         tick, fit = self._tick_flags(t_new)
         push = tick and self.mode != "MPC"
-        if push and not np.array_equal(self._b(self.action_curr, self.dim_input), act):
+        if push and not self._same(self._b(self.action_curr, self.dim_input), act):
             self._fused_dirty = True
             return None
-        prev = np.array(np.asarray(sim.state_full, dtype=float).reshape(self.B, -1)[:, :self.dim_output], copy=True)
+        prev = np.array(sim.state_full, dtype=float).reshape(self.B, -1)[:, :self.dim_output]  # (a copy: the simulator moves on)
         if self._fused_dirty:
             self._fused_sync(prev)
         st, a, stage, bj, w = self._eng.loop_step(act, step, sim.n_substeps, decide=tick, push=push, fit=fit, iters=self.opt_iters)
-        st = np.array(st, copy=True)
-        a_new = np.array(a, copy=True) if tick else np.array(act, copy=True)
-        self._fz = dict(t=t_new, obs=st, xs=prev, tick=tick, fit=fit, action=a_new, J=np.array(bj, copy=True),
-                        w=None if w is None else np.array(w, copy=True))
-        self._stage_last = (st, a_new, np.array(stage, copy=True))
+        a_new = a if tick else np.array(act, dtype=float)
+        self._fz = dict(t=t_new, obs=st, xs=prev, tick=tick, fit=fit, action=a_new, J=bj, w=w)
+        self._stage_last = (st, a_new, stage)
         self.fused_steps += 1
         return st
 
     # ------------------------------------------------------------------ helpers
     def _b(self, a, d):
         """host array ``[d]`` or ``[B, d]`` -> ``[B, d]``"""
-        return np.broadcast_to(np.asarray(a, dtype=float).reshape(-1, d), (self.B, d))
+        a = np.asarray(a, dtype=float)
+        if a.size == self.B * d:  # already one row per env: a view, no broadcast machinery (the B = 1 loop calls this 5 x per step)
+            return a.reshape(self.B, d)
+        return np.broadcast_to(a.reshape(-1, d), (self.B, d))
 
     def _unb(self, a):
         return a if self._batched else a[0]
+
+    @staticmethod
+    def _same(a, b):
+        """Bitwise sameness of two small float arrays of equal shape (what 'the inputs the fused step computed ahead for' means)."""
+        return a is b or (a.shape == b.shape and a.tobytes() == b.tobytes())
 
     # ------------------------------------------------------------------ reference interface
     def reset(self, t0):
@@ -225,7 +237,7 @@ class CtrlOptPred:
         same arguments (upd_accum_obj, then the logger: presets/main_3wrobot.py:429-441): the last result is kept."""
         y, a = self._b(observation, self.dim_output), self._b(action, self.dim_input)
         last = getattr(self, "_stage_last", None)
-        if last is not None and last[0].shape == y.shape and np.array_equal(last[0], y) and np.array_equal(last[1], a):
+        if last is not None and self._same(last[0], y) and self._same(last[1], a):
             out = last[2]
         else:
             out = self._eng.stage_obj(y, a).astype(float)
@@ -318,8 +330,8 @@ class CtrlOptPred:
         time_in_sample = t - self.ctrl_clock
         fz, self._fz = self._fz, None
         if time_in_sample >= self.sampling_time * (1 - self.clock_tol):  # new sample
-            if (fz is not None and fz["tick"] and fz["t"] == t and np.array_equal(self._b(observation, self.dim_output), fz["obs"])
-                    and np.array_equal(self._b(self.state_sys, self.dim_output), fz["xs"])):
+            if (fz is not None and fz["tick"] and fz["t"] == t and self._same(self._b(observation, self.dim_output), fz["obs"])
+                    and self._same(self._b(self.state_sys, self.dim_output), fz["xs"])):
                 return self._take_fused(t, observation, fz)
             self._fused_dirty = True  # the separate calls below use the handle's fields as scratch (and fz, if any, was for other inputs)
             self.ctrl_clock = t

@@ -167,30 +167,6 @@ static int fill_rows(rcg_handle* h, void* base, int rows, const double* vals) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// ---- kernels of rcg_loop_step (below) ----
-// pack kernel: everything the loop body reads back, env by env, written straight into the handle's pinned (device-visible) bounce
-// buffer - no device-to-host copy call
-template <typename real>
-__global__ void k_loop_pack(const real* state, const real* action, const real* stage, const real* best_J, const real* w, int B,
-                            int ds, int du, int dc, int decided, double* out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  double* o = out + (size_t)b * (ds + du + 2 + dc);
-  for (int c = 0; c < ds; ++c) o[c] = (double)state[(size_t)c * B + b];
-  for (int c = 0; c < du; ++c) o[ds + c] = (double)action[(size_t)c * B + b];
-  o[ds + du] = (double)stage[b];
-  o[ds + du + 1] = decided ? (double)best_J[b] : __builtin_nan("");
-  for (int i = 0; i < dc; ++i) o[ds + du + 2 + i] = (double)w[(size_t)i * B + b];
-}
-template <typename real>
-__global__ void k_loop_set_action(real* action, const double* src /* pinned host, [B][du] */, int B, int du) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * du) return;
-  const int b = i / du, c = i - b * du;
-  action[(size_t)c * B + b] = (real)src[i];
-}
-
-
 extern "C" {
 
 int rcg_version(void) { return RCG_VERSION; }
@@ -931,7 +907,7 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
   if (fit && h->cfg.n_critic - 1 < 1) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_loop_step: an empty TD stack (Ncritic = 1) takes the separate calls");
   const int B = h->cfg.batch, ds = h->ds, du = h->du, dc = critic ? h->dc : 0, row = ds + du + 2 + dc;
   const size_t out_bytes = (size_t)B * row * sizeof(double), in_bytes = (size_t)B * du * sizeof(double);
-  if (out_bytes + in_bytes + (size_t)B * 8 > kBounceBytes)
+  if (out_bytes + in_bytes > kBounceBytes)
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_loop_step: %d envs do not fit the handle's %zu-byte pinned buffer (a small-batch entry point)",
                     B, kBounceBytes);
   if (decide) {
@@ -942,48 +918,34 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
     h->bounce = nullptr;
     return rcg_fail(h, RCG_ERR_HIP, "rcg_loop_step: cannot allocate the pinned buffer");
   }
-  // pinned buffer: [out rows | action_in | stage scratch (device writes)]
+  // pinned buffer: [out rows | action_in]
   double* const p_out = (double*)h->bounce;
   double* const p_act = p_out + (size_t)B * row;
-  double* const p_stage = p_act + (size_t)B * du;  // (the stage kernel writes `real`s here; read back through k_loop_pack's input)
-  const bool f64 = h->cfg.dtype == RCG_F64;
-  // System.receive_action: the action the loop holds over this step
-  if (action_in) {
-    memcpy(p_act, action_in, in_bytes);
-    if (f64)
-      hipLaunchKernelGGL(k_loop_set_action<double>, dim3(blocks_for(B * du)), dim3(256), 0, h->stream, (double*)h->f[RCG_FIELD_ACTION],
-                         (const double*)p_act, B, du);
-    else
-      hipLaunchKernelGGL(k_loop_set_action<float>, dim3(blocks_for(B * du)), dim3(256), 0, h->stream, (float*)h->f[RCG_FIELD_ACTION],
-                         (const double*)p_act, B, du);
-  }
-  // Simulator.sim_step (+ the critic modes' push and fit, one launch): one step of length step_h
+  if (action_in) memcpy(p_act, action_in, in_bytes);
+  const double* const act_dev = action_in ? p_act : nullptr;
+  // the kernels take the substep from the by-value parameter block: lend it this call's length
   const float d32 = h->p32.dt_sim;
   const double d64 = h->p64.dt_sim;
   h->p64.dt_sim = step_h / (double)n_substeps;
   h->p32.dt_sim = (float)h->p64.dt_sim;
-  int rc = push ? h->sys->critic_update(h, n_substeps, 1, fit ? 1 : 0) : h->sys->sim_step(h, n_substeps);
+  int rc;
+  if (!decide && !push) {
+    // not a controller sample: System.receive_action, Simulator.sim_step, CtrlOptPred.stage_obj and the transfer - ONE launch
+    rc = h->sys->loop(h, act_dev, n_substeps, 1, 1, 0, dc, p_out);
+  } else {
+    // a sample: receive_action + sim_step (the critic modes: k_critic_fit's env step + push + fit instead), then the decision -
+    // the rollout starts from the state BEFORE the step (the loop hands the controller my_sys._state one iteration late,
+    // controllers.py:1056-1061, presets/main_3wrobot.py:425-428), the observation is the new state - then stage_obj + transfer
+    rc = h->sys->loop(h, act_dev, n_substeps, push ? 0 : 1, 0, 0, dc, p_out);
+    if (rc == RCG_OK && push) rc = h->sys->critic_update(h, n_substeps, 1, fit ? 1 : 0);
+    if (rc == RCG_OK && decide)
+      rc = h->sys->optimize(h, iters, nullptr, h->f[RCG_FIELD_STATE_PREV], nullptr, 0, h->f[RCG_FIELD_ACTION_SQN],
+                            h->f[RCG_FIELD_ACTION], h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], false, false);
+    if (rc == RCG_OK) rc = h->sys->loop(h, nullptr, n_substeps, 0, 1, decide ? 1 : 0, dc, p_out);
+  }
   h->p32.dt_sim = d32;
   h->p64.dt_sim = d64;
   if (rc) return rc;
-  // CtrlOptPred.compute_action: the rollout starts from the state BEFORE the step (the loop hands the controller my_sys._state one
-  // iteration late, controllers.py:1056-1061, presets/main_3wrobot.py:425-428), the observation is the new state
-  if (decide) {
-    rc = h->sys->optimize(h, iters, nullptr, h->f[RCG_FIELD_STATE_PREV], nullptr, 0, h->f[RCG_FIELD_ACTION_SQN], h->f[RCG_FIELD_ACTION],
-                          h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], false, false);
-    if (rc) return rc;
-  }
-  // CtrlOptPred.stage_obj(observation, action) and the one transfer
-  rc = h->sys->stage_obj(h, h->f[RCG_FIELD_STATE], h->f[RCG_FIELD_ACTION], (void*)p_stage, B);
-  if (rc) return rc;
-  if (f64)
-    hipLaunchKernelGGL(k_loop_pack<double>, dim3(blocks_for(B)), dim3(256), 0, h->stream, (const double*)h->f[RCG_FIELD_STATE],
-                       (const double*)h->f[RCG_FIELD_ACTION], (const double*)p_stage, (const double*)h->f[RCG_FIELD_BEST_J],
-                       (const double*)h->f[RCG_FIELD_W_CRITIC], B, ds, du, dc, decide ? 1 : 0, p_out);
-  else
-    hipLaunchKernelGGL(k_loop_pack<float>, dim3(blocks_for(B)), dim3(256), 0, h->stream, (const float*)h->f[RCG_FIELD_STATE],
-                       (const float*)h->f[RCG_FIELD_ACTION], (const float*)p_stage, (const float*)h->f[RCG_FIELD_BEST_J],
-                       (const float*)h->f[RCG_FIELD_W_CRITIC], B, ds, du, dc, decide ? 1 : 0, p_out);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   memcpy(out, p_out, out_bytes);

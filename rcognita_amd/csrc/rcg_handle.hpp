@@ -238,5 +238,8 @@ struct SysVTable {
                 const void* centre, int shift, void* u_best, void* action, void* best_J, int32_t* best_idx, bool tick,
                 bool sim_first);
   int (*ticks_mem)(rcg_handle*, int32_t T, int32_t K, const void* cand);  // RQL / SQL: T ticks in one launch (k_ticks_mem)
+  // rcg_loop_step's glue kernel (k_loop): [ACTION := act_in] -> [sim step] -> [stage cost + pack into `out`]; act_in / out: pinned host
+  int (*loop)(rcg_handle*, const double* act_in, int32_t n_substeps, int32_t do_sim, int32_t do_tail, int32_t decided, int32_t dc,
+              double* out);
 };
 extern const SysVTable kVt3WRobot, kVt3WRobotNI, kVt2Tank;

@@ -14,6 +14,7 @@
 #include "rcg_critic_fit_gen.hpp"
 #include "rcg_disturb.hpp"
 #include "rcg_handle.hpp"
+#include "rcg_loop.hpp"
 #include "rcg_nominal.hpp"
 #include "rcg_search.hpp"
 #include "rcg_ticks.hpp"
@@ -72,6 +73,36 @@ static int op_stage_obj(rcg_handle* h, const void* obs, const void* act, void* o
     using real = decltype(r);
     hipLaunchKernelGGL((k_stage_obj<Sys, real>), dim3(blocks_for(n)), dim3(256), 0, h->stream, (const real*)obs,
                        (const real*)act, (real*)out, (long)n, params<real>(h));
+    HIPCHK(h, hipGetLastError());
+    return (int)RCG_OK;
+  });
+}
+
+// rcg_loop_step's glue kernel (rcg_loop.hpp): [set ACTION from the pinned host buffer] -> [sim step] -> [stage cost + pack]
+template <typename Sys>
+static int op_loop(rcg_handle* h, const double* act_in, int32_t n_substeps, int32_t do_sim, int32_t do_tail, int32_t decided,
+                   int32_t dc, double* out) {
+  return by_dtype(h, [&](auto r) {
+    using real = decltype(r);
+    LoopArgs<real> A;
+    memset(&A, 0, sizeof A);
+    A.sim.state = (real*)h->f[RCG_FIELD_STATE];
+    A.sim.state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
+    A.sim.action = (const real*)h->f[RCG_FIELD_ACTION];
+    A.sim.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+    A.sim.accum = (real*)h->f[RCG_FIELD_ACCUM];
+    A.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+    A.sim.n_sub = n_substeps;
+    A.action = (real*)h->f[RCG_FIELD_ACTION];
+    A.act_in = act_in;
+    A.best_J = (const real*)h->f[RCG_FIELD_BEST_J];
+    A.w = (const real*)h->f[RCG_FIELD_W_CRITIC];
+    A.out = out;
+    A.do_sim = do_sim;
+    A.do_tail = do_tail;
+    A.decided = decided;
+    A.dc = dc;
+    hipLaunchKernelGGL((k_loop<Sys, real>), dim3(blocks_for(h->cfg.batch, 64)), dim3(64), 0, h->stream, A, params<real>(h));
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });
@@ -1046,7 +1077,7 @@ struct SysInstances {
   static SysVTable table() {
     return SysVTable{&op_rhs<Sys>,   &op_stage_obj<Sys>, &op_critic<Sys>,        &op_critic_cost<Sys>, &op_actor<Sys>,
                      &op_sim_step<Sys>, &op_critic_update<Sys>, &op_optimize<Sys>, &op_nominal<Sys>,
-                     &op_ticks<Sys>,  &op_rhs_full<Sys>, &op_search<Sys>, &op_ticks_mem<Sys>};
+                     &op_ticks<Sys>,  &op_rhs_full<Sys>, &op_search<Sys>, &op_ticks_mem<Sys>, &op_loop<Sys>};
   }
 };
 

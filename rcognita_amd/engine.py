@@ -253,6 +253,7 @@ class Engine:
         if rc != N.OK:
             raise N.NativeError(rc, N.last_error(None))
         self._h = h
+        self._loop_fn = L.rcg_loop_step
 
     # ------------------------------------------------------------------ life cycle
     def close(self):
@@ -595,15 +596,19 @@ class Engine:
         buffers, refit the critic, decide with the on-device optimiser (rollout from the state before the step), and
         evaluate the stage cost of (new state, action).  Returns ``(state [B, ds], action [B, du], stage_obj [B], best_J [B]
         (NaN without ``decide``), w_critic [B, dc] or None)`` as float64."""
-        row = self.ds + self.du + 2 + (self.dc if self.cfg.mode != "MPC" else 0)
-        out = np.empty((self.B, row), dtype=np.float64)
-        a = None
-        if action is not None:
-            a = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=np.float64), (self.B, self.du)))
-        flags = (N.LOOP_DECIDE if decide else 0) | (N.LOOP_PUSH if push else 0) | (N.LOOP_FIT if fit else 0)
-        N.check(N.lib().rcg_loop_step(self._h, None if a is None else a.ctypes.data_as(C.POINTER(C.c_double)), float(step),
-                                      int(n_substeps), flags, int(iters), out.ctypes.data_as(C.POINTER(C.c_double))), self._h)
         ds, du = self.ds, self.du
+        row = ds + du + 2 + (self.dc if self.cfg.mode != "MPC" else 0)
+        out = np.empty((self.B, row), dtype=np.float64)  # (fresh per call: the caller keeps views of it)
+        pa = None
+        if action is not None:
+            a = np.asarray(action, dtype=np.float64)
+            if a.shape != (self.B, du) or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(np.broadcast_to(a, (self.B, du)))
+            pa = C.cast(a.ctypes.data, C.POINTER(C.c_double))
+        flags = (N.LOOP_DECIDE if decide else 0) | (N.LOOP_PUSH if push else 0) | (N.LOOP_FIT if fit else 0)
+        rc = self._loop_fn(self._h, pa, float(step), int(n_substeps), flags, int(iters), C.cast(out.ctypes.data, C.POINTER(C.c_double)))
+        if rc:
+            N.check(rc, self._h)
         return (out[:, :ds], out[:, ds:ds + du], out[:, ds + du], out[:, ds + du + 1],
                 out[:, ds + du + 2:] if row > ds + du + 2 else None)
 

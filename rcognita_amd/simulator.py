@@ -83,7 +83,8 @@ class Simulator:
         ``t_next`` (build-specific, optional): advance to that time instead - one step of length ``t_next - t``
         (rcg_sim_step_h).  The reference's solver picks its own steps; a caller that has a recorded time grid of the
         reference can walk it (tests/test_hip_ref_traces.py)."""
-        act = np.broadcast_to(np.asarray(self.sys.action, dtype=float), (self.B, self.sys.dim_input))
+        act = np.asarray(self.sys.action, dtype=float)
+        act = act.reshape(self.B, -1) if act.size == self.B * self.sys.dim_input else np.broadcast_to(act, (self.B, self.sys.dim_input))
         ctrl = self.sys._fused_controller(self) if self.fuse else None
         if ctrl is not None:  # the whole loop iteration in one native call (rcg_loop_step); compute_action / stage_obj pick it up
             self.step_idx += 1
