@@ -113,7 +113,7 @@ static void abi_host_side(void) {
   BAD(c.stage_obj_struct = 2, "stage_obj_struct");
   BAD(c.critic_struct = -1, "critic_struct");
   BAD(c.n_actor = 0, "Nactor");
-  BAD(c.n_actor = 1000, "Nactor");
+  BAD(c.n_actor = RCG_MAX_NACTOR + 1, "Nactor"); /* (round 6: any horizon up to the sanity bound; 1000 is a legal Nactor) */
   BAD(c.substeps_per_tick = 0, "substeps_per_tick");
   BAD(c.buffer_size = -1, "buffer_size");
   BAD((c.mode = RCG_MODE_RQL, c.buffer_size = 1), "buffer_size");
@@ -166,6 +166,10 @@ static void abi_host_side(void) {
   EXPECT(rcg_nominal_action(NULL, x, x, x, 1, 1.0, NULL, 0) < 0);
   EXPECT(rcg_control_tick_nominal(NULL, 1.0, NULL) < 0);
   EXPECT(rcg_critic_update(NULL, 1) < 0);
+  EXPECT(rcg_loop_step(NULL, x, 0.01, 1, RCG_LOOP_DECIDE, 3, x) < 0);
+  EXPECT(rcg_sim_step_h(NULL, 1, 0.01) < 0);
+  EXPECT(rcg_set_tick_parts(NULL, 2) < 0);
+  EXPECT(rcg_join(NULL) < 0);
   EXPECT(rcg_episode_reset(NULL) < 0);
   EXPECT(rcg_episode_stats(NULL, 0, NULL, &s) < 0);
   EXPECT(rcg_profile(NULL, 1) < 0);
