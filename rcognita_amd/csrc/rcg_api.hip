@@ -238,6 +238,7 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->d_const = nullptr;
   h->fit_scratch = nullptr;
   h->fit_scratch_bytes = 0;
+  h->loop_seq = 0;
   h->prof_mask = 0;
   h->prof_stride = 1;
   memset(h->prof_seen, 0, sizeof h->prof_seen);
@@ -460,7 +461,7 @@ int rcg_memcpy_h2d(rcg_handle* h, void* dev_dst, const void* host_src, uint64_t 
 // one DMA and one wait.
 static int copy_to_host(rcg_handle* h, void* host_dst, const void* dev_src, size_t bytes) {
   if (bytes <= kBounceBytes) {
-    if (!h->bounce && hipHostMalloc(&h->bounce, kBounceBytes, hipHostMallocDefault) != hipSuccess) h->bounce = nullptr;
+    if (!h->bounce && hipHostMalloc(&h->bounce, kBounceBytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) h->bounce = nullptr;
     if (h->bounce) {
       HIPCHK(h, hipMemcpyAsync(h->bounce, dev_src, bytes, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -907,20 +908,23 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
   if (fit && h->cfg.n_critic - 1 < 1) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_loop_step: an empty TD stack (Ncritic = 1) takes the separate calls");
   const int B = h->cfg.batch, ds = h->ds, du = h->du, dc = critic ? h->dc : 0, row = ds + du + 2 + dc;
   const size_t out_bytes = (size_t)B * row * sizeof(double), in_bytes = (size_t)B * du * sizeof(double);
-  if (out_bytes + in_bytes > kBounceBytes)
+  if (out_bytes + in_bytes + (size_t)B * sizeof(double) > kBounceBytes)
     return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_loop_step: %d envs do not fit the handle's %zu-byte pinned buffer (a small-batch entry point)",
                     B, kBounceBytes);
   if (decide) {
     const int rc = check_optimizer(h, "rcg_loop_step");
     if (rc) return rc;
   }
-  if (!h->bounce && hipHostMalloc(&h->bounce, kBounceBytes, hipHostMallocDefault) != hipSuccess) {
+  if (!h->bounce && hipHostMalloc(&h->bounce, kBounceBytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
     h->bounce = nullptr;
     return rcg_fail(h, RCG_ERR_HIP, "rcg_loop_step: cannot allocate the pinned buffer");
   }
-  // pinned buffer: [out rows | action_in]
+  // pinned buffer: [out rows | action_in | one sequence number per env]
   double* const p_out = (double*)h->bounce;
   double* const p_act = p_out + (size_t)B * row;
+  double* const p_flag = p_act + (size_t)B * du;
+  memset(p_flag, 0, (size_t)B * sizeof(double));  // (other entry points use the buffer for their reads: only THIS call's kernel may set a flag)
+  const double seq = (double)++h->loop_seq;        // (exact up to 2^53 calls)
   if (action_in) memcpy(p_act, action_in, in_bytes);
   const double* const act_dev = action_in ? p_act : nullptr;
   // the kernels take the substep from the by-value parameter block: lend it this call's length
@@ -931,23 +935,43 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
   int rc;
   if (!decide && !push) {
     // not a controller sample: System.receive_action, Simulator.sim_step, CtrlOptPred.stage_obj and the transfer - ONE launch
-    rc = h->sys->loop(h, act_dev, n_substeps, 1, 1, 0, dc, p_out);
+    rc = h->sys->loop(h, act_dev, n_substeps, 1, 1, 0, dc, p_out, p_flag, seq);
   } else {
     // a sample: receive_action + sim_step (the critic modes: k_critic_fit's env step + push + fit instead), then the decision -
     // the rollout starts from the state BEFORE the step (the loop hands the controller my_sys._state one iteration late,
     // controllers.py:1056-1061, presets/main_3wrobot.py:425-428), the observation is the new state - then stage_obj + transfer
-    rc = h->sys->loop(h, act_dev, n_substeps, push ? 0 : 1, 0, 0, dc, p_out);
+    rc = h->sys->loop(h, act_dev, n_substeps, push ? 0 : 1, 0, 0, dc, p_out, p_flag, seq);
     if (rc == RCG_OK && push) rc = h->sys->critic_update(h, n_substeps, 1, fit ? 1 : 0);
     if (rc == RCG_OK && decide)
       rc = h->sys->optimize(h, iters, nullptr, h->f[RCG_FIELD_STATE_PREV], nullptr, 0, h->f[RCG_FIELD_ACTION_SQN],
                             h->f[RCG_FIELD_ACTION], h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], false, false);
-    if (rc == RCG_OK) rc = h->sys->loop(h, nullptr, n_substeps, 0, 1, decide ? 1 : 0, dc, p_out);
+    if (rc == RCG_OK) rc = h->sys->loop(h, nullptr, n_substeps, 0, 1, decide ? 1 : 0, dc, p_out, p_flag, seq);
   }
   h->p32.dt_sim = d32;
   h->p64.dt_sim = d64;
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  // wait for the glue kernel's sequence numbers in pinned memory instead of for the stream (tools/sync_probe.hip: 6.9 us per launch
+  // + wait against 12.4): every env's row is complete once its flag shows this call's number.  Bounded: after ~50 ms of polling
+  // (a fault, a hung queue) the stream is waited for the ordinary way and whatever error it carries is returned.
+  {
+    volatile double* const f = p_flag;
+    bool done = false;
+    for (long spin = 0; spin < 20000000L && !done; ++spin) {
+      done = true;
+      for (int b = 0; b < B; ++b)
+        if (f[b] != seq) {
+          done = false;
+          break;
+        }
+      if (!done) __builtin_ia32_pause();
+    }
+    if (!done) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (int b = 0; b < B; ++b)
+        if (f[b] != seq) return rcg_fail(h, RCG_ERR_HIP, "rcg_loop_step: the glue kernel did not report env %d", b);
+    }
+  }
   memcpy(out, p_out, out_bytes);
   return RCG_OK;
 }

@@ -28,6 +28,7 @@ struct rcg_handle {
   long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
   int opt_memory;   // curvature pairs of k_actor_opt (rcg_set_optimizer); -1: the default of opt_memory_of()
   void* d_const;    // constant block in HBM, layout kConst* below
+  uint64_t loop_seq;         // rcg_loop_step: sequence number of the last call (the glue kernel hands it back through pinned memory)
   void* fit_scratch;         // k_critic_fit_gen (Ncritic - 1 > kFitMaxRows): per-env stack / factor, allocated on first use
   size_t fit_scratch_bytes;
   rcg::KParams<float> p32;
@@ -240,6 +241,6 @@ struct SysVTable {
   int (*ticks_mem)(rcg_handle*, int32_t T, int32_t K, const void* cand);  // RQL / SQL: T ticks in one launch (k_ticks_mem)
   // rcg_loop_step's glue kernel (k_loop): [ACTION := act_in] -> [sim step] -> [stage cost + pack into `out`]; act_in / out: pinned host
   int (*loop)(rcg_handle*, const double* act_in, int32_t n_substeps, int32_t do_sim, int32_t do_tail, int32_t decided, int32_t dc,
-              double* out);
+              double* out, double* flag, double seq);
 };
 extern const SysVTable kVt3WRobot, kVt3WRobotNI, kVt2Tank;

@@ -20,6 +20,8 @@ struct LoopArgs {
   const real* best_J;     // [B]
   const real* w;          // [dc][B] or nullptr
   double* out;            // pinned host [B][ds + du + 2 + dc]
+  double* flag;           // pinned host [B]: := seq once the env's row is out (the host polls it instead of a stream wait:
+  double seq;             //   6.9 us per launch + wait against 12.4 with hipStreamSynchronize, tools/sync_probe.hip)
   int do_sim, do_tail, decided, dc;
 };
 
@@ -79,6 +81,8 @@ __global__ __launch_bounds__(64) void k_loop(const LoopArgs<real> A, const KPara
     o[DS + DU] = (double)stage;
     o[DS + DU + 1] = A.decided ? (double)A.best_J[b] : __builtin_nan("");
     for (int i = 0; i < A.dc; ++i) o[DS + DU + 2 + i] = (double)A.w[(long)i * B + b];
+    __threadfence_system();  // the row is visible to the host before its sequence number is
+    *(volatile double*)(A.flag + b) = A.seq;
   }
 }
 

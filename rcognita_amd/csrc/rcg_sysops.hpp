@@ -81,7 +81,7 @@ static int op_stage_obj(rcg_handle* h, const void* obs, const void* act, void* o
 // rcg_loop_step's glue kernel (rcg_loop.hpp): [set ACTION from the pinned host buffer] -> [sim step] -> [stage cost + pack]
 template <typename Sys>
 static int op_loop(rcg_handle* h, const double* act_in, int32_t n_substeps, int32_t do_sim, int32_t do_tail, int32_t decided,
-                   int32_t dc, double* out) {
+                   int32_t dc, double* out, double* flag, double seq) {
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
     LoopArgs<real> A;
@@ -98,6 +98,8 @@ static int op_loop(rcg_handle* h, const double* act_in, int32_t n_substeps, int3
     A.best_J = (const real*)h->f[RCG_FIELD_BEST_J];
     A.w = (const real*)h->f[RCG_FIELD_W_CRITIC];
     A.out = out;
+    A.flag = flag;
+    A.seq = seq;
     A.do_sim = do_sim;
     A.do_tail = do_tail;
     A.decided = decided;
