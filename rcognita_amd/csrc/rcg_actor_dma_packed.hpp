@@ -160,17 +160,21 @@ __global__ __launch_bounds__(256) void k_actor_dma_packed(const ActorArgs<real> 
   };
 
   if (fused) {
-    issue_tile(0);  // the first tile does not depend on the env step: it travels while the wave steps its envs
-    if (lane < n_env) {
-      const long b = env0 + lane;
-      uint32_t st = A.sim_status[b];
-      real x[DS], xp[DS], u[DU];
+    // Round 6: the env step's loads are REQUESTED BEFORE the first tile's DMA.  vmcnt retires in issue order: with the tile issued
+    // first (round 5) the RK4 could not start before the whole tile had landed; now the wait in front of it covers only the few
+    // state loads and the tile travels while the wave steps its envs.
+    const bool mine = lane < n_env;
+    const long b = env0 + (mine ? lane : 0);
+    uint32_t st = A.sim_status[b];
+    real x[DS], xp[DS], u[DU];
 #pragma unroll
-      for (int c = 0; c < DS; ++c) xp[c] = x[c] = A.sim_state[(long)c * B + b];
+    for (int c = 0; c < DS; ++c) xp[c] = x[c] = A.sim_state[(long)c * B + b];
+#pragma unroll
+    for (int c = 0; c < DU; ++c) u[c] = A.sim_action[(long)c * B + b];
+    const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
+    issue_tile(0);  // the first tile does not depend on the env step
+    if (mine) {
       if (!(st & 1u)) {
-#pragma unroll
-        for (int c = 0; c < DU; ++c) u[c] = A.sim_action[(long)c * B + b];
-        const auto pre = load_pre<Sys, real>(P, A.pars_env, b);
         real accum_unused = 0;  // (RCG_FLAG_ACCUM_EVERY_SUBSTEP handles are not fused)
         if (env_substeps<Sys, real, TGT>(P, pre, A.sim_n_sub, x, xp, u, st, accum_unused)) {
 #pragma unroll
