@@ -52,3 +52,52 @@ def walk(i,n):
     t=0.5*(a+b); return (t+np.pi)%(2*np.pi)-np.pi
 for n in (64,128,256,512):
     thC=np.array([walk(i,n) for i in range(len(x))]); print('walk',n, match(thC).mean(), np.where(~match(thC))[0])
+
+
+# ---- derivative-free candidates (comparisons of Fc values only: reproducible between the kernel and the oracle) ----
+def compass(i, s0, shrink=0.5, tol=1e-9):
+    th, f, s = 0.0, F(i, 0.0), s0
+    while s > tol:
+        fl, fr = F(i, th - s), F(i, th + s)
+        if fl < f and fl <= fr:
+            th, f = th - s, fl
+        elif fr < f:
+            th, f = th + s, fr
+        else:
+            s *= shrink
+    return (th + np.pi) % (2 * np.pi) - np.pi
+
+
+for s0 in (1.0, 0.5, 0.25, 0.1):
+    thD = np.array([compass(i, s0) for i in range(len(x))])
+    print('compass search from 0, first step', s0, match(thD).mean(), np.where(~match(thD))[0])
+
+
+def expand_then_golden(i, d0=1e-3, grow=2.0):
+    """downhill direction from the sign of Fc(+d0) - Fc(-d0), steps growing by `grow` until Fc rises, golden section on the bracket"""
+    f0 = F(i, 0.0)
+    sgn = -1.0 if F(i, -d0) < F(i, d0) else 1.0
+    a, b, fb, d = 0.0, sgn * d0, F(i, sgn * d0), d0
+    if fb >= f0:
+        lo, hi = -d0, d0
+    else:
+        while True:
+            d *= grow
+            c = b + sgn * d
+            fc = F(i, c)
+            if fc >= fb or abs(c) > np.pi:
+                lo, hi = (a, c) if sgn > 0 else (c, a)
+                break
+            a, b, fb = b, c, fc
+    g = 0.6180339887498949
+    for _ in range(60):
+        x1 = hi - g * (hi - lo); x2 = lo + g * (hi - lo)
+        if F(i, x1) <= F(i, x2): hi = x2
+        else: lo = x1
+    t = 0.5 * (lo + hi)
+    return (t + np.pi) % (2 * np.pi) - np.pi
+
+
+for grow in (1.5, 2.0, 3.0):
+    thE = np.array([expand_then_golden(i, grow=grow) for i in range(len(x))])
+    print('expanding bracket from 0 + golden section, growth', grow, match(thE).mean(), np.where(~match(thE))[0])
