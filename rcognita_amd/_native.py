@@ -152,7 +152,7 @@ def lib():
         "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
         "rcg_set_optimizer": (C.c_int, [vp, i32]),
         "rcg_set_tick_parts": (C.c_int, [vp, i32]),
-        "rcg_loop_step": (C.c_int, [vp, C.POINTER(C.c_double), C.c_double, i32, i32, i32, C.POINTER(C.c_double)]),
+        "rcg_loop_step": (C.c_int, [vp, vp, C.c_double, i32, i32, i32, vp]),  # (host double pointers passed as addresses)
         "rcg_join": (C.c_int, [vp]),
         "rcg_actor_search": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rcg_control_tick_search": (C.c_int, [vp, i32, i32, i32]),

@@ -385,10 +385,14 @@ class CtrlOptPred:
             else:
                 self.w_critic = self.w_critic_prev
         self._prev_opt_on_device = True
+        self._inb_action = None
         self.fused_decisions += 1
         self.last_J, self.last_idx = fz["J"], None
         action = fz["action"] if self._batched else fz["action"][0]
         self.action_curr = action
+        # the optimiser's iterates live inside the box, so Simulator.sim_step need not clip this object (float64 handles only: a
+        # float32 bound may lie a rounding outside the float64 one the host clips with)
+        self._inb_action = action if self._dtype == "f64" else None
         return action
 
 

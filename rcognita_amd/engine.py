@@ -604,9 +604,9 @@ class Engine:
             a = np.asarray(action, dtype=np.float64)
             if a.shape != (self.B, du) or not a.flags.c_contiguous:
                 a = np.ascontiguousarray(np.broadcast_to(a, (self.B, du)))
-            pa = C.cast(a.ctypes.data, C.POINTER(C.c_double))
+            pa = a.ctypes.data
         flags = (N.LOOP_DECIDE if decide else 0) | (N.LOOP_PUSH if push else 0) | (N.LOOP_FIT if fit else 0)
-        rc = self._loop_fn(self._h, pa, float(step), int(n_substeps), flags, int(iters), C.cast(out.ctypes.data, C.POINTER(C.c_double)))
+        rc = self._loop_fn(self._h, pa, step, n_substeps, flags, iters, out.ctypes.data)
         if rc:
             N.check(rc, self._h)
         return (out[:, :ds], out[:, ds:ds + du], out[:, ds + du], out[:, ds + du + 1],

@@ -96,7 +96,9 @@ class Simulator:
                 self.state_full = self._shape(st)
                 self.state = self.state_full[..., 0:self.dim_state]
                 self.observation = self.sys_out(self.state)
-                if self.sys.ctrl_bnds.any():
+                # what System.closed_loop_rhs leaves behind: the clipped action (systems.py:241-243); the controller's own last
+                # decision - the optimiser's iterates live inside the box - needs no clip
+                if self.sys.action is not getattr(ctrl, "_inb_action", None) and self.sys.ctrl_bnds.any():
                     b = self.sys.ctrl_bnds
                     self.sys.action = np.clip(np.asarray(self.sys.action, dtype=float), b[:, 0], b[:, 1])
                 self.sys._state = self.state

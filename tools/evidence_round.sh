@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 6): bench.py's default element type is now f64 (the reference's width); this script was written for the f32 default of
+# rounds 1-5 - pass --dtype f32 where it says nothing, or use tools/profile_round6.sh, which produced profiles/r06_*.
 # The measurements DESIGN.md section 5 quotes beyond tools/profile_round.sh, written under gpurun_out/ev_<round>/ on a GPU box:
 #   gpurun --timeout 1200 -- 'bash tools/evidence_round.sh r03'   then copy gpurun_out/ev_r03/* to profiles/ (tracked)
 set -u

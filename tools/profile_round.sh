@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 6): bench.py's default element type is now f64 (the reference's width); this script was written for the f32 default of
+# rounds 1-5 - pass --dtype f32 where it says nothing, or use tools/profile_round6.sh, which produced profiles/r06_*.
 # Reproduce the evidence kept under profiles/ for one round, on a GPU box (run through gpurun from the repo root):
 #
 #   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'
