@@ -24,7 +24,7 @@ UNITS   := rcg_api
 SYSP    := $(foreach s,Sys3WRobot.kVt3WRobot Sys3WRobotNI.kVt3WRobotNI Sys2Tank.kVt2Tank,$(foreach p,0 1 2 3 4,$(s).$(p)))
 SYSFLAGS = -DRCG_SYS=$(word 1,$(subst ., ,$*)) -DRCG_SYS_VT=$(word 2,$(subst ., ,$*)) -DRCG_SYS_PART=$(word 3,$(subst ., ,$*))
 # k_actor_dma instances: rcg_dma_inst.hip compiled once per (system, element type, group), see that file
-DMA     := $(foreach s,Sys3WRobot Sys3WRobotNI Sys2Tank,$(foreach r,float double,$(foreach g,0 1 2 3 4 5 6,$(s).$(r).$(g))))
+DMA     := $(foreach s,Sys3WRobot Sys3WRobotNI Sys2Tank,$(foreach r,float double,$(foreach g,0 1 2 3 4 5 6 7,$(s).$(r).$(g))))
 DMAFLAGS = -DRCG_INST_SYS=$(word 1,$(subst ., ,$*)) -DRCG_INST_REAL=$(word 2,$(subst ., ,$*)) \
            -DRCG_INST_GROUP=$(word 3,$(subst ., ,$*))
 objs     = $(addprefix $(1)/rcg_sys.,$(addsuffix .o,$(SYSP))) $(addprefix $(1)/,$(addsuffix .o,$(UNITS))) \

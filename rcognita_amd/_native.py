@@ -57,6 +57,7 @@ KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
  KID_CRITIC_FIT, KID_ACTOR_DMA_PACKED, KID_ACTOR_SEARCH) = range(12)
 DMA_MPC_G1, DMA_MPC, DMA_RQL_0, DMA_SQL_0 = 0, 1, 2, 6  # variant of k_actor_dma (+ critic_struct; rcg_actor_dma.hpp)
 LOOP_DECIDE, LOOP_PUSH, LOOP_FIT = 1, 2, 4  # rcg_loop_step flags
+DMA_RQL_GEN_0 = 12  # + critic_struct: RQL with a stage cost no preset has
 DMA_MPC_GEND, DMA_MPC_GENF = 10, 11  # MPC with a cost structure no preset has: diagonal (biquadratic / target) | full matrices
 
 

@@ -84,10 +84,15 @@ enum : int {
   DMA_SQL_0 = 6 /* + rcg_critic_struct */,
   DMA_MPC_GEND = 10,
   DMA_MPC_GENF = 11,
-  DMA_VARIANTS = 12
+  DMA_RQL_GEN_0 = 12 /* + rcg_critic_struct: RQL with a stage cost no preset has (stage_any per step), any target */,
+  DMA_VARIANTS = 16
 };
 __host__ __device__ constexpr bool dma_is_sql(int v) { return v >= DMA_SQL_0 && v < DMA_MPC_GEND; }
-__host__ __device__ constexpr bool dma_is_rql(int v) { return v >= DMA_RQL_0 && v < DMA_SQL_0; }
+__host__ __device__ constexpr bool dma_is_rql(int v) { return (v >= DMA_RQL_0 && v < DMA_SQL_0) || v >= DMA_RQL_GEN_0; }
+// critic structure of a critic variant
+__host__ __device__ constexpr int dma_cs(int v) {
+  return v >= DMA_RQL_GEN_0 ? v - DMA_RQL_GEN_0 : (dma_is_sql(v) ? v - DMA_SQL_0 : (dma_is_rql(v) ? v - DMA_RQL_0 : 0));
+}
 
 __host__ __device__ constexpr int dma_dc(int cs, int ds, int du) {
   return cs == RCG_CRITIC_QUAD_LIN ? (ds + du) * (ds + du + 1) / 2 + (ds + du)
@@ -98,8 +103,7 @@ __host__ __device__ constexpr int dma_dc(int cs, int ds, int du) {
 // bytes of LDS per wave that hold the env's critic weights (0: they live in registers) - shared by the kernel (layout)
 // and the launcher (dynamic-LDS request)
 __host__ __device__ constexpr int dma_wslot(int esz, int variant, int ds, int du) {
-  const int dcmax = dma_is_sql(variant) ? dma_dc(variant - DMA_SQL_0, ds, du)
-                                        : (dma_is_rql(variant) ? dma_dc(variant - DMA_RQL_0, ds, du) : 0);
+  const int dcmax = (dma_is_sql(variant) || dma_is_rql(variant)) ? dma_dc(dma_cs(variant), ds, du) : 0;
   return dcmax > 9 ? ((dcmax * esz + 15) / 16) * 16 : 0;
 }
 
@@ -133,8 +137,9 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP;
   constexpr bool G1 = V == DMA_MPC_G1, SQL = dma_is_sql(V), RQL = dma_is_rql(V), CRIT = RQL || SQL;
   constexpr bool GEND = V == DMA_MPC_GEND, GENF = V == DMA_MPC_GENF, GEN = GEND || GENF;
-  static_assert(!GEN || TGT, "the generic-cost instances subtract a target (zeros for a handle without one)");
-  constexpr int CS = SQL ? V - DMA_SQL_0 : (RQL ? V - DMA_RQL_0 : 0);  // compile-time critic structure
+  constexpr bool GENR = V >= DMA_RQL_GEN_0;  // RQL whose stage cost is not the presets' diagonal quadratic one: stage_any per step
+  static_assert(!(GEN || GENR) || TGT, "the generic-cost instances subtract a target (zeros for a handle without one)");
+  constexpr int CS = dma_cs(V);  // compile-time critic structure
   constexpr int DCMAX = CRIT ? dma_dc(CS, DS, DU) : 1;
   constexpr int ESZ = (int)sizeof(real);
   constexpr int WSLOT = dma_wslot(ESZ, V, DS, DU);  // > 0: critic weights in LDS (instances with more than 9 of them)
@@ -242,19 +247,49 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
     }
   };
 
-  // (GENF) the symmetrised upper triangles of R1 / R2, once per wave, in registers for every rollout of the wave
-  constexpr int NSYM = GENF ? sym_len<NCHI>() : 1;
+  // (GENF, GENR) the symmetrised upper triangles of R1 / R2, once per wave, in registers for every rollout of the wave
+  constexpr bool TRI = GENF || GENR;
+  constexpr int NSYM = TRI ? sym_len<NCHI>() : 1;
   real S1[NSYM], S2[NSYM];
-  const bool biq = GEN && (P.stage_kind & STAGE_BIQUAD);  // wave-uniform
-  if constexpr (GENF) {
-    load_sym<NCHI, real>(P.Rfull, S1);
-    if (biq) {
+  const bool biq = (GEN || GENR) && (P.stage_kind & STAGE_BIQUAD);               // wave-uniform
+  const bool full_rt = GENF || (GENR && (P.stage_kind & STAGE_FULL));           // wave-uniform (GENF: compile-time)
+  if constexpr (TRI) {
+    if (full_rt) {
+      load_sym<NCHI, real>(P.Rfull, S1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSYM; ++i) S1[i] = 0;
+    }
+    if (full_rt && biq) {
       load_sym<NCHI, real>(P.Rfull + 49, S2);
     } else {
 #pragma unroll
       for (int i = 0; i < NSYM; ++i) S2[i] = 0;
     }
   }
+  // stage_with's arithmetic (rcg_kernels.hpp) on the register copies of the matrices: the same bits as stage_any
+  auto gen_stage = [&](const real* chi) -> real {
+    real q;
+    if (TRI && full_rt)
+      q = quad_sym<NCHI, real>(S1, chi);
+    else
+      q = stage_diag<NCHI, real>(P, chi);
+    if (biq) {
+      real c2[NCHI];
+#pragma unroll
+      for (int i = 0; i < NCHI; ++i) c2[i] = chi[i] * chi[i];
+      real q4;
+      if (TRI && full_rt) {
+        q4 = quad_sym<NCHI, real>(S2, c2);
+      } else {
+        q4 = 0;
+#pragma unroll
+        for (int i = 0; i < NCHI; ++i) q4 = fma_r(P.R2d[i] * c2[i], c2[i], q4);
+      }
+      q = q4 + q;
+    }
+    return q;
+  };
 
   fetch_env(env0);
   issue_tile(envb, rows_of(0));  // after the env request: retiring the env state must not drain the first tile
@@ -363,27 +398,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
             critic_phi_accum<DS, DU, real>(chi, y, &cur[kk * DU], Phi, CS);
           } else if (RQL && kk == N - 1) {
             J += critic_with<DS, DU, real>(chi, y, &cur[kk * DU], wget, CS);
-          } else if (GEN) {  // stage_with's arithmetic (rcg_kernels.hpp) on the register copies of the matrices
-            real q;
-            if constexpr (GENF)
-              q = quad_sym<NCHI, real>(S1, chi);
-            else
-              q = stage_diag<NCHI, real>(P, chi);
-            if (biq) {
-              real c2[NCHI];
-#pragma unroll
-              for (int i = 0; i < NCHI; ++i) c2[i] = chi[i] * chi[i];
-              real q4;
-              if constexpr (GENF) {
-                q4 = quad_sym<NCHI, real>(S2, c2);
-              } else {
-                q4 = 0;
-#pragma unroll
-                for (int i = 0; i < NCHI; ++i) q4 = fma_r(P.R2d[i] * c2[i], c2[i], q4);
-              }
-              q = q4 + q;
-            }
-            J = fma_r(gk, q, J);
+          } else if (GEN || GENR) {
+            J = fma_r(gk, gen_stage(chi), J);
             gk *= P.gamma;
           } else {
             J = fma_r(gk, stage_diag<NCHI, real>(P, chi), J);
@@ -449,7 +465,8 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
         for (int c = 0; c < DS; ++c) chi[c] = TGT ? y0[c] - P.target[c] : y0[c];
 #pragma unroll
         for (int c = 0; c < DU; ++c) chi[DS + c] = bu[c];
-        acc_inc = (GEN ? stage_any<NCHI, real>(P, chi) : stage_diag<NCHI, real>(P, chi)) * P.sampling_time;
+        // (SQL has no stage cost inside the rollout, so its instances serve ANY stage structure: only upd_accum_obj sees it)
+        acc_inc = ((GEN || GENR || SQL) ? stage_any<NCHI, real>(P, chi) : stage_diag<NCHI, real>(P, chi)) * P.sampling_time;
       }
       if (lane == (int)(b - env0)) {
         resJ = bestJ;
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(256) void k_actor_dma(const ActorArgs<real> A, cons
 // ---- launchers: the instances live in their own translation units (rcg_dma_inst.hip, one object per system x
 // element type x group, so that the library builds in parallel); rcg_sysops.hpp only sees this declaration ----------
 // group 0: DMA_MPC_G1, DMA_MPC; group 1: DMA_SQL_0 .. + 3; group 2: DMA_RQL_0 .. + 3; (3-5: k_actor_dma_packed;) group 6: DMA_MPC_GEND,
-// DMA_MPC_GENF.
+// DMA_MPC_GENF; group 7: DMA_RQL_GEN_0 .. + 3.
 // Returns false when there is no instance for (row length r, variant).  ev_a / ev_b (both or neither): the launch carries
 // them as its start / stop events (rcg_profile, rcg_handle.hpp::ProfScope).
 template <typename Sys, typename real, int GROUP>

@@ -41,6 +41,13 @@ static bool launch_dma_r(int r, int variant, dim3 grid, dim3 block, size_t lds, 
           RCG_DMA_CASE(DMA_MPC_GEND)
           RCG_DMA_CASE(DMA_MPC_GENF)
         }
+      } else if constexpr (GROUP == 7) {
+        switch (variant) {
+          RCG_DMA_CASE(DMA_RQL_GEN_0 + RCG_CRITIC_QUAD_LIN)
+          RCG_DMA_CASE(DMA_RQL_GEN_0 + RCG_CRITIC_QUADRATIC)
+          RCG_DMA_CASE(DMA_RQL_GEN_0 + RCG_CRITIC_QUAD_NOMIX)
+          RCG_DMA_CASE(DMA_RQL_GEN_0 + RCG_CRITIC_QUAD_MIX)
+        }
       } else if constexpr (GROUP == 1) {
         switch (variant) {
           RCG_DMA_CASE(DMA_SQL_0 + RCG_CRITIC_QUAD_LIN)

@@ -451,13 +451,17 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   // DMA_MPC_GEND, and its gamma == 1 accumulation - per component - is the one k_ticks re-walks the rows with)
   const bool std_cost = P.stage_kind == 0 && (tgt == Sys::TGT || !tgt);
   const bool gen_cost = c.mode == RCG_MODE_MPC && P.stage_kind != 0 && !knobs.force_plain;
+  // RQL with such a stage cost (or a target its system's preset has not): DMA_RQL_GEN_* (stage_any per step); SQL has no stage
+  // cost inside the rollout - its instances serve any stage structure (only upd_accum_obj sees it)
+  const bool gen_rql = c.mode == RCG_MODE_RQL && !std_cost && !knobs.force_plain;
+  const bool sql_any = c.mode == RCG_MODE_SQL && (tgt == Sys::TGT || !tgt);
   int variant;
   if (gen_cost)
     variant = (P.stage_kind & STAGE_FULL) ? DMA_MPC_GENF : DMA_MPC_GEND;
   else if (c.mode == RCG_MODE_MPC)
     variant = (c.gamma == 1.0 && !knobs.no_g1) ? DMA_MPC_G1 : DMA_MPC;  // per-component accumulation when gamma == 1
   else if (c.mode == RCG_MODE_RQL)
-    variant = DMA_RQL_0 + c.critic_struct;
+    variant = (gen_rql ? DMA_RQL_GEN_0 : DMA_RQL_0) + c.critic_struct;
   else
     variant = DMA_SQL_0 + c.critic_struct;
   const size_t wslot = (size_t)4 * dma_wslot((int)esz, variant, Sys::DS, DU);  // critic weights parked in LDS (> 9 of them)
@@ -468,7 +472,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
   // overtakes k_actor: 66 against 105 us at K = 24, 65 against 50 at K = 16; profiles/r04_ab_min_k.txt)
   const int dma_min_k = (c.mode != RCG_MODE_MPC && knobs.dma_min_k > 20) ? 20 : knobs.dma_min_k;
   const bool dma_ok = cand && ((uintptr_t)cand % 16) == 0 && K >= dma_min_k && slab16 && R <= dma_max_row<real>() &&
-                      (std_cost || gen_cost) && mode_ok && !knobs.force_plain &&
+                      (std_cost || gen_cost || gen_rql || sql_any) && mode_ok && !knobs.force_plain &&
                       // J staging must fit next to the tiles (one block per CU then)
                       !(A.J && 4 * tile + wslot + 4 * esz * K > (size_t)160 * 1024);
   // Few candidates per env (4 <= K <= 32, whole 16-byte pieces per env) -> k_actor_dma_packed (rcg_actor_dma_packed.hpp): 64 / K envs
@@ -574,8 +578,8 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     // more of it - 4-5 % on random weights, 8-11 % inside a closed loop (profiles/r04_per_cu_matrix.txt, r04_ab_per_cu.txt:
     // SQL quad-lin 307 -> 280 us, SQL quadratic 261 -> 232); MPC and the small structures lose 1-2 % with 4
     const bool valu_heavy = variant == DMA_MPC_GENF ||  // (35-77 fused multiply-adds per step of stage cost)
-                            ((dma_is_rql(variant) || dma_is_sql(variant)) &&
-                             (size_t)dma_dc(dma_is_sql(variant) ? variant - DMA_SQL_0 : variant - DMA_RQL_0, Sys::DS, DU) * esz >= 68);
+                            variant >= DMA_RQL_GEN_0 ||
+                            ((dma_is_rql(variant) || dma_is_sql(variant)) && (size_t)dma_dc(dma_cs(variant), Sys::DS, DU) * esz >= 68);
     const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 80 && long_slab && !valu_heavy) ? 2 : 4);
     // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
     Ad.jwave = (A.J && 4 * tile + wslot + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
@@ -590,7 +594,9 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     // 10-13 % slower)
     bool ok = false;
     const ProfPair pp = prof_take(h);  // a due ProfScope's pair travels in the dispatch
-    if (variant >= DMA_MPC_GEND)
+    if (variant >= DMA_RQL_GEN_0)
+      ok = launch_dma<Sys, real, 7>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);
+    else if (variant >= DMA_MPC_GEND)
       ok = launch_dma<Sys, real, 6>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);
     else if (variant < DMA_RQL_0)
       ok = launch_dma<Sys, real, 0>(R, variant, grid, block, lds_req, h->stream, Ad, P, pp.a, pp.b);

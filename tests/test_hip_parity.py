@@ -812,3 +812,54 @@ def test_streamed_cost_structures_no_preset_has_on_the_production_kernel(name, c
         env = PAR.check_tick(cfg, env, c64, PAR.device_fields(eng, N, critic=False),
                              tol=TOL[dtype] * (4 if (dtype == "f32" and full) else 1), report=rep, what=f"{case} t={t}")
     assert_kernel(eng, "k_actor_dma", N.DMA_MPC_GENF if full else N.DMA_MPC_GEND)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name,mode,cs,case", [("3wrobot", "RQL", "quad-nomix", "full"), ("3wrobot", "RQL", "quad-lin", "biquad_diag"),
+                                               ("3wrobotNI", "RQL", "quad-mix", "biquad_full_tgt"), ("2tank", "RQL", "quadratic", "full"),
+                                               ("3wrobot", "SQL", "quad-nomix", "full"), ("2tank", "SQL", "quad-lin", "biquad_full")])
+def test_streamed_critic_modes_with_cost_structures_no_preset_has(name, mode, cs, case, dtype):
+    """RQL / SQL with a full R1 or the biquadratic stage cost, streamed K = 128: RQL on k_actor_dma's DMA_RQL_GEN_* instances
+    (stage_any per step), SQL on its ordinary instances (no stage cost inside the rollout: only upd_accum_obj sees the structure)
+    - operator, argmin and three closed-loop ticks (env step, push, fit, decision, accum) against the oracle."""
+    from oracle import parity as PAR
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(len(case) + 3 * len(name) + len(cs))
+    n = len(PRESETS[name]["R1"])
+    ds = n - len(PRESETS[name]["bnds"])
+    A = rng.uniform(-1, 1, (n, n))
+    kw = {
+        "full": dict(R1=A @ A.T),
+        "biquad_diag": dict(R2=np.diag(rng.uniform(0, 1e-3, n)), stage_obj_struct=O.STAGE_BIQUADRATIC),
+        "biquad_full": dict(R1=A @ A.T, R2=np.diag(rng.uniform(0, 1e-3, n)) + 1e-4 * (A.T @ A), stage_obj_struct=O.STAGE_BIQUADRATIC),
+        "biquad_full_tgt": dict(R1=A @ A.T, R2=np.diag(rng.uniform(0, 1e-3, n)) + 1e-4 * (A.T @ A),
+                                stage_obj_struct=O.STAGE_BIQUADRATIC, target=rng.uniform(-1, 1, ds)),
+    }[case]
+    B, K, Nh = 21, 128, 6
+    eng, cfg = both(name, B, dtype, n_actor=Nh, gamma=0.96, mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs], n_critic=4,
+                    buffer_size=6, **kw)
+    x = rand_states(rng, name, B).astype(eng.real)
+    cand = rand_actions(rng, name, (B, K, Nh)).astype(eng.real)
+    w = rng.uniform(0.1, 2.0, (B, cfg.dc)).astype(eng.real)
+    dcand = eng.to_device(cand)
+    eng.set_state(x)
+    eng.set_field(N.FIELD_W_CRITIC, w)
+    x64, c64 = x.astype(np.float64), cand.astype(np.float64)
+    J = eng.actor_cost(dcand)
+    want = (N.DMA_RQL_GEN_0 if mode == "RQL" else N.DMA_SQL_0) + N.CRITIC_IDS[cs]
+    assert_kernel(eng, "k_actor_dma", want)
+    J_or = O.actor_cost(c64, x64[:, None, :], x64[:, None, :], cfg, w_critic=w.astype(np.float64)[:, None, :])
+    scale = np.maximum(np.max(np.abs(J_or), axis=1, keepdims=True), 1.0)
+    tol = TOL[dtype] * (4 if dtype == "f32" else 1)
+    assert np.max(np.abs(J - J_or) / scale) <= tol, case
+    a, bj, bi = eng.actor_argmin(dcand)
+    np.testing.assert_array_equal(bi, np.argmin(np.where(np.isnan(J), np.inf, J), axis=1).astype(np.int32))
+    env = O.new_batch(cfg, x64)
+    rep = PAR.TickReport()
+    for t in range(3):
+        eng.control_tick(dcand)
+        env = PAR.check_tick(cfg, env, c64, PAR.device_fields(eng, N, critic=True), tol=tol if dtype == "f32" else 1e-9,
+                             tol_over={"w_critic": 1e-6, "best_J": 1e-7} if dtype == "f64" else None, report=rep,
+                             what=f"{mode} {case} t={t}")
+    assert_kernel(eng, "k_actor_dma", want)

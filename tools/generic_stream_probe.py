@@ -39,6 +39,9 @@ CASES = [
     ("3wrobot", "biquadratic, full R1 R2", 256, 10, dict(stage_obj_struct="biquadratic", R1=R1_full, R2=R2_full)),
     ("3wrobot", "diagonal R1 + observation target", 256, 10, dict(observation_target=[1.0, -2.0, 0.5, 0.0, 0.0])),
     ("3wrobot", "RQL quad-nomix, full R1", 256, 10, dict(R1=R1_full, mode="RQL", critic_struct="quad-nomix", buffer_size=10)),
+    ("3wrobot", "SQL quad-nomix, full R1", 256, 10, dict(R1=R1_full, mode="SQL", critic_struct="quad-nomix", buffer_size=10)),
+    ("3wrobot", "RQL quad-lin (35 weights), biquadratic diagonal", 256, 10, dict(stage_obj_struct="biquadratic", R2=R2_diag, mode="RQL",
+                                                                                critic_struct="quad-lin", buffer_size=10)),
     ("2tank", "diagonal R1, slab of 255 x 36 B (not 16-byte pieces)", 255, 9, {}),
     ("2tank", "full R1 (with the preset's target)", 256, 20, dict(R1=A3 @ A3.T + np.diag([10.0, 10, 1]))),
 ]
