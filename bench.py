@@ -1013,8 +1013,12 @@ def closed_loop_value(sec):
     if not regimes:
         return None
     best = max(regimes, key=lambda k: regimes[k]["value"])
+    f64r = sec.get("closed_loop_f64") or {}
+    f64v = {k: v["env_control_steps_per_s"] for k, v in f64r.items() if isinstance(v, dict) and "env_control_steps_per_s" in v}
     return {"value": regimes[best]["value"], "unit": "env-control-steps/s", "regime": best, "what": regimes[best]["what"],
             "regimes": regimes, "dtype": "f32",
+            "value_f64": (max(f64v.values()) if f64v else None), "regime_f64": (max(f64v, key=f64v.get) if f64v else None),
+            "regimes_f64": f64v,
             "note": "candidates change every tick in each of these; the headline `value` streams one static tensor"}
 
 
@@ -1193,6 +1197,20 @@ def secondary(args, device, stream_ptr, x0, B, K, Nh, torch, Engine, N):
             ot[f"memory_{mem}"] = {"env_control_steps_per_s": B / dt_o, "ms_per_step": dt_o * 1e3, "iters": 5}
         eng2.set_optimizer(4)
         sec["optimizer_tick"] = ot
+        # the same decisions in float64 (the reference's width, the headline's): optimiser tick and device search
+        ecfg64, _ = c2_engine_config(args, device, B, dtype="f64")
+        e64 = Engine(ecfg64)
+        e64.set_stream(stream_ptr)
+        e64.set_state(x0)
+        f64r = {}
+        for mem in (0, 4):
+            e64.set_optimizer(mem)
+            dt_o = timed(lambda: e64.control_tick_opt(iters=5, warm_start=True), nn)
+            f64r[f"optimizer_memory{mem}"] = {"env_control_steps_per_s": B / dt_o, "ms_per_step": dt_o * 1e3, "iters": 5}
+        dt_s = timed(lambda: e64.control_tick_search(K=K, rounds=1, warm_start=True), nn)
+        f64r["device_search_1_round"] = {"env_control_steps_per_s": B / dt_s, "ms_per_step": dt_s * 1e3}
+        e64.close()
+        sec["closed_loop_f64"] = f64r
     except Exception as e:  # never let a secondary figure take the bench line down
         sec["device_search"] = {"error": str(e)[:300]}
     eng2.close()

@@ -157,15 +157,17 @@ class CtrlOptPred:
     def _can_fuse(self, sim):
         """One native call per loop iteration (rcg_loop_step) when: the decision is the on-device optimiser, no disturbance
         model, same batch and element type as the simulator, rows that fit the handle's pinned buffer, a non-empty TD stack."""
-        key = (id(sim), self.candidates is None, self._use_gradient)
+        key = (self.candidates is None, self._use_gradient)
         hit = getattr(self, "_can_fuse_cache", None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[0]() is sim and hit[1] == key:  # (a weak reference: an id() may be reused by a later object)
+            return hit[2]
         row = self.dim_output + self.dim_input + 2 + (self.dim_critic if self.mode != "MPC" else 0)
         ok = (sim.sys is self.sys and sim.B == self.B and sim.dtype == self._dtype and not sim.is_disturb
               and self.candidates is None and self._use_gradient and (self.mode == "MPC" or self.Ncritic - 1 >= 1)
               and self.B * (row + self.dim_input) * 8 <= 16384)
-        self._can_fuse_cache = (key, ok)
+        import weakref
+
+        self._can_fuse_cache = (weakref.ref(sim), key, ok)
         return ok
 
     def _tick_flags(self, t):

@@ -48,3 +48,10 @@ python tools/critic_stream_probe.py f64 2>/dev/null | grep -v amdgpu > $O/r06_cr
 python tools/b1_profile.py 2>&1 | grep -v amdgpu | head -30 > $O/r06_b1_profile.txt
 ls $O
 fi
+if [ "$PART" = 3 ]; then
+# kernel trace of the configs that are parity cases rather than the bench line (configs[2] generated / streamed x MPC / RQL / SQL,
+# optimiser tick, operator boundary, nominal ticks, disturbed tick, env step at 2^24 envs, configs[4] shard): k_critic_fit et al.
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_configs_r06 -o kt -- \
+  python3 tools/bench_configs.py > gpurun_out/bench_configs_r06_profiled.json 2> gpurun_out/prof_kt_configs_r06.log
+python tools/bench_configs.py > gpurun_out/bench_configs_r06.json 2> gpurun_out/bench_configs_r06.err
+fi
