@@ -457,9 +457,10 @@ typedef enum rcg_kernel_id {
   RCG_KID_ACTOR_SEARCH = 11, /* k_actor_search: candidates generated, evaluated and refined in one launch (rcg_actor_search) */
   RCG_KID_COUNT_ = 12
 } rcg_kernel_id;
-/* variant: k_actor_dma, k_actor_dma_packed: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL (k_actor_dma_packed: + 16 when the env step of the tick ran inside the launch); k_actor / k_ticks: bit 0 generic
- * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates, bit 3 the hand-packed generated-grid instance; k_critic_fit: critic_struct + 16 * (rows
- * the instance is compiled for) + 256 * do_sim + 512 * do_fit + 1024 * (the four-lanes-per-env form, structures with >= 20 weights); others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
+/* variant: k_actor_dma, k_actor_dma_packed: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL (k_actor_dma_packed: + 16 when the env step of the tick ran inside the launch);
+ * k_actor_dma, round 6: 10 / 11 MPC with a biquadratic (diagonal) / full-matrix stage cost, 12 + critic_struct RQL with such a cost (SQL: its ordinary instances); k_actor / k_ticks: bit 0 generic
+ * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates, bit 3 the hand-packed generated-grid instance, bit 4 (k_actor) rows beyond RCG_MAX_ROW walked straight from HBM; k_critic_fit: critic_struct + 16 * (rows
+ * the instance is compiled for; 0: any) + 256 * do_sim + 512 * do_fit + 1024 * (the four-lanes-per-env form, structures with >= 9 weights) + 2048 * (the any-number-of-rows form, Ncritic - 1 > 8); others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
  * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Bit 12 (4096) of variant: the launch served one half
  * of a split tick (rcg_set_tick_parts).  Each out pointer may be NULL. */
 int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave);
