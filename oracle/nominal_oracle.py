@@ -6,17 +6,17 @@ SURVEY.md 8f row f3.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_ba
 
 Pinned on tests/golden/F10_nominal_*.npz (outputs of the reference, oracle/gen_nominal_fixtures.py).  The reference
 finds theta* with scipy.optimize.minimize(method='trust-constr', tol=1e-6, maxiter=50) from theta = 0
-(controllers.py:1625-1634): third-party, path dependent, local.  The build defines theta* instead as the minimiser
-of Fc over a 64-point scan of the period refined by a fixed-length golden-section search (:func:`theta_star`); F10
-compares by the value of Fc reached and, where both land in the same basin, by the action.
+(controllers.py:1625-1634): third-party, path dependent, local.  The build defines theta* instead by a compass search
+from theta = 0 (:func:`theta_star`); F10 compares by the value of Fc reached and, where both land in the same basin, by
+the action.
 
 All functions take arrays with a leading batch axis.  0/0 at the exact origin yields NaN exactly as in the reference.
 """
 import numpy as np
 
-N_THETA = 64       # scan points over one period, theta_j = -pi + j * 2 pi / 64 (j = 32 is the reference's start, 0)
-GOLD_ITERS = 40    # golden-section steps on [theta_j* - h, theta_j* + h]
-INV_PHI = 0.6180339887498949
+THETA_STEP0 = 0.25      # first step of the compass search from theta = 0
+THETA_TOL = 1e-9        # the search stops once its step is this short
+THETA_MAX_ITERS = 200   # (a period is at most 26 steps of 0.25 away, 28 halvings reach the tolerance)
 
 
 def _scbrt(d):
@@ -87,45 +87,31 @@ def _wrap(theta):
 
 def theta_star(xNI, eta):
     """Build-defined replacement of _minimizer_theta (controllers.py:1618-1627), which runs SciPy trust-constr from
-    theta = 0: a LOCAL search.  Fc is 2 pi periodic in theta:
-    (1) on the grid theta_j = -pi + j h, h = 2 pi / 64, walk downhill from theta = 0 (j = 32): step to the lower
-        neighbour (the left one on a tie) while it is lower than the current point, at most 64 steps, non-finite = +inf;
-    (2) GOLD_ITERS golden-section steps on [theta_j* - h, theta_j* + h] (ties keep the left part);
-    (3) midpoint of the final bracket, wrapped into [-pi, pi].  The HIP kernel k_nominal mirrors this exactly.
-    On the F10 states this lands on the reference's minimiser for 93 % of them (round 1 took the GLOBAL minimum of the
-    64-point scan: never a worse Fc than the reference, but the reference's own basin for only 72 %)."""
+    theta = 0: a LOCAL, path-dependent search.  Round 6: a compass search from theta = 0 (what trust-constr starts from):
+      step s = THETA_STEP0 = 0.25; at most THETA_MAX_ITERS times: evaluate Fc at theta - s and theta + s (non-finite = +inf);
+      move to the lower one if it is lower than Fc(theta) (the left one on a tie), else halve s; stop when s <= THETA_TOL;
+      wrap into [-pi, pi).
+    Only comparisons of Fc values decide, so the HIP kernel k_nominal, which mirrors this statement by statement, takes the same
+    path.  On the F10 states this is the reference's minimiser on 94.8 % of them, its action (2 %) on 96.9 %, and Fc(theta*) is
+    never above the reference's (rounds 2-5: downhill walk on a 64-point grid + golden section: 92.7 % / 94.8 % / 96.9 %;
+    round 1: the GLOBAL minimum of the scan, 72 %).  The alternatives measured: oracle/experiments/theta_search_study.py."""
     B = xNI.shape[0]
-    h = 2 * np.pi / N_THETA
     with np.errstate(all="ignore"):
         fin = lambda th: (lambda f: np.where(np.isfinite(f), f, np.inf))(Fc(xNI, eta, th))
-        grid = lambda j: -np.pi + np.mod(j, N_THETA) * h
-        bj = np.full(B, N_THETA // 2, dtype=np.int64)
-        fc = fin(grid(bj))
-        for _ in range(N_THETA):
-            fl, fr = fin(grid(bj - 1)), fin(grid(bj + 1))
-            go_l = (fl < fc) & (fl <= fr)
-            go_r = (~go_l) & (fr < fc)
-            if not (go_l | go_r).any():
+        th = np.zeros(B)
+        f = fin(th)
+        s = np.full(B, THETA_STEP0)
+        for _ in range(THETA_MAX_ITERS):
+            live = s > THETA_TOL
+            if not live.any():
                 break
-            bj = np.where(go_l, bj - 1, np.where(go_r, bj + 1, bj))
-            fc = np.where(go_l, fl, np.where(go_r, fr, fc))
-        bj = np.mod(bj, N_THETA)
-        a = -np.pi + (bj - 1) * h
-        b = -np.pi + (bj + 1) * h
-        x1 = b - INV_PHI * (b - a)
-        x2 = a + INV_PHI * (b - a)
-        f1, f2 = fin(x1), fin(x2)
-        for _ in range(GOLD_ITERS):
-            left = f1 <= f2
-            b = np.where(left, x2, b)
-            a = np.where(left, a, x1)
-            nx1 = b - INV_PHI * (b - a)
-            nx2 = a + INV_PHI * (b - a)
-            # reuse: when keeping the left part the old x1 becomes the new x2, and vice versa
-            nf1 = np.where(left, fin(nx1), f2)
-            nf2 = np.where(left, f1, fin(nx2))
-            x1, x2, f1, f2 = np.where(left, nx1, x2), np.where(left, x1, nx2), nf1, nf2
-        return _wrap(0.5 * (a + b))
+            fl, fr = fin(th - s), fin(th + s)
+            go_l = live & (fl < f) & (fl <= fr)
+            go_r = live & (~go_l) & (fr < f)
+            th = np.where(go_l, th - s, np.where(go_r, th + s, th))
+            f = np.where(go_l, fl, np.where(go_r, fr, f))
+            s = np.where(live & ~(go_l | go_r), 0.5 * s, s)
+        return th - 2 * np.pi * np.floor((th + np.pi) / (2 * np.pi))
 
 
 def clip_bnds(u, bnds):

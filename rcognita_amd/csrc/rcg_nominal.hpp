@@ -20,8 +20,9 @@
 
 namespace rcg {
 
-constexpr int NOM_N_THETA = 64;
-constexpr int NOM_GOLD_ITERS = 40;
+// theta* of CtrlNominal3WRobot (round 6): compass search from theta = 0, the statements of oracle/nominal_oracle.py::theta_star
+constexpr double NOM_THETA_STEP0 = 0.25, NOM_THETA_TOL = 1e-9;
+constexpr int NOM_THETA_MAX_ITERS = 200;
 
 template <typename real>
 __device__ __forceinline__ real sgn_r(real v) {
@@ -44,6 +45,8 @@ __device__ __forceinline__ void nom_sincos<double>(double x, double* s, double* 
 }
 __device__ __forceinline__ float abs_r(float v) { return ::fabsf(v); }
 __device__ __forceinline__ double abs_r(double v) { return ::fabs(v); }
+__device__ __forceinline__ float floor_r(float v) { return ::floorf(v); }
+__device__ __forceinline__ double floor_r(double v) { return ::floor(v); }
 
 // _Cart2NH (controllers.py:1636-1668, 1877-1893)
 template <typename real>
@@ -143,56 +146,26 @@ struct Nominal<Sys3WRobot> {
     const real sq3 = sqrt_r(ax3), a3 = ax3 * ax3 * ax3;
     const real x14x24 = xn[0] * xn[0] * xn[0] * xn[0] + xn[1] * xn[1] * xn[1] * xn[1];
     const real PI = (real)3.141592653589793238462643383279502884;
-    const real h = (real)2 * PI / (real)NOM_N_THETA;
-    // walk downhill on the grid from theta = 0 (j = N/2): to the lower neighbour (the left one on a tie) while it is
-    // lower than the current point; each step costs one new evaluation (the other two are the previous step's)
-    auto grid = [&](int j) -> real {
-      const int jm = ((j % NOM_N_THETA) + NOM_N_THETA) % NOM_N_THETA;
-      return nom_Fc<real>(xn, eta, sq3, a3, x14x24, -PI + (real)jm * h);
+    // compass search from theta = 0 (where the reference's trust-constr starts): look one step s to both sides, move to the lower
+    // side if it is lower than the current point (the left one on a tie), else halve s; non-finite values count as +inf
+    auto fin = [&](real th) -> real {
+      const real v = nom_Fc<real>(xn, eta, sq3, a3, x14x24, th);
+      return finite_r<real>(v) ? v : inf_r<real>();
     };
-    int bj = NOM_N_THETA / 2;
-    real fc = grid(bj), fl = grid(bj - 1), fr = grid(bj + 1);
-    for (int it = 0; it < NOM_N_THETA; ++it) {
-      if (fl < fc && fl <= fr) {
-        --bj;
-        fr = fc;
-        fc = fl;
-        fl = grid(bj - 1);
-      } else if (fr < fc) {
-        ++bj;
-        fl = fc;
-        fc = fr;
-        fr = grid(bj + 1);
+    real th = (real)0, f = fin((real)0), s = (real)NOM_THETA_STEP0;
+    for (int it = 0; it < NOM_THETA_MAX_ITERS && s > (real)NOM_THETA_TOL; ++it) {
+      const real fl = fin(th - s), fr = fin(th + s);
+      if (fl < f && fl <= fr) {
+        th -= s;
+        f = fl;
+      } else if (fr < f) {
+        th += s;
+        f = fr;
       } else {
-        break;
+        s *= (real)0.5;
       }
     }
-    bj = ((bj % NOM_N_THETA) + NOM_N_THETA) % NOM_N_THETA;
-    const real IPHI = (real)0.6180339887498949;
-    real a = -PI + (real)(bj - 1) * h, b = -PI + (real)(bj + 1) * h;
-    real t1 = b - IPHI * (b - a), t2 = a + IPHI * (b - a);
-    real f1 = nom_Fc<real>(xn, eta, sq3, a3, x14x24, t1), f2 = nom_Fc<real>(xn, eta, sq3, a3, x14x24, t2);
-    for (int it = 0; it < NOM_GOLD_ITERS; ++it) {
-      const bool left = f1 <= f2;
-      if (left) {
-        b = t2;
-        t2 = t1;
-        f2 = f1;
-        t1 = b - IPHI * (b - a);
-      } else {
-        a = t1;
-        t1 = t2;
-        f1 = f2;
-        t2 = a + IPHI * (b - a);
-      }
-      const real fn = nom_Fc<real>(xn, eta, sq3, a3, x14x24, left ? t1 : t2);
-      if (left)
-        f1 = fn;
-      else
-        f2 = fn;
-    }
-    real th = (real)0.5 * (a + b);
-    th = th > PI ? th - (real)2 * PI : (th < -PI ? th + (real)2 * PI : th);
+    th = th - (real)2 * PI * floor_r((th + PI) / ((real)2 * PI));
     *th_out = th;
     real st, ct, z[3], kap[2], sig;
     nom_sincos<real>(th, &st, &ct);

@@ -61,9 +61,10 @@ def _check_search_and_law(x, th, a, L, meta, what, law_tol=1e-8):
 
 def test_endi_nominal_vs_oracle_and_reference_f64():
     """(a) HIP == oracle on every env: the control law given theta*, and theta* itself (rcg_nominal_theta), separately;
-    (b) the reference's own minimiser (trust-constr from theta = 0) on > 90 % of the fixture states and Fc(theta*) not
-    above the reference's on >= 95 % - the build-defined search against SciPy's, statistical by nature (DESIGN.md 6);
-    (c) the clipped actions agree with the reference's on > 90 % of ALL states."""
+    (b) the reference's own minimiser (trust-constr from theta = 0) on > 94 % of the fixture states and Fc(theta*) not
+    above the reference's on >= 99 % - the build-defined search (round 6: compass search from theta = 0) against SciPy's,
+    statistical by nature (DESIGN.md 7);
+    (c) the clipped actions agree with the reference's on > 96 % of ALL states."""
     meta, z = load_golden("F10_nominal_3wrobot")
     x = z["state"]
     eng, _ = both("3wrobot", x.shape[0], "f64")
@@ -72,10 +73,10 @@ def test_endi_nominal_vs_oracle_and_reference_f64():
     th = eng.nominal_theta(x)
     th_or = _check_search_and_law(x, th, a, L, meta, "F10 states, f64")
     # (b), (c): against the reference's trust-constr
-    assert np.mean(L <= z["Fc_star"] * (1 + 1e-9) + 1e-12) >= 0.95
+    assert np.mean(L <= z["Fc_star"] * (1 + 1e-9) + 1e-12) >= 0.99
     same = np.abs(np.angle(np.exp(1j * (th_or - z["theta_star"])))) < 1e-3
     close = np.all(np.abs(a - z["action"]) <= 2e-2 * (np.abs(z["action"]) + 1), axis=1)
-    assert same.mean() > 0.9 and close[same].mean() > 0.95 and close.mean() > 0.9
+    assert same.mean() > 0.94 and close[same].mean() > 0.95 and close.mean() > 0.96
     # handle pars are the default controller parameters
     a2 = eng.nominal_action(x, meta["ctrl_gain"], clip=True)
     np.testing.assert_array_equal(a2, a)

@@ -52,9 +52,10 @@ def test_F10_endi_operators_match_reference():
 
 
 def test_F10_endi_theta_search_vs_reference_trust_constr():
-    """Build-defined theta* (downhill walk on the 64-point grid from theta = 0 + golden section) vs the reference's SciPy
-    trust-constr from theta = 0: the same minimiser on > 90 % of the fixture states (where trust-constr stopped short of
-    its basin's minimum, or left it, they differ), the same action there, and Fc not above the reference's on >= 95 %."""
+    """Build-defined theta* (round 6: compass search from theta = 0) vs the reference's SciPy trust-constr from theta = 0: the
+    same minimiser on 94.8 % of the fixture states (where trust-constr stopped short of its basin's minimum, or jumped a
+    barrier, they differ), the same action on 96.9 % of ALL states, and Fc never above the reference's (rounds 2-5, grid walk
+    + golden section: 92.7 % / 94.8 % / 96.9 %)."""
     meta, z = load_golden("F10_nominal_3wrobot")
     x = z["state"]
     xNI, eta = NO.cart2nh(x)
@@ -62,12 +63,12 @@ def test_F10_endi_theta_search_vs_reference_trust_constr():
     assert np.all((th >= -np.pi) & (th <= np.pi))
     with np.errstate(all="ignore"):
         F_ours, F_ref = NO.Fc(xNI, eta, th), z["Fc_star"]
-    assert np.mean(F_ours <= F_ref * (1 + 1e-9) + 1e-12) >= 0.95
+    assert np.mean(F_ours <= F_ref * (1 + 1e-9) + 1e-12) >= 0.99
     d = np.abs(np.angle(np.exp(1j * (th - z["theta_star"]))))
     same = d < 1e-3
-    assert same.mean() > 0.9, same.mean()
+    assert same.mean() > 0.94, same.mean()
     u = NO.nominal_action_endi(x, meta["ctrl_gain"], meta["m"], meta["I"], meta["bnds"])
     close = np.all(np.abs(u - z["action"]) <= 2e-2 * (np.abs(z["action"]) + 1), axis=1)
     assert close[same].mean() > 0.95, close[same].mean()
-    assert close.mean() > 0.9, close.mean()  # over ALL states, not only where the minimisers agree
+    assert close.mean() > 0.96, close.mean()  # over ALL states, not only where the minimisers agree
     print("same minimiser:", same.mean(), " strictly better Fc:", np.mean(F_ours < F_ref * (1 - 1e-6)))
