@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The reference's headless preset loop (presets/main_3wrobot.py:419-446, the loop body verbatim: sim_step, get_sim_step_data,
+"""The reference's headless preset loop (presets/main_3wrobot.py:419-446: the same calls in the same order - sim_step, get_sim_step_data,
 ctrl_selector, receive_action, receive_sys_state, upd_accum_obj, the unpacking of state_full, stage_obj, accum_obj) through the drop-in
 classes at B = 1 - the 3-wheel robot, MPC, Nactor = 5, simulation steps of dt / 2 (what the reference's solver takes: max_step = dt / 2),
 opt_iters = 30: simulation steps per second, with and without the fused loop step, and where the host time goes (cProfile, by own
@@ -12,27 +12,25 @@ from tests.test_hip_ref_traces import make_loop_objects
 
 
 def loop(t1, fuse=True):
-    my_sys, my_ctrl_benchm, my_simulator = make_loop_objects("3wrobot", "MPC", 5, t1)
-    my_simulator.fuse = fuse
-    action_manual, my_ctrl_nominal, ctrl_mode = np.zeros(2), None, "MPC"
+    """The calls of the reference's loop body, in its order (sim_step -> get_sim_step_data -> ctrl_selector -> receive_action ->
+    receive_sys_state -> upd_accum_obj -> the state components -> stage_obj -> accum_obj), written out here - not the reference's text."""
+    plant, ctrl, sim = make_loop_objects("3wrobot", "MPC", 5, t1)
+    sim.fuse = fuse
+    held = np.zeros(2)
     n = 0
     while True:
-        my_simulator.sim_step()
-        t, state, observation, state_full = my_simulator.get_sim_step_data()
-        action = controllers.ctrl_selector(t, observation, action_manual, my_ctrl_nominal, my_ctrl_benchm, ctrl_mode)
-        my_sys.receive_action(action)
-        my_ctrl_benchm.receive_sys_state(my_sys._state)
-        my_ctrl_benchm.upd_accum_obj(observation, action)
-        xCoord = state_full[0]
-        yCoord = state_full[1]
-        alpha = state_full[2]
-        v = state_full[3]
-        omega = state_full[4]
-        stage_obj = my_ctrl_benchm.stage_obj(observation, action)
-        accum_obj = my_ctrl_benchm.accum_obj_val
+        sim.sim_step()
+        t, _, obs, full = sim.get_sim_step_data()
+        u = controllers.ctrl_selector(t, obs, held, None, ctrl, "MPC")
+        plant.receive_action(u)
+        ctrl.receive_sys_state(plant._state)
+        ctrl.upd_accum_obj(obs, u)
+        px, py, heading, speed, turn = (full[i] for i in range(5))
+        rho = ctrl.stage_obj(obs, u)
+        total = ctrl.accum_obj_val
         n += 1
         if t >= t1 - 1e-12:
-            return n, (xCoord, yCoord, alpha, v, omega, stage_obj, accum_obj)
+            return n, (px, py, heading, speed, turn, rho, total)
 
 
 loop(0.1)
