@@ -996,7 +996,13 @@ __device__ __forceinline__ void actor_wave(const ActorArgs<real>& A, const KPara
 // (the instances without the generic cost structures ask for 4 waves per SIMD, i.e. <= 128 VGPRs: the generated-grid
 // instance sits at 125-129 registers depending on details, and the step from 4 to 3 resident waves costs it 15 %)
 template <typename Sys, typename real, bool GENERIC, bool TGT, bool STREAM, bool PKONLY = false, bool DIRECT = false>
-__global__ __launch_bounds__(256, (GENERIC || sizeof(real) > 4) ? 1 : 4) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
+// Resident blocks per CU asked of the compiler for the float64 generated-grid instance.  Round 6, interleaved A/B on one device
+// (profiles/r06_ab_gen64_occupancy.txt): unconstrained the 3-wheel robot's instance takes 206 VGPRs = 2 waves per SIMD, 157.4 us per
+// C2-shape tick; 3 (168 VGPRs, 8 spilled) 139.2 us; 4 (128 VGPRs, 48 spilled) 196.7 us.  NI and the tank are below 168 anyway.
+#ifndef RCG_GEN64_OCC
+#define RCG_GEN64_OCC 3
+#endif
+__global__ __launch_bounds__(256, GENERIC ? 1 : (sizeof(real) > 4 ? (STREAM ? 1 : RCG_GEN64_OCC) : 4)) void k_actor(const ActorArgs<real> A, const KParams<real> P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // readfirstlane makes the wave index provably wave-uniform: tile bases, row counts and the env's
   // addresses then live in SGPRs and the staging control flow is scalar (no exec-mask branches)

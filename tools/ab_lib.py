@@ -57,7 +57,7 @@ def child(lib, workload):
             B, Nh = int(os.environ.get("AB_B", B)), int(os.environ.get("AB_N", Nh))
             if name == "2tank" and "Ncritic" not in kw and kw:
                 kw["Ncritic"] = 4
-        if workload == "stream" and os.environ.get("AB_DTYPE"):  # AB_DTYPE=f64: the reference's width
+        if workload in ("stream", "gen") and os.environ.get("AB_DTYPE"):  # AB_DTYPE=f64: the reference's width
             kw["dtype"] = os.environ["AB_DTYPE"]
         eng = Engine(preset_engine_config(name, B, Nactor=Nh, **kw))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
