@@ -796,7 +796,14 @@ int op_search(rcg_handle* h, int32_t K, int32_t rounds, int32_t round0, const vo
     const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
     const bool tgt = (c.flags & RCG_FLAG_HAS_TARGET) != 0;
     // register rows (compile-time horizon): MPC with a diagonal stage cost, the preset's target setting, Nactor 3 / 5 / 10
-    const int nc = (!generic && tgt == Sys::TGT && (c.n_actor == 3 || c.n_actor == 5 || c.n_actor == 10)) ? c.n_actor : 0;
+// longest horizon whose FLOAT64 search keeps its rows in registers.  Round 6, interleaved A/B on one device
+// (profiles/r06_ab_search_f64_rows.txt): at Nactor = 10 the register-row instance needs 256 VGPRs + 19 AGPRs (one wave per SIMD) and
+// takes 690 us per C2-shape round of 256, the LDS-row instance (124 VGPRs, four waves) 525 us; at Nactor = 5 registers win, 257 against 268.
+#ifndef RCG_SEARCH_F64_REG_ROWS
+#define RCG_SEARCH_F64_REG_ROWS 5
+#endif
+    int nc = (!generic && tgt == Sys::TGT && (c.n_actor == 3 || c.n_actor == 5 || c.n_actor == 10)) ? c.n_actor : 0;
+    if (sizeof(real) == 8 && nc > RCG_SEARCH_F64_REG_ROWS) nc = 0;  // (float64 rows of 20 reals: 256 VGPRs + AGPRs, one wave per SIMD)
     int wpb = 4;  // waves (= envs) per workgroup
     const size_t lds_wave = (size_t)search_lds_reals(R, nc > 0) * sizeof(real);
     while (wpb > 1 && lds_wave * wpb > (size_t)64 * 1024) wpb >>= 1;

@@ -51,13 +51,13 @@ def child(lib, workload):
         if os.environ.get("AB_MODE"):  # e.g. AB_MODE=RQL AB_K=36 ... stream
             kw = dict(mode=os.environ["AB_MODE"], critic_struct=os.environ.get("AB_CS", "quad-nomix"), buffer_size=10)
         name = os.environ.get("AB_SYS", "3wrobot") if workload in ("stream", "gen") else "3wrobot"  # AB_SYS / AB_B / AB_N: stream, gen
-        if workload == "gen":
+        if workload in ("gen", "search", "opt0", "opt4"):
             Nh = int(os.environ.get("AB_N", Nh))
         if workload == "stream":
             B, Nh = int(os.environ.get("AB_B", B)), int(os.environ.get("AB_N", Nh))
             if name == "2tank" and "Ncritic" not in kw and kw:
                 kw["Ncritic"] = 4
-        if workload in ("stream", "gen") and os.environ.get("AB_DTYPE"):  # AB_DTYPE=f64: the reference's width
+        if workload in ("stream", "gen", "search", "opt0", "opt4") and os.environ.get("AB_DTYPE"):  # AB_DTYPE=f64: the reference's width
             kw["dtype"] = os.environ["AB_DTYPE"]
         eng = Engine(preset_engine_config(name, B, Nactor=Nh, **kw))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
