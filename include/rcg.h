@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCG_VERSION 118 /* 117 + rcg_loop_step (round 6) */
+#define RCG_VERSION 119 /* 117 + rcg_loop_step (_begin / _end), rcg_set_optimizer_tol (round 6) */
 
 /* ---- limits ------------------------------------------------------------------------------- */
 #define RCG_MAX_DS 5    /* largest dim_state of the built-in systems            */
@@ -265,12 +265,26 @@ int rcg_sim_step_h(rcg_handle* h, int32_t n_substeps, double step);
  * RCG_LOOP_DECIDE), W_CRITIC.  ACCUM / STEP_IDX are not touched (upd_accum_obj is the caller's multiply-add; the caller decides
  * from its clock which steps are samples).  Every number equals what the separate calls (rcg_set_field, rcg_sim_step_h,
  * rcg_critic_update, rcg_actor_optimize, rcg_stage_obj) leave, bit for bit.  Handles whose rows fit the 16-KB pinned buffer
- * (3-wheel robot, MPC: up to 200 envs); no disturbance model. */
+ * (3-wheel robot, MPC: up to 200 envs); no disturbance model.  Launches: ONE for a step that is no sample (k_loop), ONE for a
+ * sample with the plain MPC decision (diagonal stage cost, no curvature pairs - every MPC preset: k_actor_opt does the
+ * iteration's head and tail itself, rcg_last_launch variant bit 3), three otherwise. */
 #define RCG_LOOP_DECIDE 1
 #define RCG_LOOP_PUSH 2
 #define RCG_LOOP_FIT 4
 int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t n_substeps, int32_t flags, int32_t iters,
                   double* out);
+/* The same in two halves, so that the host can do its own bookkeeping of iteration i while the device already runs iteration
+ * i + 1: rcg_loop_step_begin enqueues the iteration on the handle's stream and returns (action_in is copied before it returns);
+ * rcg_loop_step_end waits for it - polling the sequence numbers the last kernel writes into the handle's pinned buffer, no stream
+ * wait - and hands over the rows (out == NULL: the iteration is dropped - STATE, ACTION, the critic buffers and weights keep its
+ * effects and the caller is expected to set them anew, ACTION_SQN stays the last collected decision's; a collected deciding step
+ * makes its sequence ACTION_SQN by swapping two buffers, so a pointer from rcg_field_ptr(ACTION_SQN) is stale after it).  One iteration
+ * may be pending per handle (a second begin: RCG_ERR_BAD_ARG); every other entry point is ordered behind a pending iteration on
+ * the stream as usual.  rcg_loop_step is begin + end.  The drop-in classes use the pair to start the next simulation step at the
+ * end of compute_action - the action it returns is the one the system will hold - while the loop body still logs the current
+ * one (rcognita_amd/controllers.py `_speculate`). */
+int rcg_loop_step_begin(rcg_handle* h, const double* action_in, double step_h, int32_t n_substeps, int32_t flags, int32_t iters);
+int rcg_loop_step_end(rcg_handle* h, double* out);
 /* Replacement of CtrlOptPred._actor_optimizer (controllers.py:1330-1427): evaluate _actor_cost for
  * K candidates per env and take the argmin (lower J wins, ties -> lower index, NaN = +inf).
  * cand [B][K][N][du], or NULL for the generated level grid (K levels for du = 1, g*g for du = 2).
@@ -355,6 +369,12 @@ int rcg_actor_optimize(rcg_handle* h, int32_t iters, const void* obs, const void
  * optimum on every MPC decision of the reference's loops; the pairs cost 2.4 x the time).  Each pair costs 2 * N * du reals
  * of LDS per env. */
 int rcg_set_optimizer(rcg_handle* h, int32_t memory);
+/* Stopping tolerance of rcg_actor_optimize, the counterpart of the accuracy the reference hands SLSQP (`tol=1e-7`,
+ * controllers.py:1396 -> SciPy's `ftol`: SLSQP ends once an iteration changes J by less than that): an env is done after an
+ * ACCEPTED step that lowered J by no more than `ftol` (absolute, in the units of J; the step is kept).  0 (the default of a
+ * handle): no such test - an env runs until `iters` steps are done or a steepest-descent line search finds nothing better.  The
+ * drop-in CtrlOptPred sets the reference's 1e-7. */
+int rcg_set_optimizer_tol(rcg_handle* h, double ftol);
 /* rcg_control_tick with rcg_actor_optimize as the decision: sim_step -> [RQL/SQL: buffer push + critic fit] -> optimise ->
  * ACTION, ACTION_SQN, BEST_J -> ACCUM, STEP_IDX.  warm_start != 0: start from the previous tick's optimum shifted by one
  * step (the reference always restarts from action_sqn_init: warm_start = 0). */
@@ -461,7 +481,8 @@ typedef enum rcg_kernel_id {
 /* variant: k_actor_dma, k_actor_dma_packed: 0 MPC gamma = 1, 1 MPC discounted, 2 + critic_struct RQL, 6 + critic_struct SQL (k_actor_dma_packed: + 16 when the env step of the tick ran inside the launch);
  * k_actor_dma, round 6: 10 / 11 MPC with a biquadratic (diagonal) / full-matrix stage cost, 12 + critic_struct RQL with such a cost (SQL: its ordinary instances); k_actor / k_ticks: bit 0 generic
  * stage cost / critic modes, bit 1 observation target, bit 2 streamed candidates, bit 3 the hand-packed generated-grid instance, bit 4 (k_actor) rows beyond RCG_MAX_ROW walked straight from HBM; k_critic_fit: critic_struct + 16 * (rows
- * the instance is compiled for; 0: any) + 256 * do_sim + 512 * do_fit + 1024 * (the four-lanes-per-env form, structures with >= 9 weights) + 2048 * (the any-number-of-rows form, Ncritic - 1 > 8); others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
+ * the instance is compiled for; 0: any) + 256 * do_sim + 512 * do_fit + 1024 * (the four-lanes-per-env form, structures with >= 9 weights) + 2048 * (the any-number-of-rows form, Ncritic - 1 > 8); k_actor_opt: bit 0 generic
+ * stage cost / critic modes, bit 1 observation target, bit 2 curvature pairs, bit 3 the launch also did rcg_loop_step's head and tail; others 0.  envs_per_wave: envs a wave owns (k_actor_dma, k_actor_dma_packed) or
  * packs into one 64-row tile (k_actor, k_ticks); 64 for lane = env kernels.  Bit 12 (4096) of variant: the launch served one half
  * of a split tick (rcg_set_tick_parts).  Each out pointer may be NULL. */
 int rcg_last_launch(const rcg_handle* h, int32_t kind, int32_t* kernel_id, int32_t* variant, int32_t* envs_per_wave);

@@ -624,7 +624,7 @@ def _quad_sum(R, term, free):
     return (p[0] + p[1]) + (p[2] + p[3])
 
 
-def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY):
+def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY, ftol=0.0):
     """Projected limited-memory quasi-Newton descent with a 16-way line search, every mode and cost structure.
 
     Per iteration, with g = grad J(u) (adjoint sweep) and the box [lo, hi] of width w:
@@ -637,7 +637,9 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
       * 16 trial points clip(u - alpha_l d): quasi-Newton alpha_l = 2^(2 - l) (the unit step is l = 2), steepest
         descent alpha_l = 4^(1 - l) / max_i |d_i / w_i| (four box widths down to 2^-28);  lower J wins, then lower l;
       * the best trial replaces u if it lowers J; otherwise a quasi-Newton iteration drops its memory and the next one
-        retries with steepest descent, a steepest-descent iteration ends the search.
+        retries with steepest descent, a steepest-descent iteration ends the search;
+      * ``ftol`` (rcg_set_optimizer_tol; the reference hands SLSQP ``tol=1e-7``, controllers.py:1396): an accepted step that
+        lowered J by no more than ``ftol`` is the last one (0: no such test).
     Deterministic, no finite differences.  Every sum over coordinates is associated as k_actor_opt (rcg_actor_opt.hpp) forms
     it with four lanes per env (_quad_sum).
     Returns ``(u [N, du], J, accepted steps)``.  Round 3's optimiser was the ``memory = 0`` case (with the steepest-descent
@@ -737,12 +739,15 @@ def actor_optimize_single(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=No
             S[head] = u_new.reshape(R) - uf
             Y[head] = g
             pending = True
+        gain = J - float(bj[0])
         u, J = u_new, float(bj[0])
         used += 1
+        if gain <= ftol:
+            break
     return u, J, used
 
 
-def actor_optimize(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY):
+def actor_optimize(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_critic=None, memory=OPT_MEMORY, ftol=0.0):
     """Batched wrapper: ``obs/state_sys [B, ds]``, ``u_init [B, N, du]`` or ``[N, du]`` ->
     ``(u [B, N, du], J [B], iterations [B] int32)``."""
     obs = np.asarray(obs, dtype=np.float64).reshape(-1, cfg.ds)
@@ -754,7 +759,7 @@ def actor_optimize(cfg: OracleCfg, obs, state_sys, u_init, iters, pars=None, w_c
     for b in range(B):
         p = None if pars is None else np.asarray(pars)[b]
         wb = None if w_critic is None else np.asarray(w_critic, dtype=np.float64).reshape(-1, cfg.dc)[b if np.ndim(w_critic) == 2 else 0]
-        u, J, n = actor_optimize_single(cfg, obs[b], xs[b], u0[b], iters, pars=p, w_critic=wb, memory=memory)
+        u, J, n = actor_optimize_single(cfg, obs[b], xs[b], u0[b], iters, pars=p, w_critic=wb, memory=memory, ftol=ftol)
         U.append(u)
         Js.append(J)
         its.append(n)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librcg.so")
 
 # ---- enums (include/rcg.h) -------------------------------------------------------------------
-RCG_VERSION = 118
+RCG_VERSION = 119
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_NONFINITE = 0, -1, -2, -3, -4, -5
 SYS_3WROBOT, SYS_3WROBOT_NI, SYS_2TANK = 0, 1, 2
 MODE_MPC, MODE_RQL, MODE_SQL = 0, 1, 2
@@ -48,7 +48,7 @@ SYMBOLS = [
     "rcg_actor_cost", "rcg_critic_cost", "rcg_sim_step", "rcg_sim_step_h", "rcg_actor_argmin", "rcg_control_tick",
     "rcg_critic_update", "rcg_control_ticks", "rcg_control_tick_n", "rcg_actor_optimize", "rcg_control_tick_opt", "rcg_nominal_action",
     "rcg_control_tick_nominal", "rcg_rhs_full", "rcg_disturb_noise", "rcg_episode_reset", "rcg_episode_stats", "rcg_tick_count", "rcg_set_tick_count", "rcg_profile", "rcg_profile_read",
-    "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream", "rcg_nominal_theta", "rcg_set_optimizer", "rcg_set_tick_parts", "rcg_join", "rcg_loop_step",
+    "rcg_profile_samples", "rcg_last_launch", "rcg_kernel_name", "rcg_wait_stream", "rcg_nominal_theta", "rcg_set_optimizer", "rcg_set_optimizer_tol", "rcg_set_tick_parts", "rcg_join", "rcg_loop_step", "rcg_loop_step_begin", "rcg_loop_step_end",
     "rcg_actor_search", "rcg_control_tick_search", "rcg_candidates_sample", "rcg_release_stream",
 ]
 KERNEL_ACTOR, KERNEL_SIM, KERNEL_CRITIC = 0, 1, 2
@@ -153,6 +153,9 @@ def lib():
         "rcg_control_tick_opt": (C.c_int, [vp, i32, i32]),
         "rcg_set_optimizer": (C.c_int, [vp, i32]),
         "rcg_set_tick_parts": (C.c_int, [vp, i32]),
+        "rcg_set_optimizer_tol": (C.c_int, [vp, C.c_double]),
+        "rcg_loop_step_begin": (C.c_int, [vp, vp, C.c_double, i32, i32, i32]),
+        "rcg_loop_step_end": (C.c_int, [vp, vp]),
         "rcg_loop_step": (C.c_int, [vp, vp, C.c_double, i32, i32, i32, vp]),  # (host double pointers passed as addresses)
         "rcg_join": (C.c_int, [vp]),
         "rcg_actor_search": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

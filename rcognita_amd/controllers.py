@@ -13,7 +13,9 @@ What differs from the reference, by construction (SURVEY.md hard part 1):
   made on the device, for every mode (MPC / RQL / SQL), stage-cost and critic structure:
   ``actor_opt='auto'|'gradient'`` (default) - the on-device optimiser ``rcg_actor_optimize``: ``opt_iters`` iterations of
   adjoint gradient + limited-memory quasi-Newton direction + 16-way projected line search from the reference's start
-  sequence; on the reference's own decisions (fixtures F8 / F8c) it ends within 0.5 % of SLSQP's cost;
+  sequence; on the reference's own decisions (fixtures F8 / F8c) it ends within 0.5 % of SLSQP's cost; an env stops early once
+  an accepted step lowers J by no more than ``opt_ftol`` = 1e-7, the accuracy the reference hands SLSQP (``tol=1e-7``,
+  controllers.py:1396; ``opt_ftol=0``: always ``opt_iters`` steps unless a line search finds nothing better);
   ``actor_opt='sampling'`` - the device-side candidate search ``rcg_actor_search``: ``rounds`` rounds of ``n_candidates``
   sequences generated (Philox), evaluated and refined around each round's winner in one launch; no candidate is ever
   built on the host.  ``candidates=`` evaluates an explicit set instead (``rcg_actor_argmin``).
@@ -50,7 +52,7 @@ class CtrlOptPred:
                  stage_obj_struct="quadratic", stage_obj_pars=[], observation_target=[],
                  # ---- build-specific, keyword-only in spirit ----
                  candidates=None, actor_opt="auto", opt_iters=30, n_candidates=256, rounds=6, seed=0, dtype="f64",
-                 device=0, clock_tol=1e-9):
+                 device=0, clock_tol=1e-9, opt_ftol=1e-7):
         if is_est_model:
             raise NotImplementedError("is_est_model=1 needs the absent `sippy` package and is out of scope "
                                       "(SURVEY.md 2, component 3)")
@@ -108,7 +110,8 @@ class CtrlOptPred:
         R1 = np.asarray(stage_obj_pars[0], dtype=float)
         R2 = np.asarray(stage_obj_pars[1], dtype=float) if len(stage_obj_pars) > 1 else None
         tgt = None if len(observation_target) == 0 else np.asarray(observation_target, dtype=float)
-        self._eng = Engine(EngineConfig(
+        self._spec = None  # the next loop iteration, started ahead (see _speculate)
+        self._eng_raw = Engine(EngineConfig(
             sys_id=spec["sys_id"], batch=self.B, dtype=dtype, device=device, Nactor=Nactor, mode=mode,
             stage_obj_struct=stage_obj_struct, critic_struct=critic_struct, Ncritic=Ncritic, buffer_size=buffer_size,
             dt_sim=sampling_time, sampling_time=sampling_time, pred_step_size=pred_step_size, gamma=gamma,
@@ -125,6 +128,8 @@ class CtrlOptPred:
         self.candidates = None if candidates is None else np.asarray(candidates, dtype=float)
         self.n_candidates, self.rounds = int(n_candidates), int(rounds)
         self.opt_iters = int(opt_iters)
+        self.opt_ftol = float(opt_ftol)
+        self._eng.set_optimizer(-1, ftol=self.opt_ftol)
         if actor_opt not in ("auto", "gradient", "sampling"):
             raise ValueError(f"actor_opt must be 'auto', 'gradient' or 'sampling', got {actor_opt!r}")
         self._use_gradient = actor_opt in ("auto", "gradient")
@@ -139,7 +144,20 @@ class CtrlOptPred:
         self._fused_dirty = True  # the handle's STATE / buffers / weights must be uploaded before the next fused step
         self.fused_steps = 0      # statistics: loop iterations served by one native call ...
         self.fused_decisions = 0  # ... and decisions of compute_action taken from them
+        self.speculate = True     # build-specific: start the next simulation step at the end of compute_action (see _speculate)
+        self.spec_hits = self.spec_drops = 0  # ... iterations started ahead that Simulator.sim_step then asked for / did not
+        self._spec_ready = False  # the last simulation step ran on this controller's handle: its STATE is the simulator's
+        self._spec_dropped = False
+        self._last_sim = None
         sys_obj._register_controller(self)
+
+    @property
+    def _eng(self):
+        """The controller's handle.  Whoever touches it outside the fused loop first gets rid of an iteration that was started
+        ahead: it is waited for and dropped, and the handle is marked for a fresh upload of the host objects' state."""
+        if self._spec is not None:
+            self._spec_drop()
+        return self._eng_raw
 
     # the optimal sequence of the last decision; after a fused step it stays on the device until somebody asks
     @property
@@ -180,10 +198,48 @@ class CtrlOptPred:
     def _fused_sync(self, state):
         """Bring the handle to the host objects' state: the simulator's state, the critic buffers and weights."""
         self._eng.set_state(np.asarray(state, dtype=float).reshape(self.B, -1), also_init=False)
+        if self._spec_dropped:  # a dropped step may have frozen an env on the handle (non-finite state) that the host never saw
+            self._eng.set_field(N.FIELD_STATUS, np.zeros(self.B, dtype=np.uint32))
+            self._spec_dropped = False
         if self.mode != "MPC":
             self._sync_critic_state()
             self._eng.set_field(N.FIELD_W_CRITIC, self._b(self.w_critic, self.dim_critic))
         self._fused_dirty = False
+
+    def _spec_drop(self):
+        spec, self._spec = self._spec, None
+        if spec is not None:
+            self._eng_raw.loop_step_end(drop=True)  # STATE / ACTION / buffers / weights on the handle are the dropped step's:
+            self._fused_dirty = True                #   the next fused step uploads the host objects' anew
+            self._spec_dropped = True
+            self.spec_drops += 1
+
+    def _speculate(self, action):
+        """Called at the end of compute_action.  In the reference's loop (presets/main_3wrobot.py:419-446) the action compute_action
+        returns is the one the system holds over the NEXT simulation step (`my_sys.receive_action(action)` follows at once), while
+        the loop body still has its bookkeeping of the current step to do (receive_action, receive_sys_state, upd_accum_obj, the
+        logger): the next iteration - the step, and what compute_action / stage_obj will ask for at its end - is enqueued now
+        (rcg_loop_step_begin) and collected by Simulator.sim_step (rcg_loop_step_end) if, by then, it is still the step that is asked
+        for: same simulator, same held action, same time and step length, same clocks.  Anything else - another action handed to
+        the system, a reset, any other use of the controller's handle - drops it (the handle is then uploaded anew): a run is the
+        same numbers with and without."""
+        self._spec_ready = False
+        sim = self._last_sim() if self._last_sim is not None else None
+        if (sim is None or not self.speculate or not sim.fuse or self._spec is not None or self._fused_dirty or self._fz is not None
+                or not sim._eng_stale):
+            return
+        act = np.asarray(action, dtype=float)
+        if act.size != self.B * self.dim_input:  # (one action for every env: the ordinary path broadcasts it)
+            return
+        act = act.reshape(self.B, self.dim_input)
+        t_new = sim.t0 + (sim.step_idx + 1) * sim.dt
+        tick, fit = self._tick_flags(t_new)
+        push = tick and self.mode != "MPC"
+        if push and not self._same(self._b(self.action_curr, self.dim_input), act):
+            return
+        step = float(sim.dt)
+        self._eng_raw.loop_step_begin(act, step, sim.n_substeps, decide=tick, push=push, fit=fit, iters=self.opt_iters)
+        self._spec = (sim, act.tobytes(), t_new, step, tick, fit, push)
 
     def _fused_step(self, sim, act, t_new, step):
         """Called by Simulator.sim_step: hold `act` over one step, and compute ahead what the loop body will ask for at
@@ -195,17 +251,35 @@ class CtrlOptPred:
         self._fz = None
         tick, fit = self._tick_flags(t_new)
         push = tick and self.mode != "MPC"
-        if push and not self._same(self._b(self.action_curr, self.dim_input), act):
-            self._fused_dirty = True
-            return None
+        res = None
+        spec = self._spec
+        if spec is not None:  # this iteration may already be running (_speculate): take it if it is exactly the one asked for
+            if (spec[0] is sim and spec[2] == t_new and spec[3] == step and spec[4:] == (tick, fit, push) and not self._fused_dirty
+                    and spec[1] == act.tobytes()
+                    and not (push and not self._same(self._b(self.action_curr, self.dim_input), act))):
+                self._spec = None
+                res = self._eng_raw.loop_step_end()
+                self.spec_hits += 1
+            else:
+                self._spec_drop()
         prev = np.array(sim.state_full, dtype=float).reshape(self.B, -1)[:, :self.dim_output]  # (a copy: the simulator moves on)
-        if self._fused_dirty:
-            self._fused_sync(prev)
-        st, a, stage, bj, w = self._eng.loop_step(act, step, sim.n_substeps, decide=tick, push=push, fit=fit, iters=self.opt_iters)
+        if res is None:
+            if push and not self._same(self._b(self.action_curr, self.dim_input), act):
+                self._fused_dirty = True
+                return None
+            if self._fused_dirty:
+                self._fused_sync(prev)
+            res = self._eng_raw.loop_step(act, step, sim.n_substeps, decide=tick, push=push, fit=fit, iters=self.opt_iters)
+        st, a, stage, bj, w = res
         a_new = a if tick else np.array(act, dtype=float)
         self._fz = dict(t=t_new, obs=st, xs=prev, tick=tick, fit=fit, action=a_new, J=bj, w=w)
         self._stage_last = (st, a_new, stage)
         self.fused_steps += 1
+        if self._last_sim is None or self._last_sim() is not sim:
+            import weakref
+
+            self._last_sim = weakref.ref(sim)
+        self._spec_ready = True
         return st
 
     # ------------------------------------------------------------------ helpers
@@ -227,6 +301,8 @@ class CtrlOptPred:
     # ------------------------------------------------------------------ reference interface
     def reset(self, t0):
         """rcognita/controllers.py:1046-1054: only the clock and the current action are reset."""
+        if self._spec is not None:
+            self._spec_drop()
         self.ctrl_clock = t0
         self.action_curr = self._unb(np.broadcast_to(self.action_min / 10, (self.B, self.dim_input)).copy())
 
@@ -328,7 +404,14 @@ class CtrlOptPred:
         return act if self._batched else act[0]
 
     def compute_action(self, t, observation):
-        """Main method (rcognita/controllers.py:1429-1493)."""
+        """Main method (rcognita/controllers.py:1429-1493).  (Build-specific: when the simulation step before this call ran as a
+        fused loop step, the NEXT one is started here with the returned action held - `_speculate`.)"""
+        action = self._compute_action(t, observation)
+        if self._spec_ready:
+            self._speculate(action)
+        return action
+
+    def _compute_action(self, t, observation):
         time_in_sample = t - self.ctrl_clock
         fz, self._fz = self._fz, None
         if time_in_sample >= self.sampling_time * (1 - self.clock_tol):  # new sample

@@ -28,6 +28,7 @@
 // iterations (tests/test_oracle_optimizer.py, tests/test_hip_optimizer.py).
 #pragma once
 #include "rcg_kernels.hpp"
+#include "rcg_loop.hpp"
 
 namespace rcg {
 
@@ -115,6 +116,8 @@ struct OptArgs {
   int shift;              // warm start: u_init is last tick's optimum, shift it by one step (last entry repeated)
   int memory;             // curvature pairs kept per env, 0 .. OPT_MAXM (0: projected steepest descent)
   int dcw;                // critic weights staged in LDS per env (dc for RQL / SQL, else 0)
+  real ftol;              // an env is done after an accepted step that lowered J by <= ftol (rcg_set_optimizer_tol; 0: never)
+  LoopArgs<real> loop;    // LOOP instances only (rcg_loop_step): the loop iteration's head and tail around the decision
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -219,7 +222,11 @@ __device__ __forceinline__ void critic_grad_with(const real* chi, const real* y,
 // structures read from KParams (wave-uniform branches)
 // PAIRS = false: the instance without curvature pairs (memory 0: box-scaled steepest descent, the default of MPC with a diagonal
 // stage cost) - the quad phase 1b and its registers are compiled out (121 VGPRs, 4 waves per SIMD; 153 with it)
-template <typename Sys, typename real, bool TGT, bool GENERIC, bool PAIRS>
+// LOOP (rcg_loop_step's sample with the plain MPC decision, one launch instead of three): lane == env first does k_loop's head -
+// System.receive_action + Simulator.sim_step, the fields written as k_loop writes them - and decides from (obs = the new STATE,
+// state_sys = STATE_PREV) held in its registers; after the decision it does k_loop's tail (stage_obj of the new state and the
+// decided action, the row and the sequence number into the pinned host buffer).  Same device functions as the three launches.
+template <typename Sys, typename real, bool TGT, bool GENERIC, bool PAIRS, bool LOOP = false>
 __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const KParams<real> P) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, NP = Sys::NP, NPS = NP > 0 ? NP : 1, G = OPT_G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -248,10 +255,20 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
   const bool mine = lane < ng;       // lane == env view
   const long be = b0 + (mine ? lane : 0);
   real y0e[DS], xse[DS], pve[NPS], w[DU], w2[DU];
+  if constexpr (LOOP) {
+    real ul[DU];
+    if (mine) {
+      loop_head<Sys, real>(A.loop, P, be, ul, y0e, xse);
+    } else {
 #pragma unroll
-  for (int c = 0; c < DS; ++c) {
-    y0e[c] = A.obs[(long)c * B + be];
-    xse[c] = A.state_sys[(long)c * B + be];
+      for (int c = 0; c < DS; ++c) y0e[c] = xse[c] = (real)0;  // an idle lane stands for no env (its values are never used)
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+      y0e[c] = A.obs[(long)c * B + be];
+      xse[c] = A.state_sys[(long)c * B + be];
+    }
   }
 #pragma unroll
   for (int i = 0; i < NP; ++i) pve[i] = A.pars_env ? A.pars_env[(long)i * B + be] : P.pars[i];
@@ -634,6 +651,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
       const int better_me = __shfl((int)better, src, 64);
       if (mine_now && active) {
         if (better_me) {
+          if (Jinc - bj_me <= A.ftol) active = false;  // the step is kept and it was the last one (ftol = 0: never - a kept step has a positive gain)
           Jinc = bj_me;
           ++used;
           pending = M > 0;
@@ -660,6 +678,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
     if (A.n_iter) A.n_iter[be] = used;
     if (A.accum) A.accum[be] = accum_update<Sys, TGT, real>(P, y0e, a, A.accum[be]);
     if (A.step_idx) A.step_idx[be] += 1;
+    if constexpr (LOOP) loop_tail<Sys, real>(A.loop, P, be, a, y0e, (double)Jinc);
   }
 }
 

@@ -239,10 +239,16 @@ int rcg_create(const rcg_cfg* cfg, rcg_handle** out) {
   h->fit_scratch = nullptr;
   h->fit_scratch_bytes = 0;
   h->loop_seq = 0;
+  h->loop_io.on = false;
+  h->loop_pending = false;
+  h->loop_pin = nullptr;
+  h->sqn_alt = nullptr;
+  h->loop_pending_decided = false;
   h->prof_mask = 0;
   h->prof_stride = 1;
   memset(h->prof_seen, 0, sizeof h->prof_seen);
   h->tick_count = 0;
+  h->opt_ftol = 0.0;
   h->opt_memory = -1;  // auto: 4 pairs for the generic instance, none for MPC with a diagonal R1 (rcg_set_optimizer)
   h->cur_a = h->cur_b = nullptr;
   h->scope_due = false;
@@ -372,6 +378,8 @@ int rcg_destroy(rcg_handle* h) {
   }
   if (h->split_fork) (void)hipEventDestroy(h->split_fork);
   if (h->bounce) (void)hipHostFree(h->bounce);
+  if (h->loop_pin) (void)hipHostFree(h->loop_pin);
+  if (h->sqn_alt) (void)hipFree(h->sqn_alt);
   if (h->d_summary) (void)hipFree(h->d_summary);
   if (h->d_const) (void)hipFree(h->d_const);
   if (h->fit_scratch) (void)hipFree(h->fit_scratch);
@@ -857,6 +865,13 @@ int rcg_set_optimizer(rcg_handle* h, int32_t memory) {
   return RCG_OK;
 }
 
+int rcg_set_optimizer_tol(rcg_handle* h, double ftol) {
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (!(ftol >= 0.0) || !(ftol < 1e300)) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_set_optimizer_tol: ftol must be finite and >= 0");
+  h->opt_ftol = ftol;
+  return RCG_OK;
+}
+
 // refusals of the optimiser that depend on the handle's shape, made before a tick mutates anything
 static int check_optimizer(rcg_handle* h, const char* who) {
   if (h->cfg.mode != RCG_MODE_MPC && !h->f[RCG_FIELD_W_CRITIC])
@@ -897,11 +912,14 @@ int rcg_control_tick_opt(rcg_handle* h, int32_t iters, int32_t warm_start) {
 }
 
 // ---- rcg_loop_step: one iteration of the reference's headless loop in ONE call and ONE host wait (rcg.h) --------------------
-int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t n_substeps, int32_t flags, int32_t iters,
-                  double* out) {
+// rcg_loop_step_begin enqueues the iteration and returns; rcg_loop_step_end waits for it and hands over the rows; rcg_loop_step is
+// the two back to back.  The rows travel through a pinned buffer of the handle's own (not the one the small device-to-host reads
+// of the other entry points share): [out rows | action_in | one sequence number per env].
+int rcg_loop_step_begin(rcg_handle* h, const double* action_in, double step_h, int32_t n_substeps, int32_t flags, int32_t iters) {
   DeviceGuard dev_guard(h);
-  if (!h || !out || n_substeps < 1 || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_loop_step: bad argument");
+  if (!h || n_substeps < 1 || iters < 0) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_loop_step: bad argument");
   if (!(step_h > 0.0) || !(step_h < 1e300)) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_loop_step: step must be positive and finite");
+  if (h->loop_pending) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_loop_step_begin: the previous step has not been collected (rcg_loop_step_end)");
   const bool critic = h->cfg.mode != RCG_MODE_MPC;
   const bool decide = flags & RCG_LOOP_DECIDE, push = critic && (flags & RCG_LOOP_PUSH), fit = push && (flags & RCG_LOOP_FIT);
   if (h->cfg.flags & RCG_FLAG_DISTURB) return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_loop_step: no disturbance model on this path");
@@ -915,16 +933,23 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
     const int rc = check_optimizer(h, "rcg_loop_step");
     if (rc) return rc;
   }
-  if (!h->bounce && hipHostMalloc(&h->bounce, kBounceBytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
-    h->bounce = nullptr;
-    return rcg_fail(h, RCG_ERR_HIP, "rcg_loop_step: cannot allocate the pinned buffer");
+  if (!h->loop_pin) {
+    if (hipHostMalloc(&h->loop_pin, kBounceBytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+      h->loop_pin = nullptr;
+      return rcg_fail(h, RCG_ERR_HIP, "rcg_loop_step: cannot allocate the pinned buffer");
+    }
+    memset(h->loop_pin, 0, kBounceBytes);  // (sequence numbers start at 1: no env has reported yet)
   }
-  // pinned buffer: [out rows | action_in | one sequence number per env]
-  double* const p_out = (double*)h->bounce;
+  // the decision's sequence goes to a spare buffer that becomes ACTION_SQN when the step is collected (rcg_loop_step_end swaps the
+  // two pointers): a step that is dropped leaves ACTION_SQN - the last decision anybody took - alone
+  if (decide && !h->sqn_alt) {
+    HIPCHK(h, hipMalloc(&h->sqn_alt, h->fbytes[RCG_FIELD_ACTION_SQN]));
+    HIPCHK(h, hipMemsetAsync(h->sqn_alt, 0, h->fbytes[RCG_FIELD_ACTION_SQN], h->stream));
+  }
+  double* const p_out = (double*)h->loop_pin;
   double* const p_act = p_out + (size_t)B * row;
   double* const p_flag = p_act + (size_t)B * du;
-  memset(p_flag, 0, (size_t)B * sizeof(double));  // (other entry points use the buffer for their reads: only THIS call's kernel may set a flag)
-  const double seq = (double)++h->loop_seq;        // (exact up to 2^53 calls)
+  const double seq = (double)++h->loop_seq;  // (exact up to 2^53 calls; only this handle's loop kernels write the flags)
   if (action_in) memcpy(p_act, action_in, in_bytes);
   const double* const act_dev = action_in ? p_act : nullptr;
   // the kernels take the substep from the by-value parameter block: lend it this call's length
@@ -933,7 +958,18 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
   h->p64.dt_sim = step_h / (double)n_substeps;
   h->p32.dt_sim = (float)h->p64.dt_sim;
   int rc;
-  if (!decide && !push) {
+  // the plain MPC decision (diagonal stage cost, no curvature pairs - every MPC preset): k_actor_opt's LOOP instance does the
+  // iteration's head and tail itself
+  const bool one_launch = decide && !push && h->cfg.mode == RCG_MODE_MPC && h->p64.stage_kind == 0 && opt_memory_of(h) == 0;
+  if (one_launch) {
+    h->loop_io.on = true;
+    h->loop_io.act_in = act_dev;
+    h->loop_io.n_substeps = n_substeps, h->loop_io.dc = dc;
+    h->loop_io.out = p_out, h->loop_io.flag = p_flag, h->loop_io.seq = seq;
+    rc = h->sys->optimize(h, iters, nullptr, h->f[RCG_FIELD_STATE_PREV], nullptr, 0, h->sqn_alt,
+                          h->f[RCG_FIELD_ACTION], h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], false, false);
+    h->loop_io.on = false;
+  } else if (!decide && !push) {
     // not a controller sample: System.receive_action, Simulator.sim_step, CtrlOptPred.stage_obj and the transfer - ONE launch
     rc = h->sys->loop(h, act_dev, n_substeps, 1, 1, 0, dc, p_out, p_flag, seq);
   } else {
@@ -943,7 +979,7 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
     rc = h->sys->loop(h, act_dev, n_substeps, push ? 0 : 1, 0, 0, dc, p_out, p_flag, seq);
     if (rc == RCG_OK && push) rc = h->sys->critic_update(h, n_substeps, 1, fit ? 1 : 0);
     if (rc == RCG_OK && decide)
-      rc = h->sys->optimize(h, iters, nullptr, h->f[RCG_FIELD_STATE_PREV], nullptr, 0, h->f[RCG_FIELD_ACTION_SQN],
+      rc = h->sys->optimize(h, iters, nullptr, h->f[RCG_FIELD_STATE_PREV], nullptr, 0, h->sqn_alt,
                             h->f[RCG_FIELD_ACTION], h->f[RCG_FIELD_BEST_J], (int32_t*)h->f[RCG_FIELD_BEST_IDX], false, false);
     if (rc == RCG_OK) rc = h->sys->loop(h, nullptr, n_substeps, 0, 1, decide ? 1 : 0, dc, p_out, p_flag, seq);
   }
@@ -951,29 +987,52 @@ int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t
   h->p64.dt_sim = d64;
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
+  h->loop_pending = true;
+  h->loop_pending_decided = decide;
+  h->loop_pending_row = row;
+  return RCG_OK;
+}
+
+int rcg_loop_step_end(rcg_handle* h, double* out) {
+  DeviceGuard dev_guard(h);
+  if (!h) return RCG_ERR_BAD_ARG;
+  if (!h->loop_pending) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_loop_step_end: no step is pending (rcg_loop_step_begin)");
+  h->loop_pending = false;
+  const int B = h->cfg.batch, row = h->loop_pending_row;
+  double* const p_out = (double*)h->loop_pin;
+  volatile double* const f = p_out + (size_t)B * row + (size_t)B * h->du;
+  const double seq = (double)h->loop_seq;
   // wait for the glue kernel's sequence numbers in pinned memory instead of for the stream (tools/sync_probe.hip: 6.9 us per launch
   // + wait against 12.4): every env's row is complete once its flag shows this call's number.  Bounded: after ~50 ms of polling
   // (a fault, a hung queue) the stream is waited for the ordinary way and whatever error it carries is returned.
-  {
-    volatile double* const f = p_flag;
-    bool done = false;
-    for (long spin = 0; spin < 20000000L && !done; ++spin) {
-      done = true;
-      for (int b = 0; b < B; ++b)
-        if (f[b] != seq) {
-          done = false;
-          break;
-        }
-      if (!done) __builtin_ia32_pause();
-    }
-    if (!done) {
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      for (int b = 0; b < B; ++b)
-        if (f[b] != seq) return rcg_fail(h, RCG_ERR_HIP, "rcg_loop_step: the glue kernel did not report env %d", b);
-    }
+  bool done = false;
+  for (long spin = 0; spin < 20000000L && !done; ++spin) {
+    done = true;
+    for (int b = 0; b < B; ++b)
+      if (f[b] != seq) {
+        done = false;
+        break;
+      }
+    if (!done) __builtin_ia32_pause();
   }
-  memcpy(out, p_out, out_bytes);
+  if (!done) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < B; ++b)
+      if (f[b] != seq) return rcg_fail(h, RCG_ERR_HIP, "rcg_loop_step: the glue kernel did not report env %d", b);
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the rows are read after the flags, for the compiler as well
+  if (out) {
+    memcpy(out, p_out, (size_t)B * row * sizeof(double));
+    if (h->loop_pending_decided) std::swap(h->f[RCG_FIELD_ACTION_SQN], h->sqn_alt);  // the collected decision is THE decision now
+  }  // (NULL: the step is dropped - STATE, ACTION, the critic buffers and weights keep its effects, ACTION_SQN does not)
   return RCG_OK;
+}
+
+int rcg_loop_step(rcg_handle* h, const double* action_in, double step_h, int32_t n_substeps, int32_t flags, int32_t iters,
+                  double* out) {
+  if (!h || !out) return rcg_fail(h, RCG_ERR_BAD_ARG, "rcg_loop_step: bad argument");
+  const int rc = rcg_loop_step_begin(h, action_in, step_h, n_substeps, flags, iters);
+  return rc ? rc : rcg_loop_step_end(h, out);
 }
 
 static int check_search(rcg_handle* h, const char* who, int32_t K, int32_t rounds) {

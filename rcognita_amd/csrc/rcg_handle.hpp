@@ -27,7 +27,20 @@ struct rcg_handle {
   double* d_summary;
   long tick_count;  // control ticks issued through rcg_control_tick (drives the critic period)
   int opt_memory;   // curvature pairs of k_actor_opt (rcg_set_optimizer); -1: the default of opt_memory_of()
+  double opt_ftol;  // k_actor_opt: an env stops after an accepted step that gained <= opt_ftol (rcg_set_optimizer_tol; 0: never)
   void* d_const;    // constant block in HBM, layout kConst* below
+  // rcg_loop_step -> op_optimize: when `on`, the decision's launch also does the loop iteration's head and tail (k_actor_opt LOOP)
+  struct {
+    bool on;
+    const double* act_in;
+    int n_substeps, dc;
+    double *out, *flag, seq;
+  } loop_io;
+  bool loop_pending;         // rcg_loop_step_begin has enqueued a step that rcg_loop_step_end has not collected
+  int loop_pending_row;      //   doubles per env of its rows
+  bool loop_pending_decided; //   it carries a decision (its sequence sits in sqn_alt until the step is collected)
+  void* sqn_alt;             // spare ACTION_SQN buffer: rcg_loop_step_end swaps it in when a deciding step is collected
+  void* loop_pin;            // rcg_loop_step's own pinned buffer (kBounceBytes, first use)
   uint64_t loop_seq;         // rcg_loop_step: sequence number of the last call (the glue kernel hands it back through pinned memory)
   void* fit_scratch;         // k_critic_fit_gen (Ncritic - 1 > kFitMaxRows): per-env stack / factor, allocated on first use
   size_t fit_scratch_bytes;

@@ -79,31 +79,37 @@ static int op_stage_obj(rcg_handle* h, const void* obs, const void* act, void* o
 }
 
 // rcg_loop_step's glue kernel (rcg_loop.hpp): [set ACTION from the pinned host buffer] -> [sim step] -> [stage cost + pack]
+template <typename real>
+static void fill_loop_args(rcg_handle* h, LoopArgs<real>& A, const double* act_in, int32_t n_substeps, int32_t do_sim,
+                           int32_t do_tail, int32_t decided, int32_t dc, double* out, double* flag, double seq) {
+  memset(&A, 0, sizeof A);
+  A.sim.state = (real*)h->f[RCG_FIELD_STATE];
+  A.sim.state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
+  A.sim.action = (const real*)h->f[RCG_FIELD_ACTION];
+  A.sim.pars_env = (const real*)h->f[RCG_FIELD_PARS];
+  A.sim.accum = (real*)h->f[RCG_FIELD_ACCUM];
+  A.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
+  A.sim.n_sub = n_substeps;
+  A.action = (real*)h->f[RCG_FIELD_ACTION];
+  A.act_in = act_in;
+  A.best_J = (const real*)h->f[RCG_FIELD_BEST_J];
+  A.w = (const real*)h->f[RCG_FIELD_W_CRITIC];
+  A.out = out;
+  A.flag = flag;
+  A.seq = seq;
+  A.do_sim = do_sim;
+  A.do_tail = do_tail;
+  A.decided = decided;
+  A.dc = dc;
+}
+
 template <typename Sys>
 static int op_loop(rcg_handle* h, const double* act_in, int32_t n_substeps, int32_t do_sim, int32_t do_tail, int32_t decided,
                    int32_t dc, double* out, double* flag, double seq) {
   return by_dtype(h, [&](auto r) {
     using real = decltype(r);
     LoopArgs<real> A;
-    memset(&A, 0, sizeof A);
-    A.sim.state = (real*)h->f[RCG_FIELD_STATE];
-    A.sim.state_prev = (real*)h->f[RCG_FIELD_STATE_PREV];
-    A.sim.action = (const real*)h->f[RCG_FIELD_ACTION];
-    A.sim.pars_env = (const real*)h->f[RCG_FIELD_PARS];
-    A.sim.accum = (real*)h->f[RCG_FIELD_ACCUM];
-    A.sim.status = (uint32_t*)h->f[RCG_FIELD_STATUS];
-    A.sim.n_sub = n_substeps;
-    A.action = (real*)h->f[RCG_FIELD_ACTION];
-    A.act_in = act_in;
-    A.best_J = (const real*)h->f[RCG_FIELD_BEST_J];
-    A.w = (const real*)h->f[RCG_FIELD_W_CRITIC];
-    A.out = out;
-    A.flag = flag;
-    A.seq = seq;
-    A.do_sim = do_sim;
-    A.do_tail = do_tail;
-    A.decided = decided;
-    A.dc = dc;
+    fill_loop_args<real>(h, A, act_in, n_substeps, do_sim, do_tail, decided, dc, out, flag, seq);
     hipLaunchKernelGGL((k_loop<Sys, real>), dim3(blocks_for(h->cfg.batch, 64)), dim3(64), 0, h->stream, A, params<real>(h));
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
@@ -701,6 +707,11 @@ int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state
     A.iters = iters;
     A.shift = shift;
     A.memory = opt_memory_of(h);
+    A.ftol = (real)h->opt_ftol;
+    const bool loop = h->loop_io.on;  // rcg_loop_step's one-launch sample: head and tail of the loop iteration in this launch
+    if (loop)
+      fill_loop_args<real>(h, A.loop, h->loop_io.act_in, h->loop_io.n_substeps, 1, 1, 1, h->loop_io.dc, h->loop_io.out,
+                           h->loop_io.flag, h->loop_io.seq);
     const bool generic = !(c.mode == RCG_MODE_MPC && P.stage_kind == 0);
     A.dcw = c.mode != RCG_MODE_MPC ? h->dc : 0;
     // waves per block: the waves of a block do not cooperate, so the block size only decides how many waves of LDS fit a CU's
@@ -738,6 +749,14 @@ int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state
     RCG_LAUNCH(h, fn, grid, block, lds, A, P);                                                                      \
   } while (0)
     const int sel = (generic ? 4 : 0) | (tgt ? 2 : 0) | (pairs ? 1 : 0);
+    if (loop) {  // (rcg_loop_step asks only where opt_plain_instance() holds)
+      if (generic || pairs || obs || state_sys != h->f[RCG_FIELD_STATE_PREV] || u_init || tick)
+        return rcg_fail(h, RCG_ERR_UNSUPPORTED, "rcg_loop_step: the one-launch sample is the plain MPC instance on the handle's own fields");
+      auto fn = tgt ? k_actor_opt<Sys, real, true, false, false, true> : k_actor_opt<Sys, real, false, false, false, true>;
+      if (lds > 64 * 1024)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RCG_LAUNCH(h, fn, grid, block, lds, A, P);
+    } else
     switch (sel) {
       case 0: RCG_OPT_LAUNCH(false, false, false); break;
       case 1: RCG_OPT_LAUNCH(false, false, true); break;
@@ -749,7 +768,7 @@ int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state
       default: RCG_OPT_LAUNCH(true, true, true); break;
     }
 #undef RCG_OPT_LAUNCH
-    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_OPT, (generic ? 1 : 0) | (tgt ? 2 : 0) | (pairs ? 4 : 0), OPT_G);
+    note_launch(h, RCG_KERNEL_ACTOR, RCG_KID_ACTOR_OPT, (generic ? 1 : 0) | (tgt ? 2 : 0) | (pairs ? 4 : 0) | (loop ? 8 : 0), OPT_G);
     HIPCHK(h, hipGetLastError());
     return (int)RCG_OK;
   });

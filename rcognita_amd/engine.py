@@ -254,6 +254,7 @@ class Engine:
             raise N.NativeError(rc, N.last_error(None))
         self._h = h
         self._loop_fn = L.rcg_loop_step
+        self._loop_begin_fn, self._loop_end_fn = L.rcg_loop_step_begin, L.rcg_loop_step_end
 
     # ------------------------------------------------------------------ life cycle
     def close(self):
@@ -612,6 +613,36 @@ class Engine:
         return (out[:, :ds], out[:, ds:ds + du], out[:, ds + du], out[:, ds + du + 1],
                 out[:, ds + du + 2:] if row > ds + du + 2 else None)
 
+    def loop_step_begin(self, action, step, n_substeps=1, decide=False, push=False, fit=False, iters=10):
+        """Enqueue one loop iteration and return (rcg_loop_step_begin): the device runs it while the host goes on;
+        ``loop_step_end`` collects it.  One iteration may be pending."""
+        pa = None
+        if action is not None:
+            a = np.asarray(action, dtype=np.float64)
+            if a.shape != (self.B, self.du) or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(np.broadcast_to(a, (self.B, self.du)))
+            pa = a.ctypes.data  # (copied into the handle's pinned buffer before the call returns)
+        flags = (N.LOOP_DECIDE if decide else 0) | (N.LOOP_PUSH if push else 0) | (N.LOOP_FIT if fit else 0)
+        rc = self._loop_begin_fn(self._h, pa, step, n_substeps, flags, iters)
+        if rc:
+            N.check(rc, self._h)
+
+    def loop_step_end(self, drop=False):
+        """Wait for the pending iteration (rcg_loop_step_end) and return its rows as ``loop_step`` does; ``drop``: wait only."""
+        if drop:
+            rc = self._loop_end_fn(self._h, None)
+            if rc:
+                N.check(rc, self._h)
+            return None
+        ds, du = self.ds, self.du
+        row = ds + du + 2 + (self.dc if self.cfg.mode != "MPC" else 0)
+        out = np.empty((self.B, row), dtype=np.float64)  # (fresh per call: the caller keeps views of it)
+        rc = self._loop_end_fn(self._h, out.ctypes.data)
+        if rc:
+            N.check(rc, self._h)
+        return (out[:, :ds], out[:, ds:ds + du], out[:, ds + du], out[:, ds + du + 1],
+                out[:, ds + du + 2:] if row > ds + du + 2 else None)
+
     def actor_argmin(self, cand=None, K=None, obs=None, state_sys=None):
         """Returns ``(action [B, du], best_J [B], best_idx [B] int32)``."""
         keep = []
@@ -704,10 +735,13 @@ class Engine:
         N.check(N.lib().rcg_candidates_sample(self._h, C.c_void_p(d.ptr), int(K), int(round), pc), self._h)
         return d.to_host()
 
-    def set_optimizer(self, memory=-1):
+    def set_optimizer(self, memory=-1, ftol=None):
         """Curvature pairs the optimiser keeps per env (rcg_set_optimizer): 0 = projected steepest descent .. 8; -1 = the
-        default (4 for RQL / SQL and non-diagonal stage costs, 0 for MPC with a diagonal R1)."""
+        default (4 for RQL / SQL and non-diagonal stage costs, 0 for MPC with a diagonal R1).  ``ftol`` (rcg_set_optimizer_tol):
+        an env is done after an accepted step that lowered J by no more than that; 0 = no such test (a handle's default)."""
         N.check(N.lib().rcg_set_optimizer(self._h, int(memory)), self._h)
+        if ftol is not None:
+            N.check(N.lib().rcg_set_optimizer_tol(self._h, float(ftol)), self._h)
 
     @staticmethod
     def _ctrl_pars(ctrl_pars):

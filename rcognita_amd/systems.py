@@ -25,6 +25,7 @@ class System:
     """Interface class of dynamical systems a.k.a. environments (rcognita/systems.py:17-253)."""
 
     _sys_id = None  # set by the concrete systems
+    _ctrl_ref = None  # weak reference to the CtrlOptPred built around this system (_register_controller)
     name = "system"
 
     def __init__(self, sys_type, dim_state, dim_input, dim_output, dim_disturb, pars=[], ctrl_bnds=[], is_dyn_ctrl=0,

@@ -167,6 +167,9 @@ static void abi_host_side(void) {
   EXPECT(rcg_control_tick_nominal(NULL, 1.0, NULL) < 0);
   EXPECT(rcg_critic_update(NULL, 1) < 0);
   EXPECT(rcg_loop_step(NULL, x, 0.01, 1, RCG_LOOP_DECIDE, 3, x) < 0);
+  EXPECT(rcg_loop_step_begin(NULL, x, 0.01, 1, RCG_LOOP_DECIDE, 3) < 0);
+  EXPECT(rcg_loop_step_end(NULL, x) < 0);
+  EXPECT(rcg_set_optimizer_tol(NULL, 1e-7) < 0);
   EXPECT(rcg_sim_step_h(NULL, 1, 0.01) < 0);
   EXPECT(rcg_set_tick_parts(NULL, 2) < 0);
   EXPECT(rcg_join(NULL) < 0);

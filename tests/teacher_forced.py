@@ -14,7 +14,7 @@ optimiser:
            point - SLSQP's included - may have a lower P; and in plain Jc, Jc(w_dev) <= Jc(w_ref) + FIT_TOL Jc(w_init):
            what the Tikhonov term costs in the directions it damps (sigma^2 / trace ~ 1e-8; measured worst 1.34e-2,
            oracle/experiments/fit_mu_study.py: resolving them as SLSQP does costs 100 x the HIP-vs-oracle agreement);
-  actor    J(u_dev; w_ref) <= J(u_ref; w_ref) (1 + ACTOR_TOL)        the weights forced to the reference's (1330-1427);
+  actor    J(u_dev; w_ref) <= J(u_ref; w_ref) (1 + ACTOR_TOL) (+ 1e-7)  the weights forced to the reference's (1330-1427);
   action   |u_dev[0, i] - u_ref[0, i]| <= tau_i                      on every tick and component where the reference's own
            cost, with that component pinned tau_i away from SLSQP's optimum and everything else re-optimised by SLSQP,
            rises by more than the excess cost g = J(u_dev) / J* - 1 the decision under test actually left (+ RISE_MARGIN for
@@ -33,6 +33,8 @@ import numpy as np
 from oracle import rcg_oracle as O
 
 ACTOR_TOL = 0.005  # the optimiser's bar on F8 / F8c: within 0.5 % of SLSQP's cost
+ACTOR_ABS = 1e-7   # the accuracy the reference itself asks of SLSQP (tol=1e-7, controllers.py:1396) and the mirror classes'
+                   # opt_ftol: two costs closer than that are the same cost (one tick of the NI robot's SQL run has J* = 1.1e-10)
 FIT_TOL = 2e-2     # of Jc(w_init): what the fit's Tikhonov term (mu = 1e-8 trace / m) may leave above SLSQP's Jc
 RISE_MARGIN = 1e-4  # added to the achieved excess cost: SLSQP's re-optimised profile is itself only good to ~1e-5
 
@@ -92,7 +94,7 @@ def check_tick(tally, cfg, z, i, w_dev, u_dev, fracs, p_tol=1e-9):
     w_ref = z["tick_w"][i]
     J = float(O.actor_cost(u_dev[None], obs, xs, cfg, w_critic=w_ref)[0])
     J_ref = float(z["tick_J"][i])
-    gap = (J - J_ref) / abs(J_ref) if J_ref != 0 else 0.0
+    gap = (J - J_ref) / abs(J_ref) if J_ref != 0 and abs(J - J_ref) > ACTOR_ABS else 0.0
     tally.worst_j = max(tally.worst_j, gap)
     if not gap <= ACTOR_TOL:
         tally.failures.append(f"tick {i}: J {J:.8g} vs SLSQP's {J_ref:.8g} ({gap:+.3%})")

@@ -314,7 +314,7 @@ def test_mirror_classes_beyond_the_former_limits_vs_oracle(name, mode, cs, Ncrit
                                                ctrl.action_buffer[None], cfg)[0])
             worst_obj = max(worst_obj, (jc(ctrl.w_critic) - jc(w_or)) / max(jc(np.ones(cfg.dc)), 1e-300))
         u0 = np.broadcast_to(O.action_sqn_init(cfg), (1, Nactor, du))
-        U_or, J_or, _ = O.actor_optimize(cfg, np.array(obs)[None], xs[None], u0, 12, w_critic=w)
+        U_or, J_or, _ = O.actor_optimize(cfg, np.array(obs)[None], xs[None], u0, 12, w_critic=w, ftol=ctrl.opt_ftol)
         worst_J = max(worst_J, abs(float(ctrl.last_J[0]) - float(J_or[0])) / max(abs(float(J_or[0])), 1.0))
         # the cost the device reports IS the reference's _actor_cost of the sequence it returns (the oracle's restatement)
         J_chk = O.actor_cost(ctrl._prev_opt[0][None, None], np.array(obs)[None, None], xs[None, None], cfg,

@@ -317,3 +317,54 @@ def test_full_size_optimizer_tick():
     assert rel_err_norm(eng.get_field(Nn.FIELD_BEST_J)[sel], J_chk) < 1e-5
     J_start = O.actor_cost(np.broadcast_to(O.action_sqn_init(cfg), (64, Nh, 2)), st, st, cfg)
     assert np.all(J_chk <= J_start * (1 + 1e-6))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name,mode", [("3wrobot", "MPC"), ("3wrobotNI", "MPC"), ("2tank", "MPC"), ("2tank", "RQL"), ("3wrobotNI", "SQL")])
+def test_stopping_tolerance_vs_oracle(name, mode, dtype):
+    """rcg_set_optimizer_tol: an env is done after an accepted step that gained <= ftol.  f64: the oracle twin's walk with the same
+    ftol (same point, same number of accepted steps, fewer than without the test); ftol = 0 is the handle's default and changes
+    nothing; a huge ftol stops every env after its first accepted step; a negative or non-finite one is refused.  f32: the gains
+    are compared in float32 - the cost reached agrees with the f64 twin to the f32 tolerance and no env takes more steps."""
+    from rcognita_amd import _native as Nn
+
+    rng = np.random.default_rng(11)
+    B = 37
+    kw = dict(n_actor=6)
+    if mode != "MPC":
+        kw.update(mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS["quad-nomix"], buffer_size=8, n_critic=4)
+    eng, cfg = both(name, B, dtype, **kw)
+    x = rand_states(rng, name, B)
+    eng.set_state(x)
+    w = None
+    if mode != "MPC":
+        w = rng.uniform(0.1, 2.0, (B, cfg.dc))
+        eng.set_field(Nn.FIELD_W_CRITIC, w)
+    u0 = O.action_sqn_init(cfg, None)
+    _, U_a, J_a, n_a = eng.actor_optimize(iters=30)
+    eng.set_optimizer(-1, ftol=0.0)
+    _, U_z, J_z, n_z = eng.actor_optimize(iters=30)
+    np.testing.assert_array_equal(U_a, U_z)
+    np.testing.assert_array_equal(n_a, n_z)
+    for bad in (-1e-9, float("nan"), float("inf")):
+        with pytest.raises(Nn.NativeError) as ei:
+            eng.set_optimizer(-1, ftol=bad)
+        assert ei.value.code == Nn.ERR_BAD_ARG
+    ftol = 1e-5
+    eng.set_optimizer(-1, ftol=ftol)
+    _, U, J, n = eng.actor_optimize(iters=30)
+    U_or, J_or, n_or = O.actor_optimize(cfg, x, x, u0, iters=30, w_critic=w, ftol=ftol)
+    assert np.all(n <= n_a) and np.all(n >= np.minimum(n_a, 1))
+    if dtype == "f64":
+        same = n == n_or  # (a gain within rounding of ftol may fall on either side)
+        assert same.mean() > 0.9, (n, n_or)
+        assert rel_err_norm(J[same], J_or[same]) < 1e-9
+        assert rel_err_norm(U[same], U_or[same], floor=float(np.max(cfg.ctrl_bnds[:, 1]))) < 1e-5
+        assert np.any(n < n_a), "no walk was cut short: the test has no case"
+    else:
+        assert rel_err_norm(J, J_or) < 2e-4
+    assert np.all(J >= J_a * (1 - (1e-12 if dtype == "f64" else 1e-5)))
+    eng.set_optimizer(-1, ftol=1e30)
+    _, _, _, n1 = eng.actor_optimize(iters=30)
+    assert np.all(n1 <= 1)
+    eng.set_optimizer(-1, ftol=0.0)

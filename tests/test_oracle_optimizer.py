@@ -143,3 +143,32 @@ def test_optimizer_on_every_decision_of_the_reference_mpc_loop(name):
     assert np.all(J <= z["mpc_tick_J_init"] * (1 + 1e-12))
     gap = (J - z["mpc_tick_J"]) / np.abs(z["mpc_tick_J"])
     assert np.max(gap) < 5e-3, (np.median(gap), np.max(gap))
+
+
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_stopping_tolerance_of_the_optimizer(name):
+    """``ftol`` (rcg_set_optimizer_tol; the reference hands SLSQP ``tol=1e-7``, controllers.py:1396): the walk is the one without
+    the test, cut after the first accepted step that gained no more than ftol - so the cost reached is within the gains of the
+    steps not taken, the reference's SLSQP optimum on F8 is still met, and ftol = 0 changes nothing."""
+    meta, z = load_golden(f"F8_slsqp_actor_{name}")
+    cfg = oracle_cfg(name, n_actor=meta["N"], gamma=meta["gamma"], pred_step_size=meta["pred_step_size"])
+    u0 = O.action_sqn_init(cfg, [0.5] if name == "2tank" else None)
+    x = z["state"]
+    U0, J0, n0 = O.actor_optimize(cfg, x, x, u0, iters=30)
+    Uz, Jz, nz = O.actor_optimize(cfg, x, x, u0, iters=30, ftol=0.0)
+    np.testing.assert_array_equal(U0, Uz)
+    np.testing.assert_array_equal(n0, nz)
+    U7, J7, n7 = O.actor_optimize(cfg, x, x, u0, iters=30, ftol=1e-7)
+    assert np.all(n7 <= n0) and np.all(n7 >= 1)
+    assert np.any(n7 < n0), "the tolerance never cut a walk short: the test has no case"
+    assert np.all(J7 >= J0 * (1 - 1e-15)) and np.all(J7 <= z["J_init"] * (1 + 1e-12))
+    ratio = J7 / z["J_opt"]
+    assert np.median(ratio) < 1.0005 and np.max(ratio) < 1.002, (np.median(ratio), np.max(ratio))
+    # the cut walk is a prefix: replaying the full walk for n7 steps gives the same point
+    for b in range(0, x.shape[0], 5):
+        Ub, Jb, nb = O.actor_optimize_single(cfg, x[b], x[b], u0, int(n7[b]))
+        if nb == n7[b]:  # (a walk that a failed quasi-Newton trial prolongs uses iterations without accepting)
+            np.testing.assert_allclose(Ub, U7[b], rtol=0, atol=0)
+    # a coarse tolerance stops after the first accepted step
+    _, _, n_big = O.actor_optimize(cfg, x, x, u0, iters=30, ftol=1e30)
+    assert np.all(n_big <= 1)

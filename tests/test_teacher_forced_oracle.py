@@ -10,9 +10,10 @@ from tests.conftest import load_golden
 from tests.test_critic_traces import CASES, MODES, trace_cfg
 
 
+@pytest.mark.parametrize("ftol", [0.0, 1e-7], ids=["run-to-the-end", "ftol-of-the-mirror-classes"])
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name,cs", CASES)
-def test_teacher_forced_replay_of_the_reference_loop_through_the_oracle(name, cs, mode):
+def test_teacher_forced_replay_of_the_reference_loop_through_the_oracle(name, cs, mode, ftol):
     meta, z = load_golden(f"F7c_trace_{name}_{mode}_{cs}")
     cfg = trace_cfg(meta)
     u0 = O.action_sqn_init(cfg, [0.5] if name == "2tank" else None)
@@ -23,7 +24,7 @@ def test_teacher_forced_replay_of_the_reference_loop_through_the_oracle(name, cs
         w = None
         if z["tick_fitted"][i]:
             w = O.critic_fit(cfg, z["tick_w_prev"][i][None], z["tick_obs_buf"][i][None], z["tick_act_buf"][i][None])[0]
-        u, _, _ = O.actor_optimize_single(cfg, z["tick_obs"][i], z["tick_state_sys"][i], u0, 30, w_critic=z["tick_w"][i])
+        u, _, _ = O.actor_optimize_single(cfg, z["tick_obs"][i], z["tick_state_sys"][i], u0, 30, w_critic=z["tick_w"][i], ftol=ftol)
         TF.check_tick(tally, cfg, z, i, w, u, meta["first_fracs"])
     print("\n" + tally.line())
     assert not tally.failures, "\n".join(tally.failures[:10])

@@ -19,8 +19,30 @@ for decide, iters in ((False, 0), (True, 30), (True, 10)):
     for _ in range(n):
         eng.loop_step(act, 0.005, 1, decide=decide, iters=iters)
     print(f"loop_step decide={decide} iters={iters}: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call")
-for fuse in (True, False):
+for decide in (False, True):  # the two halves: what the host pays when the device runs the step behind its own bookkeeping
+    tb = te = 0.0
+    n = 2000
+    for i in range(n + 50):
+        t0 = time.perf_counter()
+        eng.loop_step_begin(act, 0.005, 1, decide=decide, iters=30)
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < (40e-6 if decide else 15e-6):  # (the loop body's bookkeeping)
+            pass
+        t2 = time.perf_counter()
+        eng.loop_step_end()
+        t3 = time.perf_counter()
+        if i >= 50:
+            tb += t1 - t0
+            te += t3 - t2
+    print(f"loop_step_begin decide={decide}: {tb / n * 1e6:.1f} us, loop_step_end after the step has finished: {te / n * 1e6:.1f} us")
+for fuse, spec in ((True, True), (True, False), (False, False)):
     import rcognita_amd.simulator as S
+    import rcognita_amd.controllers as Cc
+    orig_c = Cc.CtrlOptPred.__init__
+    def patched_c(self, *a, **k):
+        orig_c(self, *a, **k)
+        self.speculate = spec
+    Cc.CtrlOptPred.__init__ = patched_c
     orig = S.Simulator.__init__
     def patched(self, *a, **k):
         orig(self, *a, **k)
@@ -30,5 +52,6 @@ for fuse in (True, False):
     t0 = time.perf_counter()
     rows = run_reference_loop("3wrobot", "MPC", 5, 2.0)
     dt = time.perf_counter() - t0
-    print(f"reference loop, fuse={fuse}: {len(rows) / dt:.0f} sim steps/s ({dt / len(rows) * 1e6:.1f} us per step)")
+    print(f"reference loop, fuse={fuse}, next step started ahead={spec}: {len(rows) / dt:.0f} sim steps/s ({dt / len(rows) * 1e6:.1f} us per step)")
     S.Simulator.__init__ = orig
+    Cc.CtrlOptPred.__init__ = orig_c

@@ -11,11 +11,12 @@ from rcognita_amd import controllers
 from tests.test_hip_ref_traces import make_loop_objects
 
 
-def loop(t1, fuse=True):
+def loop(t1, fuse=True, ahead=True):
     """The calls of the reference's loop body, in its order (sim_step -> get_sim_step_data -> ctrl_selector -> receive_action ->
     receive_sys_state -> upd_accum_obj -> the state components -> stage_obj -> accum_obj), written out here - not the reference's text."""
     plant, ctrl, sim = make_loop_objects("3wrobot", "MPC", 5, t1)
     sim.fuse = fuse
+    ctrl.speculate = ahead
     held = np.zeros(2)
     n = 0
     while True:
@@ -34,8 +35,8 @@ def loop(t1, fuse=True):
 
 
 loop(0.1)
-for fuse in (True, False):
-    t0 = time.perf_counter(); n, last = loop(5.0, fuse); dt = time.perf_counter() - t0
-    print(f"fused loop step {fuse}: {n / dt:.0f} sim steps/s ({dt / n * 1e6:.1f} us per step), {n} steps, accum_obj {last[-1]:.4f}")
+for fuse, ahead in ((True, True), (True, False), (False, False)):
+    t0 = time.perf_counter(); n, last = loop(5.0, fuse, ahead); dt = time.perf_counter() - t0
+    print(f"fused loop step {fuse}, next step started ahead {ahead}: {n / dt:.0f} sim steps/s ({dt / n * 1e6:.1f} us per step), {n} steps, accum_obj {last[-1]:.4f}")
 pr = cProfile.Profile(); pr.enable(); loop(1.0); pr.disable()
 pstats.Stats(pr).sort_stats('tottime').print_stats(14)
