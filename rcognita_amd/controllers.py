@@ -243,7 +243,7 @@ class CtrlOptPred:
             return
         step = float(sim.dt)
         self._eng_raw.loop_step_begin(act, step, sim.n_substeps, decide=tick, push=push, fit=fit, iters=self.opt_iters)
-        self._spec = (sim, act.tobytes(), t_new, step, tick, fit, push)
+        self._spec = (sim, act.tobytes(), t_new, step, tick, fit, push, sim.n_substeps, self.opt_iters)
 
     def _fused_step(self, sim, act, t_new, step):
         """Called by Simulator.sim_step: hold `act` over one step, and compute ahead what the loop body will ask for at
@@ -259,7 +259,7 @@ class CtrlOptPred:
         actb = act.tobytes()
         spec = self._spec
         if spec is not None:  # this iteration may already be running (_speculate): take it if it is exactly the one asked for
-            if (spec[0] is sim and spec[2] == t_new and spec[3] == step and spec[4:] == (tick, fit, push) and not self._fused_dirty
+            if (spec[0] is sim and spec[2] == t_new and spec[3] == step and spec[4:] == (tick, fit, push, sim.n_substeps, self.opt_iters) and not self._fused_dirty
                     and spec[1] == actb
                     and not (push and not self._same(self._b(self.action_curr, self.dim_input), act))):
                 self._spec = None
