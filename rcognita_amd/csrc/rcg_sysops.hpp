@@ -573,12 +573,14 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     Ad.env_hi = h->sub_hi;
     const long pw = (Bn + gpw - 1) / gpw;
     const dim3 grid((unsigned)((pw + 3) / 4)), block(256);
-    // blocks per CU: 2 for rows of >= 80 bytes (a block keeps R KiB in flight), 4 for shorter rows, which need more
+    // blocks per CU: 2 for rows of >= 20 reals (a block keeps R KiB in flight in f32), 4 for shorter rows, which need more
     // waves to keep enough bytes on the wire (measured R = 6 ... 32 floats: 2 vs 4 differ by 1-3 % either side of
     // R = 20, R = 10 with 2 blocks/CU is 9 % slower than with 4; 8 blocks/CU is 5-15 % slower than the better of the two)
-    // ... and 4 as well when a wave's whole slab is short (< 64 KB: K = 64 at Nactor = 10 is 8 tiles per wave - the launch
+    // ... and 4 as well when a wave's whole slab is short (< 16 Ki reals: K = 64 at Nactor = 10 is 8 tiles per wave - the launch
     // is ramp-up and tail, more resident waves fill it better: 5.15 -> 5.57 TB/s)
-    const bool long_slab = (size_t)gpw * K * row_bytes >= (size_t)64 * 1024;
+    // (both thresholds count ELEMENTS - 16 Ki per wave, rows of 20 - since round 6: measured in f32 at first and kept in bytes, they
+    // sent the float64 shapes K = 64 and Nactor = 5 to 2 blocks per CU, where 4 stream 5 % / 3 % faster: profiles/r06_sweep_f64_geometry.txt)
+    const bool long_slab = (size_t)gpw * K * row_bytes >= (size_t)16 * 1024 * esz;
     // ... and 4 for the critic instances with many weights (>= 68 bytes of them: the robots' quad-lin / quadratic / quad-mix
     // structures in f32, 2tank quad-lin in f64), which are bound by VALU issue, not by the stream: more resident waves hide
     // more of it - 4-5 % on random weights, 8-11 % inside a closed loop (profiles/r04_per_cu_matrix.txt, r04_ab_per_cu.txt:
@@ -586,7 +588,7 @@ static int launch_actor(rcg_handle* h, const char* who, const void* cand, int K,
     const bool valu_heavy = variant == DMA_MPC_GENF ||  // (35-77 fused multiply-adds per step of stage cost)
                             variant >= DMA_RQL_GEN_0 ||
                             ((dma_is_rql(variant) || dma_is_sql(variant)) && (size_t)dma_dc(dma_cs(variant), Sys::DS, DU) * esz >= 68);
-    const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 80 && long_slab && !valu_heavy) ? 2 : 4);
+    const int per_cu = knobs.per_cu > 0 ? knobs.per_cu : ((row_bytes >= 20 * esz && long_slab && !valu_heavy) ? 2 : 4);
     // J staging (operator mode): all envs of the wave when that fits under 64 KB next to the tiles, else env by env
     Ad.jwave = (A.J && 4 * tile + wslot + 4 * esz * gpw * K <= (size_t)64 * 1024) ? 1 : 0;
     size_t lds_req = 4 * tile + wslot + (A.J ? 4 * esz * K * (Ad.jwave ? gpw : 1) : 0);
