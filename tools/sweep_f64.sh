@@ -1,7 +1,8 @@
-# A/B of k_actor_dma<double>'s residency (dev library knobs; interleaved on one device): the shapes whose residency the
-# element-based thresholds of round 6 changed (default = 4 blocks per CU now) against the former 2.   bash tools/sweep_f64.sh
-export SWEEP_DTYPE=f64
-for shape in "SWEEP_N=5" "SWEEP_N=7" "SWEEP_K=64" "SWEEP_K=96" "SWEEP_B=16384" "SWEEP_B=32768" "SWEEP_N=10"; do for rep in 1 2; do
-env $shape RCG_PER_CU=2 python tools/knob_sweep.py 2>/dev/null | tail -1
-env $shape python tools/knob_sweep.py 2>/dev/null | tail -1
+# k_actor_dma<double> taken apart on the C2 shape (dev library, RCG_DBG bits: 1 no rollout, 2 no argmin / writes, 4 no env-state loads),
+# interleaved on one device; the same for float for comparison.   bash tools/sweep_f64.sh
+for dt in f64 f32; do export SWEEP_DTYPE=$dt
+for rep in 1 2 3; do
+python tools/knob_sweep.py 2>/dev/null | tail -1
+RCG_DBG=1 python tools/knob_sweep.py 2>/dev/null | tail -1
+RCG_DBG=7 python tools/knob_sweep.py 2>/dev/null | tail -1
 done; done
