@@ -36,9 +36,11 @@ for k in range(n):
     my_ctrl.upd_accum_obj(obs, a)
 dt = time.perf_counter() - t0
 line("B = 1 fused loop (3wrobotNI, MPC, Nactor 3)", steps=n, fused_steps=my_ctrl.fused_steps, fused_decisions=my_ctrl.fused_decisions,
+     started_ahead=my_ctrl.spec_hits, dropped=my_ctrl.spec_drops,
      steps_per_s=round(n / dt), final_state=np.round(np.asarray(full, dtype=float), 6).tolist(), accum=float(my_ctrl.accum_obj_val),
      finite=bool(np.all(np.isfinite(full))))
 assert my_ctrl.fused_steps == n and my_ctrl.fused_decisions == n // 2 and np.all(np.isfinite(full))
+assert my_ctrl.spec_hits >= n - 3 and my_ctrl.spec_drops <= 1
 
 # 2. the headline shape in float64, 20 000 ticks of the streamed tick
 B, K, Nh = 65536, 256, 10
