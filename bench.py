@@ -433,12 +433,42 @@ def parity_check(args, device, stream_ptr, x0, cand, K, tol=1e-5, n_sample=64, t
 
 
 # ---------------------------------------------------------------------------------------------------------------
+_STDOUT_KEEP = None
+
+
+def stdout_to_stderr():
+    """The contract is ONE JSON line on stdout, and libraries greet there (RCCL 2.26 prints five lines of versions when its first
+    communicator comes up; gloo announces its peers): while a process group exists, file descriptor 1 points at stderr."""
+    global _STDOUT_KEEP
+    if _STDOUT_KEEP is None:
+        sys.stdout.flush()
+        _STDOUT_KEEP = os.dup(1)
+        os.dup2(2, 1)
+
+
+def stdout_back():
+    """Before the JSON line: flush what Python and the C library still hold for descriptor 1, then point it at stdout again."""
+    global _STDOUT_KEEP
+    if _STDOUT_KEEP is not None:
+        sys.stdout.flush()
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(_STDOUT_KEEP, 1)
+        os.close(_STDOUT_KEEP)
+        _STDOUT_KEEP = None
+
+
 def dry_rank(args, rank, local_rank, world):
     """--dry-launch: rendezvous over gloo on the CPU and report what the launcher handed to each rank."""
     import torch
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    stdout_to_stderr()
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     mine = torch.tensor([rank, local_rank, os.getpid()], dtype=torch.int64)
     parts = [torch.empty_like(mine) for _ in range(world)]
@@ -449,6 +479,7 @@ def dry_rank(args, rank, local_rank, world):
     span = torch.tensor([lo, hi], dtype=torch.int64)
     spans = [torch.empty_like(span) for _ in range(world)]
     dist.all_gather(spans, span)
+    stdout_back()
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(),
                           "launcher": os.environ.get("RCG_BENCH_LAUNCHER", "external"),
@@ -511,6 +542,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        stdout_to_stderr()
         if args.dist_backend == "nccl":  # RCCL: the communicator is bound to this rank's GPU at creation
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=coll_dev)
         else:
@@ -979,8 +1011,11 @@ def main(argv=None):
             out["cpu_baseline"]["reference_algorithm"] = cpu_reference_algorithm(args, min(args.cpu_seconds, 8.0))
         except ImportError as e:  # SciPy missing on the box: the port above is the baseline
             out["cpu_baseline"]["reference_algorithm"] = {"error": str(e)}
+    stdout_back()
     print(json.dumps(strict_json(out)))
+    sys.stdout.flush()
     if dist is not None:
+        stdout_to_stderr()  # (whatever the teardown prints)
         dist.barrier()
         dist.destroy_process_group()
     if "parity" in out and not out["parity"]["ok"]:

@@ -45,7 +45,8 @@ python bench.py --gpus 2 --dist-backend gloo --single-device --steps 100 --warmu
 python tools/opt_probe.py 2>/dev/null | grep -v amdgpu > $O/r06_opt_probe.txt
 python tools/critic_stream_probe.py f32 2>/dev/null | grep -v amdgpu > $O/r06_critic_stream_probe_f32.txt
 python tools/critic_stream_probe.py f64 2>/dev/null | grep -v amdgpu > $O/r06_critic_stream_probe_f64.txt
-python tools/b1_profile.py 2>&1 | grep -v amdgpu | head -30 > $O/r06_b1_profile.txt
+python tools/generic_stream_probe.py f32 2>/dev/null | grep -v amdgpu > $O/r06_generic_stream_probe_f32.txt
+python tools/generic_stream_probe.py f64 2>/dev/null | grep -v amdgpu > $O/r06_generic_stream_probe_f64.txt
 ls $O
 fi
 if [ "$PART" = 3 ]; then
