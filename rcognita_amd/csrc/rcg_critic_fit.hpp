@@ -99,13 +99,11 @@ struct FitArgs {
 // The part of an env's critic update that precedes the solver: [env step] -> [push] -> TD stack (A, b) and the box.  `store`:
 // this lane writes the env's state / buffers back (false for the lanes that only help with the env's solve, k_critic_fit_ml).
 // Returns false when there is nothing to fit (F.do_fit == 0).
-template <typename Sys, typename real, int CS, int MAXM>
-__device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KParams<double>& P, const KParams<real>& Pr,
-                                                const long b, const bool store,
-                                                double (&A)[MAXM][CriticDim<CS, Sys::DS, Sys::DU>::value], double (&bv)[MAXM],
-                                                double (&w0)[CriticDim<CS, Sys::DS, Sys::DU>::value],
-                                                double (&lo)[CriticDim<CS, Sys::DS, Sys::DU>::value],
-                                                double (&hi)[CriticDim<CS, Sys::DS, Sys::DU>::value]) {
+// (`row(r, phi)` receives the regressor of TD row r, r < m: the one-lane kernels keep all of it - critic_prologue below -, the
+// four-lane kernel only the columns of the calling lane, so that no lane ever holds the whole m x dc stack in registers)
+template <typename Sys, typename real, int CS, int MAXM, typename RowSink>
+__device__ __forceinline__ bool critic_prologue_rows(const FitArgs<real>& F, const KParams<double>& P, const KParams<real>& Pr,
+                                                     const long b, const bool store, double (&bv)[MAXM], RowSink row) {
   constexpr int DS = Sys::DS, DU = Sys::DU, NCHI = DS + DU, DC = CriticDim<CS, DS, DU>::value;
   // rows of the shifted buffers that stay in registers for the TD stack: new row r = old row r + 1, r = 0 .. KEEP - 1
   constexpr int KEEP = MAXM + 1 <= 4 ? MAXM + 1 : 4;
@@ -225,20 +223,8 @@ __device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KP
     if (!F.do_fit) return false;
   }
 
-  double wp[DC];
 #pragma unroll
-  for (int i = 0; i < DC; ++i) {
-    wp[i] = (double)wpr[i];
-    w0[i] = F.wcfg[i];
-    lo[i] = F.wcfg[40 + i];
-    hi[i] = F.wcfg[80 + i];
-  }
-#pragma unroll
-  for (int r = 0; r < MAXM; ++r) {
-    bv[r] = 0.0;
-#pragma unroll
-    for (int i = 0; i < DC; ++i) A[r][i] = 0.0;
-  }
+  for (int r = 0; r < MAXM; ++r) bv[r] = 0.0;
   // ---- build A, b from buffer rows 0 .. m (the oldest rows, controllers.py:1231-1234) ----------
 #pragma unroll
   for (int r = 0; r <= MAXM; ++r) {
@@ -264,17 +250,43 @@ __device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KP
       if (r > 0) {  // gamma * w_prev . phi(row r) belongs to TD row r - 1
         double q = 0.0;
 #pragma unroll
-        for (int i = 0; i < DC; ++i) q = fma_r(wp[i], phi[i], q);
+        for (int i = 0; i < DC; ++i) q = fma_r((double)wpr[i], phi[i], q);
         bv[r - 1 < MAXM ? r - 1 : 0] += P.gamma * q;
       }
       if (r < m && r < MAXM) {
-#pragma unroll
-        for (int i = 0; i < DC; ++i) A[r][i] = phi[i];
+        row(r, phi);
         bv[r] += stage_any<NCHI, double>(P, chi);
       }
     }
   }
 
+  return true;
+}
+
+// the whole stack A [m][dc] (rows >= m zero), b, and the box: what the one-lane walks work on
+template <typename Sys, typename real, int CS, int MAXM>
+__device__ __forceinline__ bool critic_prologue(const FitArgs<real>& F, const KParams<double>& P, const KParams<real>& Pr,
+                                                const long b, const bool store,
+                                                double (&A)[MAXM][CriticDim<CS, Sys::DS, Sys::DU>::value], double (&bv)[MAXM],
+                                                double (&w0)[CriticDim<CS, Sys::DS, Sys::DU>::value],
+                                                double (&lo)[CriticDim<CS, Sys::DS, Sys::DU>::value],
+                                                double (&hi)[CriticDim<CS, Sys::DS, Sys::DU>::value]) {
+  constexpr int DC = CriticDim<CS, Sys::DS, Sys::DU>::value;
+#pragma unroll
+  for (int r = 0; r < MAXM; ++r)
+#pragma unroll
+    for (int i = 0; i < DC; ++i) A[r][i] = 0.0;
+  const bool fit = critic_prologue_rows<Sys, real, CS, MAXM>(F, P, Pr, b, store, bv, [&](int r, const double (&phi)[DC]) {
+#pragma unroll
+    for (int i = 0; i < DC; ++i) A[r][i] = phi[i];
+  });
+  if (!fit) return false;
+#pragma unroll
+  for (int i = 0; i < DC; ++i) {
+    w0[i] = F.wcfg[i];
+    lo[i] = F.wcfg[40 + i];
+    hi[i] = F.wcfg[80 + i];
+  }
   return true;
 }
 

@@ -57,36 +57,37 @@ __device__ __forceinline__ void critic_update_env_ml(const FitArgs<real>& F, con
   constexpr int NS = (DC + FIT_L - 1) / FIT_L;  // slots per lane
   const long B = P.B;
   const int m = P.n_critic - 1;
-  double Afull[MAXM][DC], bv[MAXM], w0f[DC], lof[DC], hif[DC];
-  if (!critic_prologue<Sys, real, CS, MAXM>(F, P, Pr, b, s == 0, Afull, bv, w0f, lof, hif)) return;
-
-  // my variables: i = k * FIT_L + s (a slot beyond dc: a variable fixed at 0 with a zero column - it never moves)
-  double A[MAXM][NS], w0[NS], lo[NS], hi[NS];
+  // my variables: i = k * FIT_L + s (a slot beyond dc: a variable fixed at 0 with a zero column - it never moves).  Every lane
+  // runs the prologue (the env step, the push, b: the same bits as k_critic_fit's) but keeps only ITS columns of the regressor
+  // rows - round 6: with the whole 3 x 35 stack and three 35-entry box arrays per lane the kernel needed 256 VGPRs + 134 AGPRs
+  // (one wave per SIMD); the arithmetic is unchanged
+  double A[MAXM][NS], bv[MAXM], w0[NS], lo[NS], hi[NS];
   unsigned own = 0u;  // slots that hold a variable
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    double v0 = 0.0, vl = 0.0, vh = 0.0;
-    double col[MAXM];
+    if (k * FIT_L + s < DC) own |= 1u << k;
 #pragma unroll
-    for (int r = 0; r < MAXM; ++r) col[r] = 0.0;
+    for (int r = 0; r < MAXM; ++r) A[r][k] = 0.0;
+  }
+  const bool fit = critic_prologue_rows<Sys, real, CS, MAXM>(F, P, Pr, b, s == 0, bv, [&](int r, const double (&phi)[DC]) {
 #pragma unroll
-    for (int t = 0; t < FIT_L; ++t) {
-      const int i = k * FIT_L + t;
-      if (i < DC) {
-        const bool me = s == t;
-        v0 = me ? w0f[i] : v0;
-        vl = me ? lof[i] : vl;
-        vh = me ? hif[i] : vh;
+    for (int k = 0; k < NS; ++k) {
+      double v = 0.0;
 #pragma unroll
-        for (int r = 0; r < MAXM; ++r) col[r] = me ? Afull[r][i] : col[r];
-        if (me) own |= 1u << k;
-      }
+      for (int t = 0; t < FIT_L; ++t)
+        if (k * FIT_L + t < DC) v = s == t ? phi[k * FIT_L + t] : v;
+      A[r][k] = v;
     }
-    w0[k] = v0;
-    lo[k] = vl;
-    hi[k] = vh;
+  });
+  if (!fit) return;
 #pragma unroll
-    for (int r = 0; r < MAXM; ++r) A[r][k] = col[r];
+  for (int k = 0; k < NS; ++k) {
+    const bool mine = (own >> k) & 1u;
+    const int i = mine ? k * FIT_L + s : 0;
+    const double v0 = F.wcfg[i], vl = F.wcfg[40 + i], vh = F.wcfg[80 + i];
+    w0[k] = mine ? v0 : 0.0;
+    lo[k] = mine ? vl : 0.0;
+    hi[k] = mine ? vh : 0.0;
   }
 
   double trp = 0.0;
@@ -114,25 +115,20 @@ __device__ __forceinline__ void critic_update_env_ml(const FitArgs<real>& F, con
 
   for (int it = 0; it < fit_max_iters(DC); ++it) {
     double L[MAXM][MAXM], lam[MAXM];
-    double Af[MAXM][NS], wb[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const bool fr = (fm >> k) & 1u;
-      wb[k] = fr ? w0[k] : w[k];
-#pragma unroll
-      for (int r = 0; r < MAXM; ++r) Af[r][k] = fr ? A[r][k] : 0.0;
-    }
 #pragma unroll
     for (int r = 0; r < MAXM; ++r) {
       double sp = 0.0;
 #pragma unroll
-      for (int k = 0; k < NS; ++k) sp = fma_r(-A[r][k], wb[k], sp);
+      for (int k = 0; k < NS; ++k) sp = fma_r(-A[r][k], ((fm >> k) & 1u) ? w0[k] : w[k], sp);
       lam[r] = bv[r] + quad_sum(sp);
 #pragma unroll
       for (int q = 0; q <= r; ++q) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) acc = fma_r(Af[r][k], Af[q][k], acc);
+        for (int k = 0; k < NS; ++k) {  // A_F = the free columns (a fixed one counts as a zero column: fma(0, 0, acc) = acc)
+          const bool fr = (fm >> k) & 1u;
+          acc = fma_r(fr ? A[r][k] : 0.0, fr ? A[q][k] : 0.0, acc);
+        }
         L[r][q] = quad_sum(acc) + (r == q ? mu : 0.0);
       }
     }
@@ -299,7 +295,7 @@ __device__ __forceinline__ void critic_update_env_ml(const FitArgs<real>& F, con
 
 // one quad per env: blocks of 64 threads = 16 envs
 template <typename Sys, typename real, int CS, int MAXM>
-__global__ __launch_bounds__(64) void k_critic_fit_ml(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_critic_fit_ml(const FitArgs<real> F, const KParams<double> P, const KParams<real> Pr) {
   const long b = F.env_lo + (long)blockIdx.x * (blockDim.x / FIT_L) + (threadIdx.x / FIT_L);
   if (b >= (F.env_hi > 0 ? (long)F.env_hi : P.B)) return;  // (whole quads leave together: the DPP exchanges below stay inside a quad)
   critic_update_env_ml<Sys, real, CS, MAXM>(F, P, Pr, b, (int)(threadIdx.x & (FIT_L - 1)));

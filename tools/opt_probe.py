@@ -49,7 +49,15 @@ def main():
             e.control_tick_opt(iters=5)
         b.record(st)
         torch.cuda.synchronize()
-        print(f"{mode} {cs} memory {mem} {dt}: {a.elapsed_time(b) / n:.4f} ms per tick, launch {e.last_launch()}", flush=True)
+        from rcognita_amd import _native as Nn
+
+        e.profile((Nn.KERNEL_CRITIC, Nn.KERNEL_ACTOR), stride=1)  # where the tick goes: the fit's launch against the optimiser's
+        for _ in range(n):
+            e.control_tick_opt(iters=5)
+        e.synchronize()
+        (cm, cn), (am, an) = e.profile_read(Nn.KERNEL_CRITIC), e.profile_read(Nn.KERNEL_ACTOR)
+        split = f"k_actor_opt {am / max(an, 1) * 1e3:.0f} us" + (f", env step + push + fit {cm / max(cn, 1) * 1e3:.0f} us ({e.last_launch(Nn.KERNEL_CRITIC)['variant']})" if cn else "")
+        print(f"{mode} {cs} memory {mem} {dt}: {a.elapsed_time(b) / n:.4f} ms per tick ({split}), launch {e.last_launch()}", flush=True)
         e.close()
 
 
