@@ -126,10 +126,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // reals of LDS one wave needs (host and device agree through this one function):
-// u [G][R] | d [G][R] | X [N*DS][G] | y0 [DS][G] | xs [DS][G] | pars [NPS][G] | w [DC][G] | g [R][G] | q [R][G] |
+// u [G][R] | d [G][R] (= q, the two-loop work vector) | X [N*DS][G] | y0 [DS][G] | xs [DS][G] | pars [NPS][G] | w [DC][G] | g [R][G] |
 // S [M][R][G] | Y [M][R][G] | gamma^k [N]
 __host__ __device__ constexpr int opt_lds_reals(int N, int DS, int DU, int NP, int DC, int M) {
-  return OPT_G * (2 * N * DU + N * DS + 2 * DS + (NP > 0 ? NP : 1) + DC + 2 * N * DU + 2 * M * N * DU) + N;
+  return OPT_G * (2 * N * DU + N * DS + 2 * DS + (NP > 0 ? NP : 1) + DC + N * DU + 2 * M * N * DU) + N;
 }
 
 // gk * d rho / d chi of stage_obj (controllers.py:1076-1082): quadratic chi R1 chi -> (R1 + R1^T) chi;
@@ -247,8 +247,9 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
   real* const sP = sS + DS * G;
   real* const sW = sP + NPS * G;    // critic weights [DCW][G]
   real* const sGc = sW + DCW * G;   // current gradient [R][G]
-  real* const sQ = sGc + R * G;     // two-loop work vector [R][G]
-  real* const sLS = sQ + R * G;     // pairs: s [M][R][G]
+  real* const sQ = sd;              // two-loop work vector [G][R]: IN the direction's storage (d of the last iteration is dead by then
+                                    // and the recursion's result is the new d: round 6, 1.25 KB per wave that decide 7 or 8 waves per CU)
+  real* const sLS = sGc + R * G;    // pairs: s [M][R][G]
   real* const sLY = sLS + M * R * G;  //        y [M][R][G]
   real* const sg = sLY + M * R * G;  // gamma^k, k < N, formed as the forward sum forms it (gk = 1; gk *= gamma)
 
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
         }
         quasi_q = np_q > 0;
         if (quasi_q) {  // L-BFGS two-loop recursion over the pairs restricted to the free set
-          for (int i = qq; i < R; i += 4) sQ[i * G + qe] = ((fm >> i) & 1ull) ? sGc[i * G + qe] : (real)0;
+          for (int i = qq; i < R; i += 4) sQ[qe * R + i] = ((fm >> i) & 1ull) ? sGc[i * G + qe] : (real)0;
           real a_t[OPT_MAXM], sy_t[OPT_MAXM];
           unsigned okm = 0u;
           real scale = 1;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
                   sy = fma_r(s_, y_, sy);
                   ss = fma_r(s_, s_, ss);
                   yy = fma_r(y_, y_, yy);
-                  sq = fma_r(s_, sQ[i * G + qe], sq);
+                  sq = fma_r(s_, sQ[qe * R + i], sq);
                   yhy = fma_r(y_ * w2[i % DU], y_, yhy);
                 }
               sy = opt_quad_sum(sy);
@@ -544,11 +545,11 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
                 const real a = sq / sy;
                 a_t[t] = a;
                 for (int i = qq; i < R; i += 4)
-                  if ((fm >> i) & 1ull) sQ[i * G + qe] = fma_r(-a, Yj[i * G], sQ[i * G + qe]);
+                  if ((fm >> i) & 1ull) sQ[qe * R + i] = fma_r(-a, Yj[i * G], sQ[qe * R + i]);
               }
             }
           }
-          for (int i = qq; i < R; i += 4) sQ[i * G + qe] = (scale * w2[i % DU]) * sQ[i * G + qe];
+          for (int i = qq; i < R; i += 4) sQ[qe * R + i] = (scale * w2[i % DU]) * sQ[qe * R + i];
 #pragma unroll
           for (int t = OPT_MAXM - 1; t >= 0; --t) {  // oldest -> newest
             if (t < np_q && ((okm >> t) & 1u)) {
@@ -558,15 +559,15 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
               const real* const Yj = sLY + (size_t)j * R * G + qe;
               real yr = 0;
               for (int i = qq; i < R; i += 4)
-                if ((fm >> i) & 1ull) yr = fma_r(Yj[i * G], sQ[i * G + qe], yr);
+                if ((fm >> i) & 1ull) yr = fma_r(Yj[i * G], sQ[qe * R + i], yr);
               yr = opt_quad_sum(yr);
               const real cf = a_t[t] - yr / sy_t[t];
               for (int i = qq; i < R; i += 4)
-                if ((fm >> i) & 1ull) sQ[i * G + qe] = fma_r(Sj[i * G], cf, sQ[i * G + qe]);
+                if ((fm >> i) & 1ull) sQ[qe * R + i] = fma_r(Sj[i * G], cf, sQ[qe * R + i]);
             }
           }
           real dg = 0;
-          for (int i = qq; i < R; i += 4) dg = fma_r(sQ[i * G + qe], sGc[i * G + qe], dg);
+          for (int i = qq; i < R; i += 4) dg = fma_r(sQ[qe * R + i], sGc[i * G + qe], dg);
           dg = opt_quad_sum(dg);
           if (!(dg > (real)0) || !finite_r<real>(dg)) {  // not a descent direction: drop the memory
             quasi_q = false;
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256) void k_actor_opt(const OptArgs<real> A, const 
         }
         for (int i = qq; i < R; i += 4) {
           const int c = i % DU;
-          const real dc = quasi_q ? sQ[i * G + qe] : (((fm >> i) & 1ull) ? sGc[i * G + qe] * w2[c] : (real)0);
+          const real dc = quasi_q ? sQ[qe * R + i] : (((fm >> i) & 1ull) ? sGc[i * G + qe] * w2[c] : (real)0);
           sd[qe * R + i] = dc;
           const real m = (dc < 0 ? -dc : dc) / w[c];
           gn_q = m > gn_q ? m : gn_q;

@@ -724,7 +724,8 @@ int op_optimize(rcg_handle* h, int32_t iters, const void* obs, const void* state
     size_t on_cu = 0;
     for (int cand_wpb = 4; cand_wpb >= 1; cand_wpb >>= 1) {
       const size_t fit = lds_wave * cand_wpb ? ((size_t)160 * 1024 / (lds_wave * cand_wpb)) * cand_wpb : 0;
-      if (fit > on_cu) {
+      if (fit * 4 > on_cu * 5) {  // a smaller block must bring a quarter more waves: 9 single-wave blocks against 2 x 4 measured 10 % SLOWER
+                                  // (MPC with 4 pairs, 18.1 KB per wave: one SIMD carries three waves and the second round is ragged)
         on_cu = fit;
         wpb = cand_wpb;
       }
