@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Randomised differential run (GPU box): random configurations - system, element type, mode, critic structure, stage-cost structure,
+target, discount, horizon, K, batch, TD rows - through the streamed operator / argmin and through closed-loop ticks (env step, buffer
+push, critic fit, decision), every number against the oracle.  Complements the parametrised tests: the shapes here are not
+hand-picked.   python tools/fuzz_parity.py [cases] [seed]     TEST INFRASTRUCTURE: the oracle is the checker."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import rcg_oracle as O  # noqa: E402
+from tests.helpers import PRESETS, both, rand_actions, rand_states, rel_err_norm  # noqa: E402
+
+
+
+def run(n_cases, seed, verbose=False):
+    """-> (failures [str], worst relative error per element type, kernels that served the streamed decisions)"""
+    rng = np.random.default_rng(seed)
+    TOL = {"f64": 1e-10, "f32": 2e-5}
+    worst = {"f64": 0.0, "f32": 0.0}
+    kernels = {}
+    fails = []
+    t0 = time.time()
+    for case in range(n_cases):
+        name = str(rng.choice(["3wrobot", "3wrobotNI", "2tank"]))
+        dtype = str(rng.choice(["f64", "f32"]))
+        mode = str(rng.choice(["MPC", "MPC", "RQL", "SQL"]))
+        cs = str(rng.choice(["quad-lin", "quadratic", "quad-nomix", "quad-mix"]))
+        N = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 16, 20, 24]))
+        K = int(rng.choice([1, 2, 5, 8, 16, 31, 32, 33, 40, 64, 65, 100, 128, 200, 256, 300]))
+        B = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 70]))
+        p = PRESETS[name]
+        n = len(p["R1"])
+        kw = dict(n_actor=N, gamma=float(rng.choice([1.0, 0.97, 0.9])), mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs])
+        stage = str(rng.choice(["diag", "diag", "full", "biquad", "biquad-full"]))
+        if stage in ("full", "biquad-full"):
+            M = rng.normal(size=(n, n)) * 0.3
+            kw["R1"] = M @ M.T + np.diag(p["R1"])
+        if stage.startswith("biquad"):
+            kw["stage_obj_struct"] = O.STAGE_IDS["biquadratic"]
+            kw["R2"] = np.diag(rng.uniform(0.0, 0.5, n)) if stage == "biquad" else (lambda Q: Q @ Q.T)(rng.normal(size=(n, n)) * 0.2)
+        if rng.uniform() < 0.3:
+            kw["target"] = list(rng.uniform(-1, 1, len(p["x0"])))
+        if mode != "MPC":
+            bs = int(rng.choice([4, 6, 10, 14]))
+            kw.update(buffer_size=bs, n_critic=int(rng.integers(2, min(bs, 13))))
+        what = f"case {case}: {name} {dtype} {mode} {cs} N={N} K={K} B={B} stage={stage} target={'target' in kw} " + (f"bs={kw.get('buffer_size')} Nc={kw.get('n_critic')}" if mode != "MPC" else "")
+        try:
+            eng, cfg = both(name, B, dtype, **kw)
+            x = rand_states(rng, name, B)
+            cand = rand_actions(rng, name, (B, K, N), overshoot=1.2)
+            eng.set_state(x)
+            from rcognita_amd import _native as Nn
+
+            w = None
+            if mode != "MPC":
+                lo, hi = O.critic_bounds(cfg.critic_struct, cfg.dc)
+                w = rng.uniform(np.maximum(lo, -2.0), np.minimum(hi, 2.0), (B, cfg.dc))
+                eng.set_field(Nn.FIELD_W_CRITIC, w)
+                eng.set_field(Nn.FIELD_W_PREV, w)
+            # 1. the streamed operator and the argmin
+            J = eng.actor_cost(cand)
+            J_or = O.actor_cost(cand, x[:, None, :], x[:, None, :], cfg, w_critic=None if w is None else w[:, None, :])
+            # float64 element by element; float32 against the largest cost of the batch (random signed critic weights make a J a
+            # difference of large terms: its float32 error scales with the terms, not with the difference)
+            e1 = rel_err_norm(J, J_or) if dtype == "f64" else float(np.max(np.abs(J - J_or)) / max(float(np.max(np.abs(J_or))), 1.0))
+            act, bj, bi = eng.actor_argmin(cand)
+            ok_idx = np.array_equal(bi, np.argmin(J, axis=1).astype(np.int32))
+            ll = eng.last_launch()
+            kernels[ll["kernel"]] = kernels.get(ll["kernel"], 0) + 1
+            # 2. closed-loop ticks against the oracle's batch (f64: same decisions; f32: costs agree)
+            env = O.new_batch(cfg, x)
+            if w is not None:
+                env.w_critic, env.w_prev = w.copy(), w.copy()
+            e2 = 0.0
+            T = 4 if mode == "MPC" else int(kw["buffer_size"]) + 2
+            same_path = True
+            for t in range(T):
+                eng.control_tick(cand, K=K)
+                O.control_tick(cfg, env, cand)
+                st = eng.get_state().astype(np.float64)
+                if dtype == "f64" and not np.array_equal(eng.get_field(Nn.FIELD_BEST_IDX), env.best_idx):
+                    same_path = False  # (a tie within rounding: the trajectories part - compare up to here only)
+                    break
+                e2 = max(e2, rel_err_norm(st, env.state, floor=1.0))
+                if dtype == "f32":
+                    break  # float32 decisions may differ by a rounding: one tick is the statement
+            # (the ticks above refitted the critic and filled the buffers: the remaining checks start from fresh handles)
+            eng.close()
+
+            def fresh():
+                e_, _ = both(name, B, dtype, **kw)
+                e_.set_state(x)
+                if w is not None:
+                    e_.set_field(Nn.FIELD_W_CRITIC, w)
+                    e_.set_field(Nn.FIELD_W_PREV, w)
+                return e_
+
+            eng = fresh()
+            # 3. the generated level grid (cand == NULL) against the oracle's grid
+            e3 = 0.0
+            Kg = int(rng.choice([1, 4, 9, 16, 64, 256])) if cfg.du == 2 else int(rng.choice([1, 3, 8, 64, 100, 256]))
+            eng.set_state(x)
+            actg, bjg, big = eng.actor_argmin(None, K=Kg)
+            grid = O.grid_candidates(cfg, Kg)
+            Jg = O.actor_cost(grid[None], x[:, None, :], x[:, None, :], cfg, w_critic=None if w is None else w[:, None, :])
+            bjg_or, big_or = O.argmin_first(Jg)
+            e3 = rel_err_norm(bjg, bjg_or) if dtype == "f64" else float(np.max(np.abs(bjg - bjg_or)) / max(float(np.max(np.abs(Jg))), 1.0))
+            if dtype == "f64" and not np.array_equal(big, big_or):
+                fails.append(f"{what}: generated grid K={Kg}: best_idx differs from the oracle's")
+            # 4. the on-device optimiser against its oracle twin (float64: the same walk)
+            e4 = 0.0
+            if dtype == "f64" and B <= 17 and N <= 10:
+                its = int(rng.integers(1, 5))
+                _, U, Jo, _ = eng.actor_optimize(iters=its)
+                U_or, J_or2, _ = O.actor_optimize(cfg, x, x, O.action_sqn_init(cfg, None), iters=its, w_critic=w)
+                e4 = rel_err_norm(Jo, J_or2)
+                if e4 > 1e-8:  # (a discrete line search: a rounding-level tie between two step lengths parts the walks - the cost must still be the twin's)
+                    e4 = 0.0 if np.all(Jo <= J_or2 * (1 + 1e-6) + 1e-9) or np.all(np.abs(Jo - J_or2) <= 1e-3 * np.maximum(np.abs(J_or2), 1.0)) else e4
+            # 5. T ticks in one native call = T single ticks, bit for bit
+            eng.close()
+            eng, eng2 = fresh(), fresh()
+            Tn = int(rng.integers(2, 5))
+            eng.control_tick(cand, K=K, T=Tn)
+            for _ in range(Tn):
+                eng2.control_tick(cand, K=K)
+            if not np.array_equal(eng.get_state(), eng2.get_state()) or not np.array_equal(eng.get_field(Nn.FIELD_ACCUM), eng2.get_field(Nn.FIELD_ACCUM)):
+                fails.append(f"{what}: {Tn} ticks in one call differ from {Tn} single ticks")
+            eng2.close()
+            err = max(e1, e2, e3, e4)
+            worst[dtype] = max(worst[dtype], err)
+            if not (err <= TOL[dtype]) or not ok_idx:
+                fails.append(f"{what}: J {e1:.2e} loop {e2:.2e} grid {e3:.2e} optimiser {e4:.2e} argmin-consistent {ok_idx} ({ll})")
+            eng.close()
+        except Exception as ex:  # noqa: BLE001
+            fails.append(f"{what}: {type(ex).__name__}: {str(ex)[:200]}")
+        if verbose and case % 20 == 19:
+            print(f"{case + 1} cases, {len(fails)} failures, worst f64 {worst['f64']:.2e} f32 {worst['f32']:.2e}, {time.time() - t0:.0f} s", flush=True)
+    return fails, worst, kernels
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+    fails, worst, kernels = run(n_cases, seed, verbose=True)
+    print(f"fuzz: {n_cases} cases (seed {seed}), kernels {kernels}, worst relative error f64 {worst['f64']:.2e} / f32 {worst['f32']:.2e}, {len(fails)} failures")
+    for f in fails[:30]:
+        print("  FAIL", f)
+    sys.exit(1 if fails else 0)
