@@ -236,6 +236,10 @@ __device__ __forceinline__ typename Sys::template Pre<real> load_pre(const KPara
 }
 
 // One classical RK4 step of the closed loop under a held (already clipped) action u: the build's
+// the value as it stands in a register: an empty asm the optimiser cannot see through (no instruction is emitted)
+__device__ __forceinline__ void pin_value(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_value(double& v) { asm volatile("" : "+v"(v)); }
+
 // replacement of scipy RK45 inside Simulator.sim_step (simulator.py:156-168).  Same operation order as
 // oracle rk4_step: x + h/6 * (((k1 + 2 k2) + 2 k3) + k4).
 template <typename Sys, typename real>
@@ -254,6 +258,18 @@ __device__ __forceinline__ void rk4_step(const typename Sys::template Pre<real>&
 #pragma unroll
   for (int c = 0; c < DS; ++c) t[c] = fma_r(h, k3[c], x[c]);
   Sys::template rhs<real>(pre, t, u, k4);
+  // k4 is used once, in the sum below, and a right-hand side usually ends in a multiply (1 / tau * (...), v * cos): under
+  // -ffp-contract=fast the compiler is free to fold that multiply into the "+ k4" - it did inside k_actor_dma_packed's fused env
+  // step and did not inside k_sim / k_ticks, and one state component in a thousand came out one ulp apart (found by
+  // tools/fuzz_parity.py, round 6; a contract(off) pragma does not reach the backend's fusion in this mode).  Every kernel that
+  // steps an env must produce the same bits: the slopes are pinned as rounded values before they are combined.
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    pin_value(k1[c]);
+    pin_value(k2[c]);
+    pin_value(k3[c]);
+    pin_value(k4[c]);
+  }
 #pragma unroll
   for (int c = 0; c < DS; ++c) x[c] = fma_r(h6, ((k1[c] + (real)2 * k2[c]) + (real)2 * k3[c]) + k4[c], x[c]);
 }

@@ -1,0 +1,17 @@
+"""Randomised differential test (GPU): tools/fuzz_parity.py's random configurations - system, element type, mode, critic and stage-cost
+structure, target, discount, horizon, K, batch, TD rows - through the streamed operator / argmin, closed-loop ticks with the critic
+fit, the generated grid, the on-device optimiser and T ticks per call, every number against the oracle.  A fixed seed here; the tool
+runs any number of cases with any seed (profiles/r06_fuzz.txt).  tests/test_hip_fuzz.py is the older seeded sweep of the streamed operator alone."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_configurations_vs_oracle(seed):
+    from tools.fuzz_parity import run
+
+    fails, worst, kernels = run(60, seed)
+    assert not fails, "\n".join(fails[:10])
+    assert worst["f64"] < 1e-10 and worst["f32"] < 2e-5, worst
+    assert {"k_actor_dma", "k_actor"} <= set(kernels), kernels
