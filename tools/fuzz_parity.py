@@ -114,7 +114,11 @@ def run(n_cases, seed, verbose=False):
             bjg_or, big_or = O.argmin_first(Jg)
             e3 = rel_err_norm(bjg, bjg_or) if dtype == "f64" else float(np.max(np.abs(bjg - bjg_or)) / max(float(np.max(np.abs(Jg))), 1.0))
             if dtype == "f64" and not np.array_equal(big, big_or):
-                fails.append(f"{what}: generated grid K={Kg}: best_idx differs from the oracle's")
+                # a mirrored pair of grid levels can tie exactly (a cost that only sees u^2: RQL at Nactor = 1): whichever of the
+                # two the rounding of the level favours is a correct argmin - anything else is a failure
+                sel = Jg[np.arange(B), big]
+                if not np.all(sel <= bjg_or + 1e-12 * np.maximum(np.abs(bjg_or), 1.0)):
+                    fails.append(f"{what}: generated grid K={Kg}: best_idx differs from the oracle's and is no tie")
             # 4. the on-device optimiser against its oracle twin (float64: the same walk)
             e4 = 0.0
             if dtype == "f64" and B <= 17 and N <= 10 and not huge:
@@ -146,6 +150,61 @@ def run(n_cases, seed, verbose=False):
     return fails, worst, kernels
 
 
+def run_bits(n_cases, seed, verbose=False):
+    """Claims of bit-identity between code paths, no oracle involved, on batches large enough to meet one-in-a-thousand events:
+    T ticks in one native call (k_ticks / k_ticks_pk / k_ticks_mem, or the library's own loop) against T single ticks - streamed and
+    generated candidates, every mode - on STATE, ACTION, ACCUM, BEST_J, BEST_IDX and the critic's weights and buffers."""
+    from rcognita_amd import _native as Nn
+
+    rng = np.random.default_rng(seed)
+    fails, kernels = [], {}
+    for case in range(n_cases):
+        name = str(rng.choice(["3wrobot", "3wrobotNI", "2tank"]))
+        dtype = str(rng.choice(["f64", "f32"]))
+        mode = str(rng.choice(["MPC", "MPC", "RQL", "SQL"]))
+        cs = str(rng.choice(["quad-lin", "quadratic", "quad-nomix", "quad-mix"]))
+        N = int(rng.choice([1, 3, 5, 7, 10, 16]))
+        B = int(rng.choice([1024, 3000, 4096]))
+        generated = bool(rng.uniform() < 0.4)
+        du = 1 if name == "2tank" else 2
+        K = int(rng.choice([16, 64, 256] if du == 2 else [8, 64, 100, 256])) if generated else int(rng.choice([4, 8, 16, 32, 40, 64, 100]))
+        T = int(rng.integers(2, 6))
+        kw = dict(n_actor=N, gamma=float(rng.choice([1.0, 0.95])), mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs])
+        if mode != "MPC":
+            kw.update(buffer_size=int(rng.choice([4, 6, 10])), n_critic=int(rng.choice([2, 3, 4])))
+        what = f"bits case {case}: {name} {dtype} {mode} {cs} N={N} K={K} B={B} T={T} {'generated' if generated else 'streamed'}"
+        try:
+            x = rand_states(rng, name, B)
+            cand = None if generated else rand_actions(rng, name, (B, K, N), overshoot=1.1)
+            outs = []
+            for single in (False, True):
+                e, cfg = both(name, B, dtype, **kw)
+                e.set_state(x)
+                dcand = None if cand is None else e.to_device(cand.astype(e.real))
+                if single:
+                    for _ in range(T):
+                        e.control_tick(dcand, K=K)
+                else:
+                    e.control_tick(dcand, K=K, T=T)
+                ll = e.last_launch()
+                fields = [Nn.FIELD_STATE, Nn.FIELD_ACTION, Nn.FIELD_ACCUM, Nn.FIELD_BEST_J, Nn.FIELD_BEST_IDX, Nn.FIELD_STEP_IDX]
+                if mode != "MPC":
+                    fields += [Nn.FIELD_W_CRITIC, Nn.FIELD_W_PREV, Nn.FIELD_OBS_BUF, Nn.FIELD_ACT_BUF]
+                outs.append(([e.get_field(f).copy() for f in fields], ll))
+                e.close()
+            kernels[outs[0][1]["kernel"]] = kernels.get(outs[0][1]["kernel"], 0) + 1
+            for fi, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+                if not np.array_equal(a, b, equal_nan=True):
+                    nd = int(np.sum(a != b))
+                    fails.append(f"{what}: field #{fi} differs in {nd} of {a.size} entries (max {float(np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))):.2e}); one call: {outs[0][1]}, single: {outs[1][1]}")
+                    break
+        except Exception as ex:  # noqa: BLE001
+            fails.append(f"{what}: {type(ex).__name__}: {str(ex)[:200]}")
+        if verbose and case % 10 == 9:
+            print(f"bits: {case + 1} cases, {len(fails)} failures", flush=True)
+    return fails, kernels
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
@@ -153,4 +212,9 @@ if __name__ == "__main__":
     print(f"fuzz: {n_cases} cases (seed {seed}), kernels {kernels}, worst relative error f64 {worst['f64']:.2e} / f32 {worst['f32']:.2e}, {len(fails)} failures")
     for f in fails[:30]:
         print("  FAIL", f)
-    sys.exit(1 if fails else 0)
+    nb = max(n_cases // 5, 10)
+    bfails, bk = run_bits(nb, seed, verbose=True)
+    print(f"bit-identity of T ticks per call vs single ticks: {nb} cases on 1 024 - 4 096 envs, one-call kernels {bk}, {len(bfails)} failures")
+    for f in bfails[:30]:
+        print("  FAIL", f)
+    sys.exit(1 if fails or bfails else 0)
