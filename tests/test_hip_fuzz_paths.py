@@ -15,3 +15,14 @@ def test_random_configurations_vs_oracle(seed):
     assert not fails, "\n".join(fails[:10])
     assert worst["f64"] < 1e-10 and worst["f32"] < 2e-5, worst
     assert {"k_actor_dma", "k_actor"} <= set(kernels), kernels
+
+
+def test_random_bit_identity_and_loop_cases():
+    """T ticks per native call = T single ticks on 1 024 - 4 096 envs (every field, every mode, streamed and generated), and the drop-in
+    loop's rows with the next step started ahead = with one call per iteration = with the separate calls, on random configurations."""
+    from tools.fuzz_parity import run_bits, run_loop
+
+    fails, _ = run_bits(16, 3)
+    assert not fails, "\n".join(fails[:10])
+    fails = run_loop(10, 3)
+    assert not fails, "\n".join(fails[:10])

@@ -205,6 +205,39 @@ def run_bits(n_cases, seed, verbose=False):
     return fails, kernels
 
 
+def run_loop(n_cases, seed, verbose=False):
+    """The drop-in classes' loop (tests/test_hip_loop_step.py::_run: the reference's loop body on System / Simulator / CtrlOptPred) for
+    random systems, modes, critic structures, horizons, batches and element types: the rows with the next step started ahead, with one
+    native call per iteration, and with the separate calls must be the same bits."""
+    from tests.test_hip_loop_step import _run
+
+    rng = np.random.default_rng(seed)
+    fails = []
+    for case in range(n_cases):
+        name = str(rng.choice(["3wrobot", "3wrobotNI", "2tank"]))
+        mode = str(rng.choice(["MPC", "RQL", "SQL"]))
+        cs = str(rng.choice(["quad-lin", "quadratic", "quad-nomix", "quad-mix"]))
+        dtype = str(rng.choice(["f64", "f32"]))
+        Nactor = int(rng.choice([1, 2, 3, 5, 8]))
+        B = None if rng.uniform() < 0.5 else int(rng.choice([2, 3, 5, 9]))
+        T = int(rng.integers(6, 26))
+        what = f"loop case {case}: {name} {mode} {cs} {dtype} Nactor={Nactor} B={B} T={T}"
+        try:
+            ahead, c2 = _run(name, mode, cs, True, T, B=B, dtype=dtype, Nactor=Nactor, speculate=True)
+            fused, c1 = _run(name, mode, cs, True, T, B=B, dtype=dtype, Nactor=Nactor, speculate=False)
+            plain, c0 = _run(name, mode, cs, False, T, B=B, dtype=dtype, Nactor=Nactor)
+            if not (np.array_equal(ahead, fused, equal_nan=True) and np.array_equal(ahead, plain, equal_nan=True)):
+                bad = np.argwhere(~((ahead == plain) | (np.isnan(ahead) & np.isnan(plain))))
+                fails.append(f"{what}: rows differ (first at row/col {bad[0].tolist() if len(bad) else '?'}); hits {c2.spec_hits} drops {c2.spec_drops} fused {c1.fused_steps}")
+            elif c2.spec_hits < T - 4:
+                fails.append(f"{what}: only {c2.spec_hits} of {T} iterations were started ahead ({c2.spec_drops} dropped)")
+        except Exception as ex:  # noqa: BLE001
+            fails.append(f"{what}: {type(ex).__name__}: {str(ex)[:200]}")
+        if verbose and case % 10 == 9:
+            print(f"loop: {case + 1} cases, {len(fails)} failures", flush=True)
+    return fails
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
@@ -217,4 +250,9 @@ if __name__ == "__main__":
     print(f"bit-identity of T ticks per call vs single ticks: {nb} cases on 1 024 - 4 096 envs, one-call kernels {bk}, {len(bfails)} failures")
     for f in bfails[:30]:
         print("  FAIL", f)
-    sys.exit(1 if fails or bfails else 0)
+    nl = max(n_cases // 10, 10)
+    lfails = run_loop(nl, seed, verbose=True)
+    print(f"drop-in loop, next step started ahead / one call per iteration / separate calls: {nl} random cases, {len(lfails)} failures")
+    for f in lfails[:30]:
+        print("  FAIL", f)
+    sys.exit(1 if fails or bfails or lfails else 0)
