@@ -306,12 +306,15 @@ int rcg_control_tick(rcg_handle* h, const void* cand, int32_t K);
 /* T consecutive rcg_control_tick(h, NULL, K) - the loop of presets/main_3wrobot.py:415-468 for T sampling periods with
  * the generated candidate grid - in ONE kernel launch: each env's wave keeps state, held action, ACCUM and STEP_IDX (and,
  * with the disturbance model, the disturbance state and the noise counter) in registers and loops over {sim_step, K x
- * _actor_cost, argmin, upd_accum_obj}.  Every field ends bit-identical to T single ticks on the library as built (same
- * source expressions; tests/test_hip_ticks.py checks it for every system, element type and shape).  Across compilers the
- * contract is "within rounding" for Sys2Tank: its rollout right-hand side leaves the choice of fused multiply-adds to the
- * compiler (18-26 % faster than the written-out form), and k_ticks and k_actor inline it at different call sites; the robots'
- * right-hand sides and every simulator step write their fusions out.  A checkpoint taken under one entry point and resumed
- * under the other inherits the same caveat.  BEST_J / BEST_IDX are the last tick's.  MPC handles: any stage-cost structure,
+ * _actor_cost, argmin, upd_accum_obj}.  Every field ends bit-identical to T single ticks (same source expressions;
+ * tests/test_hip_ticks.py checks it for every system, element type and shape) - with ONE stated exception, Sys2Tank's BEST_J:
+ * its rollout right-hand side leaves the choice of fused multiply-adds to the compiler (18-26 % faster than the written-out
+ * form), and the persistent kernels and the per-tick kernels inline it into different surroundings, so a cost may differ by a
+ * rounding of its terms (measured on the library as built, float32, streamed candidates: BEST_J of one env in about 4 000, by 1 to
+ * 40 ulp where the critic's signed terms cancel; tools/fuzz_parity.py).
+ * The decision - and with it STATE, ACTION, ACCUM and everything downstream - differs only where two candidates' costs tie to the
+ * last bit.  The robots' right-hand sides and every simulator step (one set of bits in every kernel: rk4_step) write their fusions
+ * out.  A checkpoint taken under one entry point and resumed under the other inherits the same caveat.  BEST_J / BEST_IDX are the last tick's.  MPC handles: any stage-cost structure,
  * with or without RCG_FLAG_DISTURB.  RQL / SQL handles (1 <= Ncritic - 1 <= 8, no disturbance model, the preset's observation
  * target setting): the two launches of a tick - env step + buffer push + critic fit, then the decision - run as phases of
  * one persistent launch (k_ticks_mem), same functions on the same memory, bit-identical as well (critic structures with 20 or
@@ -328,7 +331,8 @@ int rcg_control_ticks(rcg_handle* h, int32_t T, int32_t K);
  * tensor with the accumulation order of k_actor_dma / k_actor_dma_packed, the kernels of the single ticks); larger batches issue
  * the launches of T single ticks without T trips through the
  * caller's FFI (a Python caller needs ~12 us per call, and a GPU that idles between short ticks clocks down).  Either way
- * every field ends as T single calls leave it, bit for bit; stops at the first error. */
+ * every field ends as T single calls leave it, bit for bit (Sys2Tank's BEST_J: to a rounding of its terms - see
+ * rcg_control_ticks); stops at the first error. */
 int rcg_control_tick_n(rcg_handle* h, const void* cand, int32_t K, int32_t T);
 /* A tick in two halves.  An RQL / SQL handle whose decision streams a caller's tensor through k_actor_dma (no disturbance
  * model, 1 .. 8 TD rows) runs rcg_control_tick for the envs [0, B / 2) and [B / 2, B) on two internal streams: the critic fit of
