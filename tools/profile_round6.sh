@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6 evidence on a GPU box (one gpurun call each part; run from the repo root through gpurun):
 #   gpurun --timeout 1200 -- 'PART=1 bash tools/profile_round6.sh'     bench line + kernel traces (f64 headline, f32) + FETCH / WRITE
-#   gpurun --timeout 1200 -- 'PART=2 bash tools/profile_round6.sh'     the other bench shapes and probes
+#   gpurun --timeout 1200 -- 'PART=2 bash tools/profile_round6.sh'     the other bench shapes and probes (PART=3: configs kernel trace, PART=4: fuzz, soak, presets, B = 1)
 # then, back in the build container (see tools/prof_summary.py):
 #   python tools/prof_summary.py --round r06 --tag f64 --kt gpurun_out/prof_kt_f64 --fetch gpurun_out/prof_fetch_f64 \
 #       --write gpurun_out/prof_write_f64 --key k_actor_streamed_3wrobot_B65536_K256_N10_f64
@@ -55,4 +55,12 @@ if [ "$PART" = 3 ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_configs_r06 -o kt -- \
   python3 tools/bench_configs.py > gpurun_out/bench_configs_r06_profiled.json 2> gpurun_out/prof_kt_configs_r06.log
 python tools/bench_configs.py > gpurun_out/bench_configs_r06.json 2> gpurun_out/bench_configs_r06.err
+fi
+if [ "$PART" = 4 ]; then
+# the randomised differential run (oracle as the checker) and the soak
+python tools/fuzz_parity.py 1500 31337 2>/dev/null | grep -v amdgpu | tail -4 > gpurun_out/r06_fuzz_tail.txt
+python tools/soak_r06.py 2>/dev/null | grep -v amdgpu > gpurun_out/r06_soak.txt
+python tools/preset_timing.py 2>/dev/null | grep -v amdgpu > gpurun_out/r06_preset_timing.txt
+python tools/b1_profile.py 2>/dev/null | grep -v amdgpu | head -4 > gpurun_out/r06_b1_profile_head.txt
+cat gpurun_out/r06_fuzz_tail.txt gpurun_out/r06_b1_profile_head.txt
 fi
