@@ -72,3 +72,31 @@ def test_env_step_bits_are_the_same_in_every_kernel(name, dtype):
         st, _, _, _, _ = e.loop_step(a0[:Bs], float(cfg.dt_sim), 1, decide=decide, iters=2)
         np.testing.assert_array_equal(st.astype(ref.dtype), ref[:Bs], err_msg=f"loop step decide={decide}")
     e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_vector_env_step_of_the_tank_is_the_same_bits(dtype):
+    """k_sim_v (16 bytes per lane and component: the tank from 2^18 envs) against k_sim on the same envs."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(6)
+    B = 1 << 18
+    x = rand_states(rng, "2tank", B)
+    a0 = rand_actions(rng, "2tank", (B,), overshoot=1.2)
+    big, _ = both("2tank", B, dtype, n_actor=3)
+    big.set_state(x)
+    big.set_field(N.FIELD_ACTION, a0)
+    big.sim_step(2)
+    assert big.last_launch(N.KERNEL_SIM)["kernel"] == "k_sim_v", big.last_launch(N.KERNEL_SIM)
+    got = big.get_state()
+    big.close()
+    Bs = 1 << 16
+    small, _ = both("2tank", Bs, dtype, n_actor=3)
+    for i in range(0, B, Bs):
+        small.set_state(x[i:i + Bs])
+        small.set_field(N.FIELD_STATUS, np.zeros(Bs, dtype=np.uint32))
+        small.set_field(N.FIELD_ACTION, a0[i:i + Bs])
+        small.sim_step(2)
+        assert small.last_launch(N.KERNEL_SIM)["kernel"] == "k_sim"
+        np.testing.assert_array_equal(got[i:i + Bs], small.get_state(), err_msg=f"envs {i} ..")
+    small.close()
