@@ -133,6 +133,21 @@ __device__ __forceinline__ void rk4_step_full(const typename Sys::template Pre<r
 #pragma unroll
   for (int c = 0; c < DD; ++c) s[c] = fma_r(h, l3[c], q[c]);
   rhs_full<Sys, real>(pre, D, t, s, u, xi, k4, l4);
+  // (the slopes as rounded values before they are combined: rk4_step, rcg_kernels.hpp - one set of bits in k_sim_dist and k_ticks)
+#pragma unroll
+  for (int c = 0; c < DS; ++c) {
+    pin_value(k1[c]);
+    pin_value(k2[c]);
+    pin_value(k3[c]);
+    pin_value(k4[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < DD; ++c) {
+    pin_value(l1[c]);
+    pin_value(l2[c]);
+    pin_value(l3[c]);
+    pin_value(l4[c]);
+  }
 #pragma unroll
   for (int c = 0; c < DS; ++c) x[c] = fma_r(h6, ((k1[c] + (real)2 * k2[c]) + (real)2 * k3[c]) + k4[c], x[c]);
 #pragma unroll

@@ -100,3 +100,33 @@ def test_vector_env_step_of_the_tank_is_the_same_bits(dtype):
         assert small.last_launch(N.KERNEL_SIM)["kernel"] == "k_sim"
         np.testing.assert_array_equal(got[i:i + Bs], small.get_state(), err_msg=f"envs {i} ..")
     small.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name", SYSTEMS)
+def test_disturbed_env_step_bits_in_one_launch_and_in_single_ticks(name, dtype):
+    """The env step with the disturbance model (rk4_step_full on [state, disturb]) inside k_ticks against k_sim_dist, 4 096 envs:
+    STATE and DISTURB after 3 ticks in one launch = after 3 single ticks (tests/test_hip_ticks.py holds the same on 261 envs; a
+    one-in-a-thousand rounding needs more)."""
+    from rcognita_amd import _native as N
+
+    rng = np.random.default_rng(9)
+    B, T, Nh, K = 4096, 3, 5, 64
+    dist = dict(is_disturb=True, pars_disturb=[[30.0, 10.0], [0.5, -0.2], [2.0, 1.5]], disturb_init=[1.0, -2.0], seed=31,
+                env_id_base=5_000_000_000)
+    x0 = rand_states(rng, name, B)
+    out = []
+    for one_launch in (True, False):
+        e, _ = both(name, B, dtype, n_actor=Nh, substeps_per_tick=2, engine_only=dist)
+        e.set_state(x0)
+        if one_launch:
+            e.control_ticks(T, K)
+            assert e.last_launch()["kernel"] == "k_ticks"
+        else:
+            for _ in range(T):
+                e.control_tick(None, K=K)
+            assert e.last_launch(N.KERNEL_SIM)["kernel"] == "k_sim_dist"
+        out.append((e.get_state().copy(), e.get_field(N.FIELD_DISTURB).copy()))
+        e.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
