@@ -248,6 +248,69 @@ def run_loop(n_cases, seed, verbose=False):
     return fails
 
 
+def run_loop_step(n_cases, seed, verbose=False):
+    """rcg_loop_step against the separate calls (set ACTION, rcg_sim_step_h, rcg_critic_update, rcg_actor_optimize, rcg_stage_obj) on a
+    twin handle, batches as large as the entry point takes: state, action, stage cost, best_J, weights - the same bits (the claim of
+    rcg.h; tests/test_hip_loop_step.py holds it on four shapes of up to 7 envs)."""
+    from rcognita_amd import _native as Nn
+
+    rng = np.random.default_rng(seed)
+    fails = []
+    for case in range(n_cases):
+        name = str(rng.choice(["3wrobot", "3wrobotNI", "2tank"]))
+        mode = str(rng.choice(["MPC", "MPC", "RQL", "SQL"]))
+        cs = str(rng.choice(["quad-lin", "quadratic", "quad-nomix", "quad-mix"]))
+        dtype = str(rng.choice(["f64", "f32"]))
+        Nactor = int(rng.choice([1, 3, 5, 8]))
+        kw = dict(n_actor=Nactor, mode=O.MODE_IDS[mode], critic_struct=O.CRITIC_IDS[cs], n_critic=int(rng.choice([2, 3, 4])), buffer_size=6)
+        what = f"loop_step case {case}: {name} {mode} {cs} {dtype} Nactor={Nactor}"
+        try:
+            probe, cfg = both(name, 1, dtype, **kw)
+            row = cfg.ds + cfg.du + 2 + (cfg.dc if mode != "MPC" else 0)
+            probe.close()
+            B = int(min(200, (16384 // 8 - 1) // (row + cfg.du + 1)))  # what fits the 16-KB pinned buffer
+            a, _ = both(name, B, dtype, **kw)
+            b, _ = both(name, B, dtype, **kw)
+            x0 = rand_states(rng, name, B)
+            a.set_state(x0)
+            b.set_state(x0)
+            act = rand_actions(rng, name, (B,), overshoot=0.9)
+            h = cfg.dt_sim / 2
+            for it in range(int(rng.integers(6, 14))):
+                decide = it % 2 == 1
+                push = mode != "MPC" and decide
+                fit = push and it % 4 == 1
+                st, ac, stage, bj, w = a.loop_step(act, h, 1, decide=decide, push=push, fit=fit, iters=4)
+                b.set_field(Nn.FIELD_ACTION, act)
+                b.sim_step(1, step=h)
+                if push:
+                    b.critic_update(do_fit=fit)
+                xs = b.get_field(Nn.FIELD_STATE_PREV)
+                st_b = b.get_state()
+                if decide:
+                    a_b, _, bj_b, _ = b.actor_optimize(iters=4, obs=st_b, state_sys=xs)
+                    b.set_field(Nn.FIELD_ACTION, a_b)
+                else:
+                    a_b, bj_b = act.astype(b.real), None
+                stage_b = b.stage_obj(st_b, a_b)
+                bad = [n for n, u, v in (("state", st, st_b), ("action", ac, a_b), ("stage", stage, stage_b)) if not np.array_equal(u, np.asarray(v, dtype=np.float64))]
+                if decide and not np.array_equal(bj, bj_b.astype(np.float64)):
+                    bad.append("best_J")
+                if mode != "MPC" and not np.array_equal(w, b.get_field(Nn.FIELD_W_CRITIC).astype(np.float64)):
+                    bad.append("w_critic")
+                if bad:
+                    fails.append(f"{what} B={B} iteration {it}: {bad} differ")
+                    break
+                act = np.asarray(ac, dtype=np.float64).copy()
+            a.close()
+            b.close()
+        except Exception as ex:  # noqa: BLE001
+            fails.append(f"{what}: {type(ex).__name__}: {str(ex)[:200]}")
+        if verbose and case % 10 == 9:
+            print(f"loop_step: {case + 1} cases, {len(fails)} failures", flush=True)
+    return fails
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
@@ -265,4 +328,8 @@ if __name__ == "__main__":
     print(f"drop-in loop, next step started ahead / one call per iteration / separate calls: {nl} random cases, {len(lfails)} failures")
     for f in lfails[:30]:
         print("  FAIL", f)
-    sys.exit(1 if fails or bfails or lfails else 0)
+    sfails = run_loop_step(nl, seed, verbose=True)
+    print(f"rcg_loop_step against the separate calls, up to 200 envs: {nl} random cases, {len(sfails)} failures")
+    for f in sfails[:30]:
+        print("  FAIL", f)
+    sys.exit(1 if fails or bfails or lfails or sfails else 0)
